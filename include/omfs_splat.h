@@ -1,0 +1,180 @@
+/*
+ * omfs_splat.h -- C ABI of libomfs_splat.so: the MI355X (gfx950) engine behind the
+ * reference's process boundary.
+ *
+ * What this replaces.  The reference has no FFI: `02_Visual_Engine/train_ghost.py:227-271`
+ * and `02_Visual_Engine/render_surgery.py:289-315` spawn `gaussian_avatars_repo/train.py`
+ * and `.../render.py` (un-vendored, `.gitignore:27`), whose per-iteration work is the
+ * FLAME-mesh-bound Gaussian splat.  Each entry point below is one stage of that absent
+ * engine (SURVEY.md §8a row a-13, §8b "inner contract"); the Python engine
+ * (`omfs_4d_video_gen_amd/engine/`) binds them with ctypes and is what `train.py` /
+ * `render.py` in that directory run.  `omfs_simpleflame_*` replace the tensor math of
+ * `02_Visual_Engine/flame_fitter.py:154-197` (forward) and `:377-413` (fit loop).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless the name ends in _host;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing syncs;
+ *  - no hidden allocation, no global state; scratch comes in through the structs;
+ *  - return 0 on success, a negative OMFS_ERR_* otherwise, text via omfs_last_error()
+ *    (thread-local);
+ *  - fp32 throughout; Gaussian parameters are a planar SoA `params[59][n_pad]`
+ *    (plane order: OMFS_P_* below), n_pad a multiple of 256.
+ */
+#ifndef OMFS_SPLAT_H
+#define OMFS_SPLAT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OMFS_ABI_VERSION 1
+#define OMFS_TILE 16
+#define OMFS_NPLANES 59
+#define OMFS_P_XYZ 0      /* 3 planes: local position in the parent triangle frame          */
+#define OMFS_P_SCALE 3    /* 3 planes: log scale (triangle-relative)                         */
+#define OMFS_P_ROT 6      /* 4 planes: quaternion w,x,y,z (un-normalised)                    */
+#define OMFS_P_OPACITY 10 /* 1 plane : opacity logit                                         */
+#define OMFS_P_SH 11      /* 48 planes: SH coefficient k, channel c at 11 + 3*k + c          */
+#define OMFS_FLAME_JOINTS 5
+#define OMFS_FLAME_POSEDIRS 36
+
+#define OMFS_OK 0
+#define OMFS_ERR_ARG (-1)
+#define OMFS_ERR_HIP (-2)
+#define OMFS_ERR_CAPACITY (-3)
+
+/* status word bits written by the device (omfs_raster_buffers.status) */
+#define OMFS_STATUS_DUP_OVERFLOW 1u  /* sum of tiles touched exceeded dup_capacity: frame left empty */
+
+int omfs_abi_version(void);
+const char* omfs_last_error(void);
+
+/* ------------------------------------------------------------------ FLAME rig -> vertices
+ * Replaces (and completes: SimpleFLAME has no LBS) flame_fitter.py:154-197 for the engine. */
+typedef struct omfs_flame_rig {
+  int n_verts;              /* V                                                               */
+  int v_pad;                /* V rounded up to 16                                              */
+  int n_expr;               /* expression coefficients used per frame (<=100)                  */
+  int k_pad;                /* n_expr + 36 rounded up to 16                                    */
+  const float* basis_tiled; /* [3][v_pad/16][k_pad/16][64][4]  MFMA-A tiles, see DESIGN.md     */
+  const float* v_static;    /* [3][v_pad]   template + shape blendshapes + static_offset       */
+  const float* lbs_weights; /* [v_pad][8]   5 skinning weights + 3 zero pads                   */
+  const float* j_static;    /* [5][3]       J_regressor . v_static                             */
+  const float* j_expr;      /* [15][n_expr] J_regressor . exprdirs                             */
+} omfs_flame_rig;
+
+/* Joint transforms + blendshape coefficients for `n_frames` frames.
+ * expr [n_frames][n_expr], rotmats [n_frames][5][9] row-major, translation unused here.
+ * Writes joint_xf [n_frames][5][12] (R row-major 9, t 3) and coef [k_pad][b_pad]
+ * (b_pad = n_frames rounded up to 16; rows: expr, then 36 pose features, then zeros). */
+int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, const float* rotmats,
+                      int n_frames, float* joint_xf, float* coef, void* stream);
+
+/* verts [n_frames][v_pad][4] = LBS(v_static + basis . coef) (+ dynamic_offset) + translation.
+ * dynamic_offset may be NULL; layout [n_frames][V][3]. translation [n_frames][3]. */
+int omfs_flame_lbs(const omfs_flame_rig* rig, const float* coef, const float* joint_xf,
+                   const float* translation, const float* dynamic_offset, int n_frames,
+                   float* verts, void* stream);
+
+/* face_xf [n_frames][n_faces][16]: R row-major (columns a0,n,a2) 9, centre 3, scale 1, pad 3 */
+int omfs_face_frames(const float* verts, int v_pad, const int32_t* faces, int n_faces, int n_frames,
+                     float* face_xf, void* stream);
+
+/* ------------------------------------------------------------------ rasteriser */
+typedef struct omfs_camera {
+  float view[12];   /* world->view, rows of [R|t] (3x4 row-major)                               */
+  float cam_pos[3];
+  float fx, fy;
+  float cx, cy;     /* (width-1)/2, (height-1)/2                                                */
+  float limx, limy; /* 1.3*tan(fov/2)                                                           */
+  int width, height;
+  int sh_degree;
+  float bg[3];
+} omfs_camera;
+
+typedef struct omfs_gaussians {
+  int n;                  /* Gaussians                                                          */
+  int n_pad;              /* plane stride (multiple of 256)                                     */
+  const float* params;    /* [59][n_pad]                                                        */
+  const int32_t* binding; /* [n] parent face                                                    */
+} omfs_gaussians;
+
+typedef struct omfs_raster_buffers {
+  /* per Gaussian (written by project_fwd) */
+  float* g0;              /* [n][4] mean2d.x, mean2d.y, conic.a, conic.b                         */
+  float* g1;              /* [n][4] conic.c, opacity, r, g                                       */
+  float* g2;              /* [n][4] b, depth, bits(radius | clamp<<28), bits(rect x0|y0<<8|x1<<16|y1<<24) */
+  /* binning */
+  uint32_t* tile_count;   /* [n_tiles]                                                           */
+  uint32_t* tile_start;   /* [n_tiles+1] exclusive scan; [n_tiles] = D                           */
+  uint32_t* tile_cursor;  /* [n_tiles] scratch                                                   */
+  uint32_t* tile_order;   /* [n_tiles] tiles by descending count bucket                          */
+  uint32_t* keys;         /* [dup_capacity][2] (depth bits, gaussian id), tile-segmented         */
+  uint32_t* keys_tmp;     /* [dup_capacity][2] scratch for tiles longer than the LDS capacity    */
+  uint32_t* sorted_ids;   /* [dup_capacity] per-tile front-to-back Gaussian ids                  */
+  uint32_t dup_capacity;
+  uint32_t sort_lds_pairs; /* pairs per tile sorted inside LDS (0 = default 4096; 16 B of LDS each); longer
+                              tiles are sorted through keys/keys_tmp                              */
+  uint32_t* status;       /* [1] OMFS_STATUS_* bits, OR-ed by kernels (caller zeroes)            */
+  /* per pixel */
+  float* image;           /* [3][height][width]                                                  */
+  float* final_T;         /* [height][width]                                                     */
+  uint32_t* n_contrib;    /* [height][width]                                                     */
+} omfs_raster_buffers;
+
+/* deform + project + colour for one view; zeroes and fills tile_count. face_xf [n_faces][16]. */
+int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_camera* cam,
+                     const omfs_raster_buffers* rb, void* stream);
+/* scan tile_count -> tile_start/tile_order, scatter (depth,id) keys, per-tile radix depth sort */
+int omfs_bin_sort(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
+/* front-to-back alpha composite -> image, final_T, n_contrib */
+int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
+/* image [3][H][W] fp32 -> rgb8 [H][W][3], clamp to [0,1], round(x*255) */
+int omfs_image_to_rgb8(const float* image, int width, int height, uint8_t* rgb8, void* stream);
+
+/* ------------------------------------------------------------------ backward + optimiser */
+typedef struct omfs_grad_buffers {
+  float* dsplat;          /* [n][16] per-Gaussian 2D-splat gradient record (atomically accumulated):
+                             dmean2d.xy, dconic.abc, dopacity, drgb, |dmean2d| ... ; caller zeroes */
+  float* grads;           /* [59][n_pad] parameter gradients (overwritten)                         */
+  const float* dimage;    /* [3][H][W] dL/dimage                                                   */
+} omfs_grad_buffers;
+
+int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, const omfs_grad_buffers* gb, void* stream);
+
+typedef struct omfs_reg_params {
+  float lambda_xyz, thr_xyz, lambda_scale, thr_scale;
+  const uint32_t* n_visible; /* device word: #visible Gaussians of this view (omfs_count_visible); the
+                                regularisers are means over the visible Gaussians                   */
+} omfs_reg_params;
+
+int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, const omfs_camera* cam,
+                     const omfs_raster_buffers* rb, const omfs_grad_buffers* gb,
+                     const omfs_reg_params* reg, void* stream);
+
+/* (1-lambda) L1 + lambda (1-SSIM), 11x11 gaussian window, zero padding.
+ * Writes dimage [3][H][W] and adds the scalar loss into loss_out[0] (caller zeroes).
+ * scratch: 3 * 3*H*W floats. */
+int omfs_loss_l1_ssim(const float* image, const float* target, int width, int height, float lambda_dssim,
+                      float* dimage, float* loss_out, float* scratch, void* stream);
+
+typedef struct omfs_adam_params {
+  float lr[OMFS_NPLANES]; /* learning rate per plane                                              */
+  float beta1, beta2, eps;
+  int step;               /* 1-based                                                              */
+  float grad_scale;       /* multiply gradients (1/world_size after a sum all-reduce)             */
+} omfs_adam_params;
+
+/* torch.optim.Adam semantics on params/m/v [59][n_pad] */
+int omfs_adam_step(float* params, const float* grads, float* m, float* v, int n, int n_pad,
+                   const omfs_adam_params* ap, void* stream);
+
+/* #Gaussians with radius>0 of the last projected view -> count_out[0] (device) */
+int omfs_count_visible(const omfs_raster_buffers* rb, int n, uint32_t* count_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OMFS_SPLAT_H */

@@ -1,0 +1,122 @@
+"""ctypes binding of libomfs_splat.so (C ABI declared in include/omfs_splat.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or a call fails the
+engine raises.  `torch` is imported first so that the library binds to the HIP runtime that
+PyTorch-ROCm has already loaded (same SONAME, libamdhip64.so.7) and device pointers of torch
+tensors are valid in our kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
+ABI_VERSION = 1
+NPLANES = 59
+TILE = 16
+
+c_float_p = C.POINTER(C.c_float)
+c_u32_p = C.POINTER(C.c_uint32)
+c_i32_p = C.POINTER(C.c_int32)
+c_void_p = C.c_void_p
+
+
+class OmfsError(RuntimeError):
+    pass
+
+
+class FlameRigC(C.Structure):
+    _fields_ = [("n_verts", C.c_int), ("v_pad", C.c_int), ("n_expr", C.c_int), ("k_pad", C.c_int),
+                ("basis_tiled", c_void_p), ("v_static", c_void_p), ("lbs_weights", c_void_p),
+                ("j_static", c_void_p), ("j_expr", c_void_p)]
+
+
+class CameraC(C.Structure):
+    _fields_ = [("view", C.c_float * 12), ("cam_pos", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("limx", C.c_float), ("limy", C.c_float),
+                ("width", C.c_int), ("height", C.c_int), ("sh_degree", C.c_int), ("bg", C.c_float * 3)]
+
+
+class GaussiansC(C.Structure):
+    _fields_ = [("n", C.c_int), ("n_pad", C.c_int), ("params", c_void_p), ("binding", c_void_p)]
+
+
+class RasterBuffersC(C.Structure):
+    _fields_ = [("g0", c_void_p), ("g1", c_void_p), ("g2", c_void_p),
+                ("tile_count", c_void_p), ("tile_start", c_void_p), ("tile_cursor", c_void_p),
+                ("tile_order", c_void_p), ("keys", c_void_p), ("keys_tmp", c_void_p), ("sorted_ids", c_void_p),
+                ("dup_capacity", C.c_uint32), ("sort_lds_pairs", C.c_uint32), ("status", c_void_p),
+                ("image", c_void_p), ("final_T", c_void_p), ("n_contrib", c_void_p)]
+
+
+class GradBuffersC(C.Structure):
+    _fields_ = [("dsplat", c_void_p), ("grads", c_void_p), ("dimage", c_void_p)]
+
+
+class RegParamsC(C.Structure):
+    _fields_ = [("lambda_xyz", C.c_float), ("thr_xyz", C.c_float), ("lambda_scale", C.c_float),
+                ("thr_scale", C.c_float), ("n_visible", c_void_p)]
+
+
+class AdamParamsC(C.Structure):
+    _fields_ = [("lr", C.c_float * NPLANES), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("step", C.c_int), ("grad_scale", C.c_float)]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
+SIGNATURES = {
+    "omfs_abi_version": (C.c_int, []),
+    "omfs_last_error": (C.c_char_p, []),
+    "omfs_flame_joints": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p]),
+    "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
+    "omfs_project_fwd": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
+    "omfs_bin_sort": (C.c_int, [C.POINTER(GaussiansC), C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
+    "omfs_composite_fwd": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
+    "omfs_image_to_rgb8": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
+    "omfs_composite_bwd": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), C.POINTER(GradBuffersC), c_void_p]),
+    "omfs_project_bwd": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC),
+                                   C.POINTER(GradBuffersC), C.POINTER(RegParamsC), c_void_p]),
+    "omfs_loss_l1_ssim": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "omfs_adam_step": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), c_void_p]),
+    "omfs_count_visible": (C.c_int, [C.POINTER(RasterBuffersC), C.c_int, c_void_p, c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the library (once).  Raises OmfsError if it is not built: no fallback exists."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OmfsError(f"{LIB_PATH} not found: build it with omfs_4d_video_gen_amd/csrc/build.sh "
+                        "(or __graft_entry__.build()); the engine has no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.omfs_abi_version()
+    if v != ABI_VERSION:
+        raise OmfsError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise OmfsError(f"{what} failed ({rc}): {load().omfs_last_error().decode()}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream

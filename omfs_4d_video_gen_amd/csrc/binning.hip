@@ -1,0 +1,232 @@
+// Tile binning: scan of per-tile hit counts, key scatter, per-tile radix depth sort in LDS.
+//
+// Design (DESIGN.md "Binning"): instead of the upstream single global 64-bit radix sort of
+// (tile<<32 | depth) keys the D = sum(tiles touched) pairs are
+// counting-sorted by tile (counts come from project_fwd's atomics, offsets from one small scan,
+// placement by a per-tile cursor) and each tile's segment is then sorted on its own by a 4x8-bit
+// LSD radix sort that lives entirely in LDS (160 KB per CU on gfx950): wave-level digit matching
+// (ballots) gives stable ranks, per-wave digit tables give the offsets.  Arrival order inside a
+// tile is arbitrary (atomics), so equal depths are finally ordered by Gaussian id: the result is
+// exactly the order of the upstream stable global sort whose emission order is the Gaussian index.
+// HBM traffic: write 8 B + read 8 B + write 4 B per pair, versus ~24 B x 6 passes for the global sort.
+#include "common.hpp"
+
+namespace omfs {
+
+// ------------------------------------------------------------------ scan + launch order
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* __restrict__ tile_count,
+                                                         uint32_t* __restrict__ tile_start,
+                                                         uint32_t* __restrict__ tile_cursor,
+                                                         uint32_t* __restrict__ tile_order, uint32_t dup_capacity,
+                                                         uint32_t* __restrict__ status) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t bucket_cnt[33];
+  __shared__ uint32_t bucket_off[33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n_tiles + 1023) / 1024;
+  const int beg = min(n_tiles, tid * per), end = min(n_tiles, beg + per);
+  if (tid < 33) bucket_cnt[tid] = 0;
+  uint32_t sum = 0;
+  for (int t = beg; t < end; ++t) sum += tile_count[t];
+  uint32_t incl = wave_incl_scan_u32(sum, lane);
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    uint32_t v = wave_tot[w];
+    if (w < wave) base += v;
+    total += v;
+  }
+  const bool overflow = total > dup_capacity;
+  uint32_t run = base + incl - sum;
+  for (int t = beg; t < end; ++t) {
+    uint32_t c = tile_count[t];
+    if (overflow) { c = 0; tile_count[t] = 0; }
+    tile_start[t] = overflow ? 0u : run;
+    tile_cursor[t] = 0;
+    run += c;
+    int bucket = c ? (32 - __clz(c)) : 0;  // 0..32, larger = more work
+    atomicAdd(&bucket_cnt[32 - bucket], 1u);
+  }
+  if (tid == 0) {
+    tile_start[n_tiles] = overflow ? 0u : total;
+    if (overflow) atomicOr(status, OMFS_STATUS_DUP_OVERFLOW);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t r = 0;
+    for (int b = 0; b < 33; ++b) { bucket_off[b] = r; r += bucket_cnt[b]; }
+  }
+  __syncthreads();
+  for (int t = beg; t < end; ++t) {
+    uint32_t c = tile_count[t];
+    int bucket = c ? (32 - __clz(c)) : 0;
+    uint32_t pos = atomicAdd(&bucket_off[32 - bucket], 1u);
+    tile_order[pos] = (uint32_t)t;
+  }
+}
+
+// ------------------------------------------------------------------ key scatter
+__global__ __launch_bounds__(256) void scatter_keys_kernel(int n, const float4* __restrict__ g2, int gx, int n_tiles,
+                                                           const uint32_t* __restrict__ tile_start,
+                                                           uint32_t* __restrict__ tile_cursor, uint2* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (tile_start[n_tiles] == 0u) return;  // nothing visible, or capacity overflow (flagged by the scan)
+  const float4 r = g2[i];
+  const uint32_t rect = __float_as_uint(r.w);
+  if (rect == 0u) return;
+  const int x0 = rect & 255u, y0 = (rect >> 8) & 255u, x1 = (rect >> 16) & 255u, y1 = rect >> 24;
+  const uint32_t depth_bits = __float_as_uint(r.y);
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      const int t = y * gx + x;
+      const uint32_t pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+      keys[pos] = make_uint2(depth_bits, (uint32_t)i);
+    }
+}
+
+// ------------------------------------------------------------------ per-tile radix sort
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_WAVES = SORT_THREADS / 64;
+
+// Sorts n (depth,id) pairs ascending by depth bits; ping-pongs between a and b, returns the buffer
+// holding the result.  hist: SORT_WAVES*256 words, misc: 8 words (both LDS).
+__device__ __forceinline__ uint2* radix_sort_pairs(uint2* a, uint2* b, int n, volatile uint32_t* hist,
+                                                   volatile uint32_t* misc) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seg = ((n + SORT_THREADS - 1) / SORT_THREADS) * 64;  // per-wave segment, multiple of 64
+  const int wbeg = min(n, wave * seg), wend = min(n, wbeg + seg);
+  uint2 *src = a, *dst = b;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * 8;
+    for (int k = tid; k < SORT_WAVES * 256; k += SORT_THREADS) hist[k] = 0;
+    if (tid == 0) misc[0] = 0;
+    __syncthreads();
+    for (int k = wbeg + lane; k < wend; k += 64) atomicAdd((uint32_t*)&hist[wave * 256 + ((src[k].x >> shift) & 255u)], 1u);
+    __syncthreads();
+    // digit-major, wave-minor exclusive scan; thread t owns digit t
+    uint32_t c[SORT_WAVES], tot = 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) { c[w] = hist[w * 256 + tid]; tot += c[w]; }
+    uint32_t incl = wave_incl_scan_u32(tot, lane);
+    if (lane == 63) misc[1 + wave] = incl;
+    if (tot == (uint32_t)n) misc[0] = 1;  // every key has this digit: pass is the identity
+    __syncthreads();
+    uint32_t run = incl - tot;
+    for (int w = 0; w < wave; ++w) run += misc[1 + w];
+    const bool skip = misc[0] != 0;
+#pragma unroll
+    for (int w = 0; w < SORT_WAVES; ++w) { hist[w * 256 + tid] = run; run += c[w]; }
+    __syncthreads();
+    if (skip) continue;
+    for (int base = wbeg; base < wend; base += 64) {
+      const int k = base + lane;
+      const bool active = k < wend;
+      uint2 item = make_uint2(0u, 0u);
+      if (active) item = src[k];
+      const uint32_t d = (item.x >> shift) & 255u;
+      unsigned long long m = __ballot(active);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool set = (d >> bit) & 1u;
+        const unsigned long long bal = __ballot(active && set);
+        m &= set ? bal : ~bal;
+      }
+      const uint32_t rank = __popcll(m & ((1ull << lane) - 1ull));
+      const uint32_t cnt = __popcll(m);
+      uint32_t prev = 0;
+      if (active) prev = hist[wave * 256 + d];
+      __builtin_amdgcn_wave_barrier();
+      if (active) {
+        dst[prev + rank] = item;
+        if (rank == 0) hist[wave * 256 + d] = prev + cnt;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    uint2* t = src; src = dst; dst = t;
+  }
+  return src;
+}
+
+// Equal depth bits -> ascending Gaussian id (runs are almost always of length 1).
+__device__ __forceinline__ void fix_ties(uint2* s, int n) {
+  for (int k = threadIdx.x; k < n; k += SORT_THREADS) {
+    const uint32_t key = s[k].x;
+    const bool start = (k == 0 || s[k - 1].x != key) && (k + 1 < n && s[k + 1].x == key);
+    if (!start) continue;
+    int e = k + 1;
+    while (e < n && s[e].x == key) ++e;
+    for (int i = k + 1; i < e; ++i) {
+      const uint32_t id = s[i].y;
+      int j = i - 1;
+      while (j >= k && s[j].y > id) { s[j + 1].y = s[j].y; --j; }
+      s[j + 1].y = id;
+    }
+  }
+}
+
+// grid = n_tiles (blocks walk tile_order: heavy tiles first), block = 256.
+// dynamic LDS = lds_cap*16 (two pair buffers) + (SORT_WAVES*256 + 8)*4.
+__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
+                                                                 const uint32_t* __restrict__ tile_start,
+                                                                 uint2* __restrict__ keys, uint2* __restrict__ keys_tmp,
+                                                                 uint32_t* __restrict__ sorted_ids, int lds_cap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint2* bufA = reinterpret_cast<uint2*>(smem);
+  uint2* bufB = bufA + lds_cap;
+  volatile uint32_t* hist = reinterpret_cast<volatile uint32_t*>(bufB + lds_cap);
+  volatile uint32_t* misc = hist + SORT_WAVES * 256;
+  const uint32_t tile = tile_order[blockIdx.x];
+  const uint32_t s = tile_start[tile];
+  const int n = (int)(tile_start[tile + 1] - s);
+  if (n == 0) return;
+  const int tid = threadIdx.x;
+  if (n <= lds_cap) {
+    for (int k = tid; k < n; k += SORT_THREADS) bufA[k] = keys[s + k];
+    __syncthreads();
+    uint2* res = n > 1 ? radix_sort_pairs(bufA, bufB, n, hist, misc) : bufA;
+    fix_ties(res, n);
+    __syncthreads();
+    for (int k = tid; k < n; k += SORT_THREADS) sorted_ids[s + k] = res[k].y;
+  } else {
+    uint2* res = radix_sort_pairs(keys + s, keys_tmp + s, n, hist, misc);
+    __syncthreads();
+    fix_ties(res, n);
+    __syncthreads();
+    for (int k = tid; k < n; k += SORT_THREADS) sorted_ids[s + k] = res[k].y;
+  }
+}
+
+}  // namespace omfs
+
+using namespace omfs;
+
+extern "C" int omfs_bin_sort(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb,
+                             void* stream) {
+  OMFS_REQUIRE(g && cam && rb, "null pointer");
+  OMFS_REQUIRE(rb->g2 && rb->tile_count && rb->tile_start && rb->tile_cursor && rb->tile_order && rb->keys &&
+                   rb->keys_tmp && rb->sorted_ids && rb->status, "raster buffers");
+  OMFS_REQUIRE(rb->dup_capacity > 0, "dup_capacity");
+  const int gx = cdiv(cam->width, OMFS_TILE), gy = cdiv(cam->height, OMFS_TILE), n_tiles = gx * gy;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, rb->tile_count, rb->tile_start,
+                     rb->tile_cursor, rb->tile_order, rb->dup_capacity, rb->status);
+  OMFS_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(scatter_keys_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, (const float4*)rb->g2, gx,
+                     n_tiles, rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
+  OMFS_CHECK_HIP(hipGetLastError());
+  const int cap = rb->sort_lds_pairs ? (int)rb->sort_lds_pairs : 4096;
+  OMFS_REQUIRE(cap >= 256 && (size_t)cap * 16 + (SORT_WAVES * 256 + 8) * 4 <= 160 * 1024, "sort_lds_pairs");
+  const size_t lds = (size_t)cap * 16 + (SORT_WAVES * 256 + 8) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(SORT_THREADS), lds, s, rb->tile_order, rb->tile_start,
+                     (uint2*)rb->keys, (uint2*)rb->keys_tmp, rb->sorted_ids, cap);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}

@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Builds libomfs_splat.so for gfx950 in-tree (cross-compiles without a GPU).
+# -ffp-contract=off: FMAs are written explicitly so the geometric stage is bit-exact vs oracle/.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../libomfs_splat.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
+objs=()
+for src in flame project binning composite project_bwd loss_adam; do
+  "$HIPCC" $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$here/$src.hip" -o "$here/$src.o" &
+  objs+=("$here/$src.o")
+done
+"$HIPCC" $FLAGS -x hip -c "$here/api.cpp" -o "$here/api.o" &
+objs+=("$here/api.o")
+wait
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+echo "built $out"

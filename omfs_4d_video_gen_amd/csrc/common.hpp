@@ -1,0 +1,81 @@
+// Shared device helpers for libomfs_splat.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/omfs_splat.h"
+
+namespace omfs {
+
+int set_error(int code, const char* fmt, ...);
+
+#define OMFS_CHECK_HIP(expr)                                                                  \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      return omfs::set_error(OMFS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e__));          \
+  } while (0)
+
+#define OMFS_REQUIRE(cond, msg)                                                               \
+  do {                                                                                        \
+    if (!(cond)) return omfs::set_error(OMFS_ERR_ARG, "%s: requirement failed: %s (%s)", __func__, #cond, msg); \
+  } while (0)
+
+constexpr int WAVE = 64;
+
+// ---- exactly specified fp32 helpers (DESIGN.md "Frozen arithmetic"): every operation is an
+// individually rounded IEEE op or an explicit fma, so the C oracle reproduces them bit for bit.
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float dot3_(float ax, float ay, float az, float bx, float by, float bz) {
+  return fma_(az, bz, fma_(ay, by, ax * bx));
+}
+// Cephes-style expf with fixed operation order (used for the scale activation so that radii and
+// tile rectangles are bit-exact against the oracle).
+__device__ __forceinline__ float exp_exact(float x) {
+  x = fminf(fmaxf(x, -87.0f), 88.0f);
+  float n = rintf(x * 1.44269504088896341f);
+  float r = fma_(n, -0.693359375f, x);
+  r = fma_(n, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = fma_(p, r, 1.3981999507e-3f);
+  p = fma_(p, r, 8.3334519073e-3f);
+  p = fma_(p, r, 4.1665795894e-2f);
+  p = fma_(p, r, 1.6666665459e-1f);
+  p = fma_(p, r, 5.0000001201e-1f);
+  float y = fma_(p, r * r, r) + 1.0f;
+  int e = (int)n;
+  return y * __int_as_float((e + 127) << 23);
+}
+
+// ---- wave64 reductions via DPP (no LDS traffic).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// Sum over the 64 lanes; result valid in lane 63.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+  v += dpp_mov<0x111>(v);  // row_shr:1
+  v += dpp_mov<0x112>(v);  // row_shr:2
+  v += dpp_mov<0x114>(v);  // row_shr:4
+  v += dpp_mov<0x118>(v);  // row_shr:8   -> lane 15 of each row has the row sum
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, true));  // row_bcast:15
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, true));  // row_bcast:31
+  return v;
+}
+__device__ __forceinline__ float wave_sum_all(float v) {
+  v = wave_sum_to_lane63(v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace omfs

@@ -1,0 +1,209 @@
+// FLAME rig -> posed vertices -> per-face frames.  gfx950.
+//
+// Stage map (the reference's own FLAME code,
+// 02_Visual_Engine/flame_fitter.py:154-197, stops at linear blendshapes and has no LBS):
+//   flame_joints_kernel : J = J_static + JE.expr, kinematic chain -> 5 rigid transforms / frame,
+//                         blendshape coefficient matrix coef[k_pad][b_pad] (expr | pose features)
+//   flame_lbs_kernel    : v_posed = v_static + basis.coef on f32 MFMA (16x16x4), then linear
+//                         blend skinning straight out of the accumulator registers
+//   face_frames_kernel  : per triangle orthonormal frame, centroid and scale
+//
+// The basis product is the only GEMM-shaped work on the whole path; it is HBM/L2-bound on the
+// basis (k_pad*V*3*4 bytes per call), so f32 MFMA (exact k-ordered fma chain) is used for it and
+// nothing is down-converted.
+#include "common.hpp"
+
+namespace omfs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// One thread per frame.
+__global__ void flame_joints_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
+                                    const float* __restrict__ expr, const float* __restrict__ rotmats, int n_frames,
+                                    int n_expr, int k_pad, int b_pad, float* __restrict__ joint_xf,
+                                    float* __restrict__ coef) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= b_pad) return;
+  if (b >= n_frames) {  // padded frame columns: zero coefficients
+    for (int k = 0; k < k_pad; ++k) coef[(size_t)k * b_pad + b] = 0.f;
+    return;
+  }
+  const float* e = expr + (size_t)b * n_expr;
+  const float* R = rotmats + (size_t)b * 45;
+  // joints: J[j][c] = j_static + sum_k j_expr[j*3+c][k] * e[k]   (k ascending fma chain)
+  float J[5][3];
+  for (int jc = 0; jc < 15; ++jc) {
+    float acc = j_static[jc];
+    const float* row = j_expr + (size_t)jc * n_expr;
+    for (int k = 0; k < n_expr; ++k) acc = fma_(row[k], e[k], acc);
+    J[jc / 3][jc % 3] = acc;
+  }
+  // kinematic chain, parents = [-1, 0, 1, 1, 1]
+  float Rw[5][9], tw[5][3];
+  for (int i = 0; i < 9; ++i) Rw[0][i] = R[i];
+  for (int c = 0; c < 3; ++c) tw[0][c] = J[0][c];
+  for (int j = 1; j < 5; ++j) {
+    int p = (j == 1) ? 0 : 1;
+    const float* Rl = R + j * 9;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        Rw[j][r * 3 + c] = dot3_(Rw[p][r * 3 + 0], Rw[p][r * 3 + 1], Rw[p][r * 3 + 2], Rl[c], Rl[3 + c], Rl[6 + c]);
+    float dx = J[j][0] - J[p][0], dy = J[j][1] - J[p][1], dz = J[j][2] - J[p][2];
+    for (int r = 0; r < 3; ++r) tw[j][r] = dot3_(Rw[p][r * 3 + 0], Rw[p][r * 3 + 1], Rw[p][r * 3 + 2], dx, dy, dz) + tw[p][r];
+  }
+  float* out = joint_xf + (size_t)b * 60;
+  for (int j = 0; j < 5; ++j) {
+    for (int i = 0; i < 9; ++i) out[j * 12 + i] = Rw[j][i];
+    for (int r = 0; r < 3; ++r)
+      out[j * 12 + 9 + r] = tw[j][r] - dot3_(Rw[j][r * 3 + 0], Rw[j][r * 3 + 1], Rw[j][r * 3 + 2], J[j][0], J[j][1], J[j][2]);
+  }
+  // coefficient column: expr, then pose features (R_j - I), j = 1..4, row-major
+  for (int k = 0; k < n_expr; ++k) coef[(size_t)k * b_pad + b] = e[k];
+  for (int j = 1; j < 5; ++j)
+    for (int i = 0; i < 9; ++i)
+      coef[(size_t)(n_expr + (j - 1) * 9 + i) * b_pad + b] = R[j * 9 + i] - ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f);
+  for (int k = n_expr + 36; k < k_pad; ++k) coef[(size_t)k * b_pad + b] = 0.f;
+}
+
+// grid = (v_pad/16 strips, b_pad/16 column blocks), block = 64 (one wave per 16 vertices x 16 frames).
+// A tile (c, strip, kt): 64 lanes x float4; lane l holds basis rows k = 16*kt + 4*j + (l>>4), j=0..3,
+// for vertex strip*16 + (l&15).  MFMA j of tile kt therefore consumes k = 16kt+4j .. 16kt+4j+3 in
+// order: the accumulator is a single ascending-k fma chain (bit-exact vs the oracle's fmaf loop).
+__global__ __launch_bounds__(64) void flame_lbs_kernel(const float* __restrict__ basis_tiled,
+                                                       const float* __restrict__ v_static,
+                                                       const float* __restrict__ lbs_weights,
+                                                       const float* __restrict__ coef,
+                                                       const float* __restrict__ joint_xf,
+                                                       const float* __restrict__ translation,
+                                                       const float* __restrict__ dynamic_offset, int n_verts, int v_pad,
+                                                       int k_pad, int n_frames, int b_pad, float* __restrict__ verts) {
+  const int strip = blockIdx.x, cb = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int n_strips = v_pad / 16, n_kt = k_pad / 16;
+  const int col = lane & 15, grp = lane >> 4;
+  const int frame = cb * 16 + col;
+  f32x4 acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    // C/D map of 16x16x4 f32: row = grp*4 + reg (vertex in strip), col = lane&15 (frame)
+    const float* vs = v_static + (size_t)c * v_pad + strip * 16 + grp * 4;
+    acc[c] = f32x4{vs[0], vs[1], vs[2], vs[3]};
+  }
+  for (int kt = 0; kt < n_kt; ++kt) {
+    f32x4 a[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      a[c] = *reinterpret_cast<const f32x4*>(basis_tiled + ((((size_t)c * n_strips + strip) * n_kt + kt) * 64 + lane) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // B operand: lane holds coef[k = 16kt + 4j + grp][frame col]
+      float bv = coef[(size_t)(kt * 16 + j * 4 + grp) * b_pad + cb * 16 + col];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], bv, acc[c], 0, 0, 0);
+    }
+  }
+  if (frame >= n_frames) return;
+  const float* X = joint_xf + (size_t)frame * 60;
+  const float tx = translation[frame * 3 + 0], ty = translation[frame * 3 + 1], tz = translation[frame * 3 + 2];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    int v = strip * 16 + grp * 4 + r;
+    if (v >= n_verts) continue;
+    const float* w = lbs_weights + (size_t)v * 8;
+    float M[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      float m = w[0] * X[i];
+#pragma unroll
+      for (int j = 1; j < 5; ++j) m = fma_(w[j], X[j * 12 + i], m);
+      M[i] = m;
+    }
+    float x = acc[0][r], y = acc[1][r], z = acc[2][r];
+    float ox = dot3_(M[0], M[1], M[2], x, y, z) + M[9];
+    float oy = dot3_(M[3], M[4], M[5], x, y, z) + M[10];
+    float oz = dot3_(M[6], M[7], M[8], x, y, z) + M[11];
+    if (dynamic_offset) {
+      const float* d = dynamic_offset + ((size_t)frame * n_verts + v) * 3;
+      ox += d[0]; oy += d[1]; oz += d[2];
+    }
+    ox += tx; oy += ty; oz += tz;
+    *reinterpret_cast<float4*>(verts + ((size_t)frame * v_pad + v) * 4) = make_float4(ox, oy, oz, 1.f);
+  }
+}
+
+__device__ __forceinline__ void safe_normalize3(float& x, float& y, float& z) {
+  float d = fmaxf(dot3_(x, y, z, x, y, z), 1e-20f);
+  float l = sqrtf(d);
+  x = x / l; y = y / l; z = z / l;
+}
+
+// One thread per (face, frame).
+__global__ void face_frames_kernel(const float* __restrict__ verts, int v_pad, const int32_t* __restrict__ faces,
+                                   int n_faces, int n_frames, float* __restrict__ face_xf) {
+  int f = blockIdx.x * blockDim.x + threadIdx.x;
+  int b = blockIdx.y;
+  if (f >= n_faces) return;
+  const float4* vb = reinterpret_cast<const float4*>(verts) + (size_t)b * v_pad;
+  int i0 = faces[f * 3 + 0], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+  float4 v0 = vb[i0], v1 = vb[i1], v2 = vb[i2];
+  float e1x = v1.x - v0.x, e1y = v1.y - v0.y, e1z = v1.z - v0.z;
+  float e2x = v2.x - v0.x, e2y = v2.y - v0.y, e2z = v2.z - v0.z;
+  float a0x = e1x, a0y = e1y, a0z = e1z;
+  safe_normalize3(a0x, a0y, a0z);
+  // n = normalize(a0 x e2)
+  float nx = fma_(a0y, e2z, -(a0z * e2y)), ny = fma_(a0z, e2x, -(a0x * e2z)), nz = fma_(a0x, e2y, -(a0y * e2x));
+  safe_normalize3(nx, ny, nz);
+  // a2 = -normalize(n x a0)
+  float cx = fma_(ny, a0z, -(nz * a0y)), cy = fma_(nz, a0x, -(nx * a0z)), cz = fma_(nx, a0y, -(ny * a0x));
+  safe_normalize3(cx, cy, cz);
+  float a2x = -cx, a2y = -cy, a2z = -cz;
+  float s0 = sqrtf(dot3_(e1x, e1y, e1z, e1x, e1y, e1z));
+  float s1 = fabsf(dot3_(a2x, a2y, a2z, e2x, e2y, e2z));
+  float scale = (s0 + s1) * 0.5f;
+  const float third = 1.0f / 3.0f;
+  float ccx = ((v0.x + v1.x) + v2.x) * third, ccy = ((v0.y + v1.y) + v2.y) * third, ccz = ((v0.z + v1.z) + v2.z) * third;
+  float4* o = reinterpret_cast<float4*>(face_xf) + ((size_t)b * n_faces + f) * 4;
+  // R row-major, columns (a0, n, a2)
+  o[0] = make_float4(a0x, nx, a2x, a0y);
+  o[1] = make_float4(ny, a2y, a0z, nz);
+  o[2] = make_float4(a2z, ccx, ccy, ccz);
+  o[3] = make_float4(scale, 0.f, 0.f, 0.f);
+}
+
+}  // namespace omfs
+
+using namespace omfs;
+
+extern "C" int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, const float* rotmats, int n_frames,
+                                 float* joint_xf, float* coef, void* stream) {
+  OMFS_REQUIRE(rig && expr && rotmats && joint_xf && coef, "null pointer");
+  OMFS_REQUIRE(n_frames > 0 && rig->n_expr > 0 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36, "shape");
+  int b_pad = cdiv(n_frames, 16) * 16;
+  hipLaunchKernelGGL(flame_joints_kernel, dim3(cdiv(b_pad, 64)), dim3(64), 0, (hipStream_t)stream, rig->j_static,
+                     rig->j_expr, expr, rotmats, n_frames, rig->n_expr, rig->k_pad, b_pad, joint_xf, coef);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_flame_lbs(const omfs_flame_rig* rig, const float* coef, const float* joint_xf,
+                              const float* translation, const float* dynamic_offset, int n_frames, float* verts,
+                              void* stream) {
+  OMFS_REQUIRE(rig && coef && joint_xf && translation && verts, "null pointer");
+  OMFS_REQUIRE(n_frames > 0 && rig->v_pad % 16 == 0 && rig->v_pad >= rig->n_verts && rig->k_pad % 16 == 0, "shape");
+  int b_pad = cdiv(n_frames, 16) * 16;
+  hipLaunchKernelGGL(flame_lbs_kernel, dim3(rig->v_pad / 16, b_pad / 16), dim3(64), 0, (hipStream_t)stream,
+                     rig->basis_tiled, rig->v_static, rig->lbs_weights, coef, joint_xf, translation, dynamic_offset,
+                     rig->n_verts, rig->v_pad, rig->k_pad, n_frames, b_pad, verts);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_face_frames(const float* verts, int v_pad, const int32_t* faces, int n_faces, int n_frames,
+                                float* face_xf, void* stream) {
+  OMFS_REQUIRE(verts && faces && face_xf, "null pointer");
+  OMFS_REQUIRE(n_faces > 0 && n_frames > 0 && v_pad > 0, "shape");
+  hipLaunchKernelGGL(face_frames_kernel, dim3(cdiv(n_faces, 256), n_frames), dim3(256), 0, (hipStream_t)stream, verts,
+                     v_pad, faces, n_faces, n_frames, face_xf);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}

@@ -1,0 +1,200 @@
+"""FLAME rig on the device: blendshapes + pose correctives + LBS -> vertices -> triangle frames.
+
+Host side of `omfs_flame_joints / omfs_flame_lbs / omfs_face_frames` (include/omfs_splat.h).
+The reference's own FLAME code (`02_Visual_Engine/flame_fitter.py:69-197`, SimpleFLAME) is
+linear blendshapes + a jaw heuristic; the engine behind `train_ghost` / `render_surgery` needs
+the full model, which is what this module drives.
+
+`rodrigues` follows `SimpleFLAME._axis_angle_to_matrix` (`flame_fitter.py:122-152`) exactly and
+is pinned by the golden vectors generated from the reference.
+"""
+from __future__ import annotations
+
+import pickle
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+PARENTS = (-1, 0, 1, 1, 1)
+N_SHAPE_MAX = 300
+N_POSEDIRS = 36
+
+
+def rodrigues(axis_angle: torch.Tensor) -> torch.Tensor:
+    """(B,3) axis-angle -> (B,3,3); same formula and epsilon as flame_fitter.py:133-152."""
+    B = axis_angle.shape[0]
+    angle = torch.norm(axis_angle, dim=1, keepdim=True)
+    axis = axis_angle / (angle + 1e-8)
+    cos_a = torch.cos(angle).unsqueeze(-1)
+    sin_a = torch.sin(angle).unsqueeze(-1)
+    zeros = torch.zeros(B, dtype=axis_angle.dtype, device=axis_angle.device)
+    K = torch.stack([
+        torch.stack([zeros, -axis[:, 2], axis[:, 1]], dim=1),
+        torch.stack([axis[:, 2], zeros, -axis[:, 0]], dim=1),
+        torch.stack([-axis[:, 1], axis[:, 0], zeros], dim=1),
+    ], dim=1)
+    eye = torch.eye(3, dtype=axis_angle.dtype, device=axis_angle.device).unsqueeze(0).expand(B, -1, -1)
+    return eye + sin_a * K + (1 - cos_a) * torch.bmm(K, K)
+
+
+def pose_rotmats(flame_params: dict) -> np.ndarray:
+    """Dataset FLAME params (`flame_fitter.py:431-441` schema) -> (T,5,3,3) float32
+    [global rotation, neck, jaw, eye-L, eye-R]."""
+    def as2d(a, w):
+        a = np.asarray(a, np.float32)
+        return a.reshape(-1, w)
+    rot = as2d(flame_params["rotation"], 3)
+    T = rot.shape[0]
+    neck = as2d(flame_params.get("neck_pose", np.zeros((T, 3))), 3)
+    jaw = as2d(flame_params.get("jaw_pose", np.zeros((T, 3))), 3)
+    eyes = as2d(flame_params.get("eyes_pose", np.zeros((T, 6))), 6)
+    aa = np.stack([rot, neck, jaw, eyes[:, :3], eyes[:, 3:]], 1).reshape(-1, 3)
+    return rodrigues(torch.from_numpy(aa)).reshape(T, 5, 3, 3).numpy()
+
+
+class FlameRig:
+    """Static rig arrays (host, numpy) in FLAME-pickle conventions."""
+
+    def __init__(self, v_template, shapedirs, posedirs, J_regressor, weights, faces, parents=PARENTS):
+        self.v_template = np.asarray(v_template, np.float32)          # (V,3)
+        self.shapedirs = np.asarray(shapedirs, np.float32)            # (V,3,>=300+n_expr)
+        self.posedirs = np.asarray(posedirs, np.float32)              # (V,3,36)
+        self.J_regressor = np.asarray(J_regressor, np.float32)        # (5,V)
+        self.weights = np.asarray(weights, np.float32)                # (V,5)
+        self.faces = np.asarray(faces, np.int32)                      # (F,3)
+        if tuple(int(p) for p in parents) != PARENTS:
+            raise ValueError(f"unsupported kinematic tree {tuple(parents)}; FLAME's is {PARENTS}")
+        V = self.v_template.shape[0]
+        if self.shapedirs.shape[:2] != (V, 3) or self.posedirs.shape != (V, 3, N_POSEDIRS):
+            raise ValueError("rig array shapes do not match FLAME conventions")
+        if self.J_regressor.shape != (5, V) or self.weights.shape != (V, 5):
+            raise ValueError("FLAME has 5 joints: J_regressor (5,V), weights (V,5)")
+
+    @property
+    def n_verts(self):
+        return self.v_template.shape[0]
+
+    @property
+    def n_faces(self):
+        return self.faces.shape[0]
+
+    @classmethod
+    def from_synthetic(cls, rig):
+        return cls(rig.v_template, rig.shapedirs, rig.posedirs, rig.J_regressor, rig.weights, rig.faces)
+
+    @classmethod
+    def from_pickle(cls, path: str):
+        """Same keys `SimpleFLAME.__init__` reads (`flame_fitter.py:80-120`) plus `posedirs`."""
+        with open(path, "rb") as f:
+            m = pickle.load(f, encoding="latin1")
+        jr = m["J_regressor"]
+        jr = np.asarray(jr.todense() if hasattr(jr, "todense") else jr, np.float32)
+        kt = np.asarray(m["kintree_table"], np.int64)
+        parents = kt[0].copy()
+        parents[0] = -1
+        return cls(np.asarray(m["v_template"], np.float32), np.asarray(m["shapedirs"], np.float32),
+                   np.asarray(m["posedirs"], np.float32), jr, np.asarray(m["weights"], np.float32),
+                   np.asarray(m["f"], np.int64).astype(np.int32), parents)
+
+
+def tile_basis(basis_kcv: np.ndarray, k_pad: int, v_pad: int) -> np.ndarray:
+    """[K][3][V] -> MFMA-A tiles [3][v_pad/16][k_pad/16][64][4]:
+    lane l, element j holds row k = 16*kt + 4*j + (l>>4) of vertex strip*16 + (l&15)."""
+    K, _, V = basis_kcv.shape
+    pad = np.zeros((k_pad, 3, v_pad), np.float32)
+    pad[:K, :, :V] = basis_kcv
+    n_kt, n_strips = k_pad // 16, v_pad // 16
+    t = pad.reshape(n_kt, 4, 4, 3, n_strips, 16)            # kt, j, grp, c, strip, vl
+    return np.ascontiguousarray(t.transpose(3, 4, 0, 2, 5, 1)).reshape(3, n_strips, n_kt, 64, 4)
+
+
+class DeviceFlame:
+    """A rig specialised to one subject (shape + static_offset folded in) and one FLAME sequence,
+    resident in HBM.  `face_frames(t)` runs the three FLAME kernels for frame(s) t."""
+
+    def __init__(self, rig: FlameRig, flame_params: dict, device="cuda", n_expr: int | None = None):
+        self.rig = rig
+        self.device = torch.device(device)
+        V, F = rig.n_verts, rig.n_faces
+        expr = np.asarray(flame_params["expr"], np.float32)
+        expr = expr.reshape(-1, expr.shape[-1])
+        self.n_frames = expr.shape[0]
+        self.n_expr = int(n_expr if n_expr is not None else expr.shape[1])
+        if rig.shapedirs.shape[2] < N_SHAPE_MAX + self.n_expr:
+            raise ValueError("rig has fewer expression directions than the sequence uses")
+        self.v_pad = (V + 15) // 16 * 16
+        K = self.n_expr + N_POSEDIRS
+        self.k_pad = (K + 15) // 16 * 16
+        shape = np.zeros(N_SHAPE_MAX, np.float64)
+        s_in = np.asarray(flame_params["shape"], np.float64).reshape(-1)
+        shape[:min(len(s_in), N_SHAPE_MAX)] = s_in[:N_SHAPE_MAX]
+        v_static = rig.v_template.astype(np.float64) + rig.shapedirs[:, :, :N_SHAPE_MAX].astype(np.float64) @ shape
+        so = flame_params.get("static_offset")
+        if so is not None:
+            so = np.asarray(so, np.float64).reshape(-1, 3)
+            if so.shape[0] != V:
+                raise ValueError(f"static_offset has {so.shape[0]} vertices, rig has {V}")
+            v_static = v_static + so
+        exprdirs = rig.shapedirs[:, :, N_SHAPE_MAX:N_SHAPE_MAX + self.n_expr].astype(np.float64)   # (V,3,E)
+        basis = np.concatenate([exprdirs.transpose(2, 1, 0), rig.posedirs.astype(np.float64).transpose(2, 1, 0)], 0)
+        JR = rig.J_regressor.astype(np.float64)
+        # host copies (float32) of exactly what the kernels read -- the oracle gets the same arrays
+        self.h_v_static = np.zeros((3, self.v_pad), np.float32)
+        self.h_v_static[:, :V] = v_static.T.astype(np.float32)
+        self.h_basis = basis.astype(np.float32)                                    # [K][3][V]
+        self.h_j_static = (JR @ v_static).astype(np.float32)                       # (5,3)
+        self.h_j_expr = np.einsum("jv,vck->jck", JR, exprdirs).reshape(15, self.n_expr).astype(np.float32)
+        self.h_weights = np.zeros((self.v_pad, 8), np.float32)
+        self.h_weights[:V, :5] = rig.weights
+        self.h_rotmats = pose_rotmats(flame_params).reshape(self.n_frames, 45)
+        self.h_expr = np.ascontiguousarray(expr[:, :self.n_expr])
+        self.h_translation = np.asarray(flame_params["translation"], np.float32).reshape(-1, 3)
+        dyn = flame_params.get("dynamic_offset")
+        self.h_dynamic = None
+        if dyn is not None and np.any(dyn):
+            self.h_dynamic = np.asarray(dyn, np.float32).reshape(self.n_frames, V, 3)
+        dev = self.device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.basis_tiled = up(tile_basis(self.h_basis, self.k_pad, self.v_pad))
+        self.v_static = up(self.h_v_static)
+        self.lbs_weights = up(self.h_weights)
+        self.j_static = up(self.h_j_static)
+        self.j_expr = up(self.h_j_expr)
+        self.expr = up(self.h_expr)
+        self.rotmats = up(self.h_rotmats)
+        self.translation = up(self.h_translation)
+        self.dynamic = up(self.h_dynamic) if self.h_dynamic is not None else None
+        self.faces = up(rig.faces)
+        self.c_rig = L.FlameRigC(V, self.v_pad, self.n_expr, self.k_pad, L.ptr(self.basis_tiled), L.ptr(self.v_static),
+                                 L.ptr(self.lbs_weights), L.ptr(self.j_static), L.ptr(self.j_expr))
+        self._scratch = {}
+
+    def _buffers(self, nb: int):
+        if nb not in self._scratch:
+            b_pad = (nb + 15) // 16 * 16
+            dev = self.device
+            self._scratch[nb] = (
+                torch.empty(nb, 60, device=dev), torch.empty(self.k_pad, b_pad, device=dev),
+                torch.empty(nb, self.v_pad, 4, device=dev), torch.empty(nb, self.rig.n_faces, 16, device=dev))
+        return self._scratch[nb]
+
+    def face_frames(self, t0: int, nb: int = 1, out=None):
+        """Frames t0..t0+nb-1 -> (verts [nb][v_pad][4], face_xf [nb][F][16]) device tensors.
+        The returned tensors are reused by the next call with the same nb."""
+        if not (0 <= t0 and t0 + nb <= self.n_frames):
+            raise IndexError(f"frames [{t0},{t0 + nb}) outside sequence of {self.n_frames}")
+        lib = L.load()
+        s = L.stream_ptr()
+        joint_xf, coef, verts, face_xf = self._buffers(nb)
+        if out is not None:
+            face_xf = out
+        L.check(lib.omfs_flame_joints(self.c_rig, L.ptr(self.expr[t0]), L.ptr(self.rotmats[t0]), nb, L.ptr(joint_xf),
+                                      L.ptr(coef), s), "omfs_flame_joints")
+        dyn = L.ptr(self.dynamic[t0]) if self.dynamic is not None else 0
+        L.check(lib.omfs_flame_lbs(self.c_rig, L.ptr(coef), L.ptr(joint_xf), L.ptr(self.translation[t0]), dyn, nb,
+                                   L.ptr(verts), s), "omfs_flame_lbs")
+        L.check(lib.omfs_face_frames(L.ptr(verts), self.v_pad, L.ptr(self.faces), self.rig.n_faces, nb, L.ptr(face_xf), s),
+                "omfs_face_frames")
+        return verts, face_xf

@@ -1,0 +1,187 @@
+"""Host driver of the splat kernels: project -> bin/sort -> composite (+ backward, loss, Adam).
+
+All buffers are allocated once per (N, width, height) and reused; every call only enqueues
+kernels on the current HIP stream (no host sync), so a frame or a training step can be captured
+into a hipGraph by the caller.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+from .gaussians import GaussianModel, NPLANES
+
+TILE = 16
+
+
+def make_camera_struct(cam: dict, sh_degree: int = 3, bg=(0.0, 0.0, 0.0)) -> L.CameraC:
+    """cam: dict from synthetic.make_camera / dataset reader (world_to_view 4x4, fl_x, fl_y, tanfov*, size)."""
+    c = L.CameraC()
+    w2v = np.asarray(cam["world_to_view"], np.float32)
+    c.view[:] = [float(v) for v in w2v[:3, :4].reshape(-1)]
+    c.cam_pos[:] = [float(v) for v in np.asarray(cam["cam_pos"], np.float32)]
+    c.fx, c.fy = float(np.float32(cam["fl_x"])), float(np.float32(cam["fl_y"]))
+    c.width, c.height = int(cam["width"]), int(cam["height"])
+    c.cx, c.cy = (c.width - 1) * 0.5, (c.height - 1) * 0.5
+    c.limx = float(np.float32(1.3) * np.float32(cam["tanfovx"]))
+    c.limy = float(np.float32(1.3) * np.float32(cam["tanfovy"]))
+    c.sh_degree = int(sh_degree)
+    c.bg[:] = [float(b) for b in bg]
+    return c
+
+
+class Rasterizer:
+    def __init__(self, n: int, width: int, height: int, device="cuda", dup_capacity: int | None = None,
+                 sort_lds_pairs: int = 0):
+        self.device = torch.device(device)
+        self.n, self.width, self.height = int(n), int(width), int(height)
+        self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+        self.n_tiles = self.gx * self.gy
+        # 288 GB of HBM: be generous rather than re-allocate; overflow is flagged by the device
+        self.dup_capacity = int(dup_capacity if dup_capacity else max(1 << 20, 24 * n))
+        dev = self.device
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        self.g0, self.g1, self.g2 = z(n, 4), z(n, 4), z(n, 4)
+        self.tile_count = z(self.n_tiles, dt=torch.int32)
+        self.tile_start = z(self.n_tiles + 1, dt=torch.int32)
+        self.tile_cursor = z(self.n_tiles, dt=torch.int32)
+        self.tile_order = z(self.n_tiles, dt=torch.int32)
+        self.keys = z(self.dup_capacity, 2, dt=torch.int32)
+        self.keys_tmp = z(self.dup_capacity, 2, dt=torch.int32)
+        self.sorted_ids = z(self.dup_capacity, dt=torch.int32)
+        self.status = z(1, dt=torch.int32)
+        self.image = z(3, height, width)
+        self.final_T = z(height, width)
+        self.n_contrib = z(height, width, dt=torch.int32)
+        self.n_visible = z(1, dt=torch.int32)
+        self.rb = L.RasterBuffersC(L.ptr(self.g0), L.ptr(self.g1), L.ptr(self.g2), L.ptr(self.tile_count),
+                                   L.ptr(self.tile_start), L.ptr(self.tile_cursor), L.ptr(self.tile_order),
+                                   L.ptr(self.keys), L.ptr(self.keys_tmp), L.ptr(self.sorted_ids),
+                                   self.dup_capacity, int(sort_lds_pairs), L.ptr(self.status), L.ptr(self.image),
+                                   L.ptr(self.final_T), L.ptr(self.n_contrib))
+        # backward-side buffers are created on first use
+        self.dsplat = None
+        self.dimage = None
+        self.loss = None
+        self.loss_scratch = None
+        self.rgb8 = None
+
+    # ------------------------------------------------------------------ forward
+    def _gauss(self, model: GaussianModel) -> L.GaussiansC:
+        if model.n != self.n:
+            raise ValueError(f"rasterizer was sized for {self.n} Gaussians, model has {model.n}")
+        return L.GaussiansC(model.n, model.n_pad, L.ptr(model.params), L.ptr(model.binding))
+
+    def project(self, model: GaussianModel, face_xf: torch.Tensor, cam: L.CameraC):
+        if cam.width != self.width or cam.height != self.height:
+            raise ValueError("camera size does not match the rasterizer's buffers")
+        if face_xf.dtype != torch.float32 or not face_xf.is_contiguous() or face_xf.shape[-1] != 16:
+            raise ValueError("face_xf must be a contiguous float32 [F][16] tensor")
+        lib = L.load()
+        L.check(lib.omfs_project_fwd(self._gauss(model), L.ptr(face_xf), cam, self.rb, L.stream_ptr()), "omfs_project_fwd")
+
+    def bin_sort(self, model: GaussianModel, cam: L.CameraC):
+        L.check(L.load().omfs_bin_sort(self._gauss(model), cam, self.rb, L.stream_ptr()), "omfs_bin_sort")
+
+    def composite(self, cam: L.CameraC):
+        L.check(L.load().omfs_composite_fwd(cam, self.rb, L.stream_ptr()), "omfs_composite_fwd")
+
+    def forward(self, model: GaussianModel, face_xf: torch.Tensor, cam: L.CameraC) -> torch.Tensor:
+        """Enqueue one view; returns the (reused) image tensor [3][H][W]."""
+        self.project(model, face_xf, cam)
+        self.bin_sort(model, cam)
+        self.composite(cam)
+        return self.image
+
+    def to_rgb8(self) -> torch.Tensor:
+        if self.rgb8 is None:
+            self.rgb8 = torch.zeros(self.height, self.width, 3, dtype=torch.uint8, device=self.device)
+        L.check(L.load().omfs_image_to_rgb8(L.ptr(self.image), self.width, self.height, L.ptr(self.rgb8), L.stream_ptr()),
+                "omfs_image_to_rgb8")
+        return self.rgb8
+
+    def check_status(self):
+        """Host sync: raise if the device flagged a capacity overflow."""
+        st = int(self.status.item())
+        if st & 1:
+            raise L.OmfsError(f"tile-list capacity {self.dup_capacity} exceeded; re-create the Rasterizer with a larger dup_capacity")
+
+    # ------------------------------------------------------------------ backward
+    def _ensure_bwd(self):
+        if self.dsplat is None:
+            dev = self.device
+            self.dsplat = torch.zeros(self.n, 16, device=dev)
+            self.dimage = torch.zeros(3, self.height, self.width, device=dev)
+            self.loss = torch.zeros(1, device=dev)
+            self.loss_scratch = torch.zeros(3, 3, self.height, self.width, device=dev)
+
+    def loss_l1_ssim(self, target: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
+        """Adds this view's loss into self.loss (device scalar, zero it yourself) and writes self.dimage."""
+        self._ensure_bwd()
+        if target.shape != self.image.shape or target.dtype != torch.float32 or not target.is_contiguous():
+            raise ValueError("target must be a contiguous float32 [3][H][W] tensor")
+        L.check(L.load().omfs_loss_l1_ssim(L.ptr(self.image), L.ptr(target), self.width, self.height, float(lambda_dssim),
+                                           L.ptr(self.dimage), L.ptr(self.loss), L.ptr(self.loss_scratch), L.stream_ptr()),
+                "omfs_loss_l1_ssim")
+        return self.loss
+
+    def backward(self, model: GaussianModel, face_xf: torch.Tensor, cam: L.CameraC, grads: torch.Tensor,
+                 dimage: torch.Tensor | None = None, reg=(0.01, 1.0, 1.0, 0.6)):
+        """dL/dimage (default: self.dimage from loss_l1_ssim) -> grads [59][n_pad] (overwritten)."""
+        self._ensure_bwd()
+        lib = L.load()
+        s = L.stream_ptr()
+        dimg = self.dimage if dimage is None else dimage
+        if dimg.shape != self.image.shape or dimg.dtype != torch.float32 or not dimg.is_contiguous():
+            raise ValueError("dimage must be a contiguous float32 [3][H][W] tensor")
+        if grads.shape != (NPLANES, model.n_pad) or grads.dtype != torch.float32 or not grads.is_contiguous():
+            raise ValueError("grads must be a contiguous float32 [59][n_pad] tensor")
+        self.dsplat.zero_()
+        gb = L.GradBuffersC(L.ptr(self.dsplat), L.ptr(grads), L.ptr(dimg))
+        L.check(lib.omfs_composite_bwd(cam, self.rb, gb, s), "omfs_composite_bwd")
+        L.check(lib.omfs_count_visible(self.rb, self.n, L.ptr(self.n_visible), s), "omfs_count_visible")
+        rp = L.RegParamsC(float(reg[0]), float(reg[1]), float(reg[2]), float(reg[3]), L.ptr(self.n_visible))
+        L.check(lib.omfs_project_bwd(self._gauss(model), L.ptr(face_xf), cam, self.rb, gb, rp, s), "omfs_project_bwd")
+
+
+class Adam:
+    """Fused per-Gaussian Adam over the [59][n_pad] SoA (torch.optim.Adam semantics)."""
+
+    def __init__(self, model: GaussianModel, lr_planes, beta1=0.9, beta2=0.999, eps=1e-15):
+        self.model = model
+        self.m = torch.zeros_like(model.params)
+        self.v = torch.zeros_like(model.params)
+        self.step_count = 0
+        self.ap = L.AdamParamsC()
+        self.set_lr(lr_planes)
+        self.ap.beta1, self.ap.beta2, self.ap.eps = beta1, beta2, eps
+        self.ap.grad_scale = 1.0
+
+    def set_lr(self, lr_planes):
+        lr = np.asarray(lr_planes, np.float32).reshape(-1)
+        if lr.shape[0] != NPLANES:
+            raise ValueError("need one learning rate per parameter plane (59)")
+        self.ap.lr[:] = [float(x) for x in lr]
+
+    def step(self, grads: torch.Tensor, grad_scale: float = 1.0):
+        self.step_count += 1
+        self.ap.step = self.step_count
+        self.ap.grad_scale = float(grad_scale)
+        m = self.model
+        L.check(L.load().omfs_adam_step(L.ptr(m.params), L.ptr(grads), L.ptr(self.m), L.ptr(self.v), m.n, m.n_pad,
+                                        C.byref(self.ap), L.stream_ptr()), "omfs_adam_step")
+
+
+def default_lr_planes(position_lr=1.6e-4, scaling_lr=1.7e-2, rotation_lr=1e-3, opacity_lr=5e-2, feature_lr=2.5e-3):
+    """Per-plane learning rates (GaussianAvatars' larger scaling lr)."""
+    lr = np.zeros(NPLANES, np.float32)
+    lr[0:3] = position_lr
+    lr[3:6] = scaling_lr
+    lr[6:10] = rotation_lr
+    lr[10] = opacity_lr
+    lr[11:14] = feature_lr
+    lr[14:] = feature_lr / 20.0
+    return lr
