@@ -236,7 +236,9 @@ def composite(proj: dict, lists, width: int, height: int, bg):
             dx = m[:, 0:1] - px
             dy = m[:, 1:2] - py
             power = -0.5 * (con[:, 0:1] * dx * dx + con[:, 2:3] * dy * dy) - con[:, 1:2] * dx * dy
-            alpha = torch.clamp(op[:, None] * torch.exp(power), max=0.99)
+            a_raw = op[:, None] * torch.exp(power)
+            # value clamped at 0.99, gradient passed straight through (as the upstream rasteriser does)
+            alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()
             keep = (power <= 0) & (alpha >= 1.0 / 255.0)
             a = torch.where(keep, alpha, torch.zeros_like(alpha))
             Tinc = torch.cumprod(1 - a, dim=0)
