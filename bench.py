@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the FLAME-rigged Gaussian-avatar hot path on MI355X.
+
+Metric (BASELINE.json): train_ghost iterations/s at 1920x1080, 300k mesh-bound Gaussians (the
+configuration the metric is quoted on; it fits one GPU).  A "step" is one training iteration of
+one rank on one synthetic view: FLAME LBS -> triangle frames -> project -> bin/sort -> composite
+-> L1+D-SSIM -> composite bwd -> projection bwd -> [RCCL all-reduce of the gradient SoA] -> Adam.
+With N ranks every step consumes N views (views shard across ranks, weak scaling), so
+value = N * K / t.  render_surgery fps on the same scene is reported in "aux" of the same line.
+
+python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n_gaussians", type=int, default=300_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--views", type=int, default=16)
+    ap.add_argument("--render_frames", type=int, default=300)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_aux", action="store_true")
+    ap.add_argument("--profile_steps", type=int, default=40)
+    return ap.parse_args()
+
+
+def stage_bytes(N, n_pad, D, P, n_tiles, F, D_visit):
+    """Algorithmic HBM bytes per launch of each stage (DESIGN.md 'Algorithmic bytes')."""
+    return {
+        "flame": 0.0,   # set by caller (basis read)
+        "project": N * (59 * 4 + 4) + N * 48 + F * 64,
+        "bin_scan": n_tiles * 20,
+        "bin_scatter": N * 16 + D * 8,
+        "tile_sort": D * 8 + D * 4,
+        "composite_fwd": D * 4 + D * 36 + P * 12 + P * 8,
+        "loss": 3 * P * (8 + 12) + 3 * P * (12 + 8 + 4),
+        "composite_bwd": D_visit * (4 + 36) + D * 40 + P * (12 + 8),
+        "project_bwd": N * (64 + 240 + 236) + F * 64,
+        "adam": 7 * 59 * n_pad * 4,
+    }
+
+
+def host_cores() -> int:
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes a container badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline_train(n_s=20000, w_s=480, h_s=270):
+    """PyTorch-CPU oracle: one full training iteration (render, L1+D-SSIM, autograd backward, Adam)
+    on a bounded sample; returns (seconds, D_sample)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import torch_splat as O
+    from omfs_4d_video_gen_amd.engine import synthetic
+    from omfs_4d_video_gen_amd.engine.flame_rig import pose_rotmats
+    torch.set_num_threads(host_cores())
+    rig = synthetic.make_rig(0)
+    g = synthetic.make_gaussians(n_s, rig.faces.shape[0], 0)
+    seq = synthetic.make_flame_sequence(2, 0)
+    cam = synthetic.make_camera(w_s, h_s, 0.2)
+    org = {"v_template": torch.from_numpy(rig.v_template), "shapedirs": torch.from_numpy(rig.shapedirs),
+           "posedirs": torch.from_numpy(rig.posedirs), "J_regressor": torch.from_numpy(rig.J_regressor),
+           "weights": torch.from_numpy(rig.weights), "faces": torch.from_numpy(rig.faces.astype(np.int64))}
+    rm = pose_rotmats(seq)
+    frame = {"shape": torch.from_numpy(seq["shape"]), "expr": torch.from_numpy(seq["expr"][1]),
+             "rotmats": torch.from_numpy(rm[1]), "translation": torch.from_numpy(seq["translation"][1]),
+             "static_offset": torch.from_numpy(seq["static_offset"][0]), "dynamic_offset": None}
+    og = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in g.items()}
+    names = ("xyz", "log_scale", "rot", "opacity", "sh")
+    for k in names:
+        og[k].requires_grad_(True)
+    target = torch.rand(3, h_s, w_s)
+    m = {k: torch.zeros_like(og[k]) for k in names}
+    v = {k: torch.zeros_like(og[k]) for k in names}
+    t0 = time.perf_counter()
+    out = O.render(org, og, frame, cam, bg=(0.0, 0.0, 0.0), sh_degree=3)
+    loss = O.photometric_loss(out["image"], target) + O.regularisers(og, out["proj"]["visible"])
+    loss.backward()
+    with torch.no_grad():
+        for k in names:
+            O.adam_step(og[k], og[k].grad, m[k], v[k], 1, 1e-3)
+    dt = time.perf_counter() - t0
+    return dt, sum(len(l) for l in out["lists"])
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        print(json.dumps({"error": "bench.py needs a GPU (MI355X); no CPU fallback exists"}))
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        pg = dist.group.WORLD
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from omfs_4d_video_gen_amd.engine import synthetic
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, Trainer, View, StageTimer
+
+    N, W, H = args.n_gaussians, args.width, args.height
+    srig = synthetic.make_rig(0)
+    rig = FlameRig.from_synthetic(srig)
+    F = rig.n_faces
+    T = max(args.views, 2)
+    seq = synthetic.make_flame_sequence(T, 0)
+    cams = synthetic.make_camera_arc(W, H, args.views)
+    g_init = synthetic.make_gaussians(N, F, 0)
+    g_target = synthetic.make_gaussians(N, F, 1)
+
+    log(f"inputs built: N={N} {W}x{H} F={F}")
+    # targets: the same scene rendered from a second seeded Gaussian set (data = synthetic)
+    tr = Renderer(rig, seq, g_target, W, H)
+    views = []
+    for i, cam in enumerate(cams):
+        v = View(cam, timestep=i % T)
+        v.target = tr.render(v).clone()
+        views.append(v)
+    torch.cuda.synchronize()
+    tr.rast.check_status()
+    del tr
+
+    log("targets rendered")
+    trainer = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3,
+                      rank=rank, world_size=world, process_group=pg)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for i in range(args.warmup):
+        trainer.step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    log("warmup done")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.step()
+    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    log(f"timed region done: {dt:.3f}s")
+    trainer.rast.check_status()
+    loss_end = trainer.loss_value()
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt
+
+    # ---- per-kernel timing with HIP events on the launch stream (same step function)
+    trainer.timer = StageTimer(True)
+    for _ in range(args.profile_steps):
+        trainer.step()
+    torch.cuda.synchronize()
+    stages = trainer.timer.summary()
+    log("stage timing done: " + ", ".join(f"{k}={v[0]:.3f}" for k, v in stages.items()))
+    trainer.timer = StageTimer(False)
+    D = int(trainer.rast.tile_start[-1].item())
+    n_contrib = trainer.rast.n_contrib
+    P = W * H
+    n_tiles = trainer.rast.n_tiles
+    # entries actually walked by the backward pass: per tile, the maximum n_contrib of its pixels
+    gy, gx = trainer.rast.gy, trainer.rast.gx
+    pad = torch.zeros(gy * 16, gx * 16, dtype=torch.int32, device="cuda")
+    pad[:H, :W] = n_contrib
+    D_visit = int(pad.view(gy, 16, gx, 16).permute(0, 2, 1, 3).reshape(gy * gx, 256).max(1).values.sum().item())
+    sb = stage_bytes(N, trainer.model.n_pad, D, P, n_tiles, F, D_visit)
+    sb["flame"] = trainer.dflame.k_pad * trainer.dflame.v_pad * 3 * 4 + trainer.dflame.v_pad * 16 + F * (64 + 12)
+    dom = max((k for k in stages if k != "allreduce"), key=lambda k: stages[k][0])
+    dom_ms = stages[dom][0]
+    achieved = sb[dom] / (dom_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = tj.get(f"{dom}@{W}x{H}x{N}")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes": int(sb[dom]), "avg_ms": round(dom_ms, 4)}
+    total_bytes = sum(sb[k] for k in stages if k in sb)
+
+    out = {
+        "metric": "train_ghost_iters_per_sec", "value": round(value, 3), "unit": "iters/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"train_ghost {N} mesh-bound Gaussians, {W}x{H}, {args.views} synthetic views, "
+                               f"SH degree 3, L1+D-SSIM, Adam, fixed N (no densification)",
+                   "n_gaussians": N, "width": W, "height": H, "views": args.views, "tile_pairs_D": D,
+                   "parallelism": f"dp{world} (views sharded, RCCL all-reduce of {59 * trainer.model.n_pad * 4 / 1e6:.1f} MB grads)"
+                   if world > 1 else "single GPU"},
+        "roofline": roofline,
+        "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},
+        "stage_hbm_gbs": {k: round(sb[k] / (stages[k][0] * 1e-3) / 1e9, 1) for k in stages if k in sb and stages[k][0] > 0},
+        "step_algorithmic_bytes": int(total_bytes),
+        "step_hbm_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        "final_loss": round(loss_end, 6),
+    }
+
+    # ---- aux: render_surgery fps on the same scene (frames shard across ranks, no collective)
+    if not args.no_aux:
+        rr = Renderer(rig, seq, g_init, W, H)
+        frames = [View(cams[i % len(cams)], timestep=i % T) for i in range(rank, args.render_frames, world)]
+        for v in frames[:5]:
+            rr.render(v, rgb8=True)
+        torch.cuda.synchronize(); barrier()
+        t1 = time.perf_counter()
+        for v in frames:
+            rr.render(v, rgb8=True)
+        torch.cuda.synchronize(); barrier()
+        dtr = time.perf_counter() - t1
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([dtr], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtr = float(tt.item())
+        log("render aux done")
+        out["aux"] = {"render_surgery_fps": round(args.render_frames / dtr, 2),
+                      "render_note": f"{args.render_frames} frames {W}x{H}, {N} Gaussians, GPU-resident rgb8 output, PNG encode excluded"}
+
+    # ---- CPU baseline (rank 0, single GPU run only): the PyTorch-CPU oracle on a bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_s, w_s, h_s = 20000, 480, 270
+        sec, D_s = cpu_baseline_train(n_s, w_s, h_s)
+        log(f"cpu baseline done: {sec:.2f}s")
+        scale = D_s / max(D, 1)
+        out["cpu_baseline"] = {
+            "value": round((1.0 / sec) * scale, 6), "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"PyTorch-CPU oracle (oracle/torch_splat.py), 1 full iteration at {n_s} Gaussians {w_s}x{h_s} "
+                      f"(D={D_s} tile pairs) took {sec:.2f} s; value extrapolated to the bench workload by the "
+                      f"tile-pair ratio D_sample/D = {scale:.5f}",
+            "sample_seconds": round(sec, 3)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,8 +115,8 @@ typedef struct omfs_raster_buffers {
   uint32_t* keys_tmp;     /* [dup_capacity][2] scratch for tiles longer than the LDS capacity    */
   uint32_t* sorted_ids;   /* [dup_capacity] per-tile front-to-back Gaussian ids                  */
   uint32_t dup_capacity;
-  uint32_t sort_lds_pairs; /* pairs per tile sorted inside LDS (0 = default 4096; 16 B of LDS each); longer
-                              tiles are sorted through keys/keys_tmp                              */
+  uint32_t sort_lds_pairs; /* longest tile list sorted inside LDS (0 = default 8960 pairs = 160 KB; 16 B of LDS
+                              each); longer lists are sorted through keys/keys_tmp in global memory */
   uint32_t* status;       /* [1] OMFS_STATUS_* bits, OR-ed by kernels (caller zeroes)            */
   /* per pixel */
   float* image;           /* [3][height][width]                                                  */
@@ -127,7 +127,13 @@ typedef struct omfs_raster_buffers {
 /* deform + project + colour for one view; zeroes and fills tile_count. face_xf [n_faces][16]. */
 int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_camera* cam,
                      const omfs_raster_buffers* rb, void* stream);
-/* scan tile_count -> tile_start/tile_order, scatter (depth,id) keys, per-tile radix depth sort */
+/* the three binning steps, separately launchable (omfs_bin_sort = all three in order):
+ *  scan    : tile_count -> tile_start (exclusive scan), tile_order, zeroed tile_cursor
+ *  scatter : (depth bits, id) pairs into their tile's segment of keys
+ *  sort    : per-tile radix sort by depth (ties by id) -> sorted_ids                              */
+int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
+int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
+int omfs_tile_sort(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 int omfs_bin_sort(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 /* front-to-back alpha composite -> image, final_T, n_contrib */
 int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);

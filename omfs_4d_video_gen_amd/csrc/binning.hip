@@ -87,37 +87,44 @@ __global__ __launch_bounds__(256) void scatter_keys_kernel(int n, const float4* 
 }
 
 // ------------------------------------------------------------------ per-tile radix sort
-constexpr int SORT_THREADS = 256;
-constexpr int SORT_WAVES = SORT_THREADS / 64;
-
 // Sorts n (depth,id) pairs ascending by depth bits; ping-pongs between a and b, returns the buffer
-// holding the result.  hist: SORT_WAVES*256 words, misc: 8 words (both LDS).
+// holding the result.  NT threads; hist: (NT/64)*256 words, misc: 8 words (both LDS).
+template <int NT>
 __device__ __forceinline__ uint2* radix_sort_pairs(uint2* a, uint2* b, int n, volatile uint32_t* hist,
                                                    volatile uint32_t* misc) {
+  constexpr int NW = NT / 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int seg = ((n + SORT_THREADS - 1) / SORT_THREADS) * 64;  // per-wave segment, multiple of 64
+  const int seg = ((n + NT - 1) / NT) * 64;  // per-wave segment, multiple of 64
   const int wbeg = min(n, wave * seg), wend = min(n, wbeg + seg);
   uint2 *src = a, *dst = b;
   for (int pass = 0; pass < 4; ++pass) {
     const int shift = pass * 8;
-    for (int k = tid; k < SORT_WAVES * 256; k += SORT_THREADS) hist[k] = 0;
+    for (int k = tid; k < NW * 256; k += NT) hist[k] = 0;
     if (tid == 0) misc[0] = 0;
     __syncthreads();
     for (int k = wbeg + lane; k < wend; k += 64) atomicAdd((uint32_t*)&hist[wave * 256 + ((src[k].x >> shift) & 255u)], 1u);
     __syncthreads();
-    // digit-major, wave-minor exclusive scan; thread t owns digit t
-    uint32_t c[SORT_WAVES], tot = 0;
-#pragma unroll
-    for (int w = 0; w < SORT_WAVES; ++w) { c[w] = hist[w * 256 + tid]; tot += c[w]; }
-    uint32_t incl = wave_incl_scan_u32(tot, lane);
-    if (lane == 63) misc[1 + wave] = incl;
-    if (tot == (uint32_t)n) misc[0] = 1;  // every key has this digit: pass is the identity
+    // digit-major, wave-minor exclusive scan; thread t < 256 owns digit t
+    uint32_t tot = 0, incl = 0;
+    if (tid < 256) {
+#pragma unroll 4
+      for (int w = 0; w < NW; ++w) tot += hist[w * 256 + tid];
+      incl = wave_incl_scan_u32(tot, lane);
+      if (lane == 63) misc[1 + wave] = incl;
+      if (tot == (uint32_t)n) misc[0] = 1;  // every key has this digit: pass is the identity
+    }
     __syncthreads();
-    uint32_t run = incl - tot;
-    for (int w = 0; w < wave; ++w) run += misc[1 + w];
     const bool skip = misc[0] != 0;
-#pragma unroll
-    for (int w = 0; w < SORT_WAVES; ++w) { hist[w * 256 + tid] = run; run += c[w]; }
+    if (tid < 256) {
+      uint32_t run = incl - tot;
+      for (int w = 0; w < wave; ++w) run += misc[1 + w];
+#pragma unroll 4
+      for (int w = 0; w < NW; ++w) {
+        const uint32_t c = hist[w * 256 + tid];
+        hist[w * 256 + tid] = run;
+        run += c;
+      }
+    }
     __syncthreads();
     if (skip) continue;
     for (int base = wbeg; base < wend; base += 64) {
@@ -151,8 +158,9 @@ __device__ __forceinline__ uint2* radix_sort_pairs(uint2* a, uint2* b, int n, vo
 }
 
 // Equal depth bits -> ascending Gaussian id (runs are almost always of length 1).
+template <int NT>
 __device__ __forceinline__ void fix_ties(uint2* s, int n) {
-  for (int k = threadIdx.x; k < n; k += SORT_THREADS) {
+  for (int k = threadIdx.x; k < n; k += NT) {
     const uint32_t key = s[k].x;
     const bool start = (k == 0 || s[k - 1].x != key) && (k + 1 < n && s[k + 1].x == key);
     if (!start) continue;
@@ -167,66 +175,105 @@ __device__ __forceinline__ void fix_ties(uint2* s, int n) {
   }
 }
 
-// grid = n_tiles (blocks walk tile_order: heavy tiles first), block = 256.
-// dynamic LDS = lds_cap*16 (two pair buffers) + (SORT_WAVES*256 + 8)*4.
-__global__ __launch_bounds__(SORT_THREADS) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
-                                                                 const uint32_t* __restrict__ tile_start,
-                                                                 uint2* __restrict__ keys, uint2* __restrict__ keys_tmp,
-                                                                 uint32_t* __restrict__ sorted_ids, int lds_cap) {
+// grid = n_tiles (blocks walk tile_order: heavy tiles first), block = NT.  A launch handles the
+// tiles with n_lo < n <= n_hi; lists longer than lds_cap are sorted through keys/keys_tmp (global).
+// dynamic LDS = lds_cap*16 (two pair buffers) + ((NT/64)*256 + 8)*4.
+template <int NT>
+__global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
+                                                       const uint32_t* __restrict__ tile_start,
+                                                       uint2* __restrict__ keys, uint2* __restrict__ keys_tmp,
+                                                       uint32_t* __restrict__ sorted_ids, int lds_cap, int n_lo, int n_hi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NW = NT / 64;
   uint2* bufA = reinterpret_cast<uint2*>(smem);
   uint2* bufB = bufA + lds_cap;
   volatile uint32_t* hist = reinterpret_cast<volatile uint32_t*>(bufB + lds_cap);
-  volatile uint32_t* misc = hist + SORT_WAVES * 256;
+  volatile uint32_t* misc = hist + NW * 256;
   const uint32_t tile = tile_order[blockIdx.x];
   const uint32_t s = tile_start[tile];
   const int n = (int)(tile_start[tile + 1] - s);
-  if (n == 0) return;
+  if (n <= n_lo || n > n_hi) return;
   const int tid = threadIdx.x;
   if (n <= lds_cap) {
-    for (int k = tid; k < n; k += SORT_THREADS) bufA[k] = keys[s + k];
+    for (int k = tid; k < n; k += NT) bufA[k] = keys[s + k];
     __syncthreads();
-    uint2* res = n > 1 ? radix_sort_pairs(bufA, bufB, n, hist, misc) : bufA;
-    fix_ties(res, n);
+    uint2* res = n > 1 ? radix_sort_pairs<NT>(bufA, bufB, n, hist, misc) : bufA;
+    fix_ties<NT>(res, n);
     __syncthreads();
-    for (int k = tid; k < n; k += SORT_THREADS) sorted_ids[s + k] = res[k].y;
+    for (int k = tid; k < n; k += NT) sorted_ids[s + k] = res[k].y;
   } else {
-    uint2* res = radix_sort_pairs(keys + s, keys_tmp + s, n, hist, misc);
+    uint2* res = radix_sort_pairs<NT>(keys + s, keys_tmp + s, n, hist, misc);
     __syncthreads();
-    fix_ties(res, n);
+    fix_ties<NT>(res, n);
     __syncthreads();
-    for (int k = tid; k < n; k += SORT_THREADS) sorted_ids[s + k] = res[k].y;
+    for (int k = tid; k < n; k += NT) sorted_ids[s + k] = res[k].y;
   }
 }
+
+constexpr int SORT_SMALL_NT = 256, SORT_SMALL_CAP = 2048;
+constexpr int SORT_LARGE_NT = 1024, SORT_LARGE_CAP_DEFAULT = 8960;
+constexpr size_t sort_lds_bytes(int cap, int nt) { return (size_t)cap * 16 + ((nt / 64) * 256 + 8) * 4; }
 
 }  // namespace omfs
 
 using namespace omfs;
 
-extern "C" int omfs_bin_sort(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb,
-                             void* stream) {
-  OMFS_REQUIRE(g && cam && rb, "null pointer");
+static int check_bin_args(const omfs_camera* cam, const omfs_raster_buffers* rb) {
+  OMFS_REQUIRE(cam && rb, "null pointer");
   OMFS_REQUIRE(rb->g2 && rb->tile_count && rb->tile_start && rb->tile_cursor && rb->tile_order && rb->keys &&
                    rb->keys_tmp && rb->sorted_ids && rb->status, "raster buffers");
   OMFS_REQUIRE(rb->dup_capacity > 0, "dup_capacity");
-  const int gx = cdiv(cam->width, OMFS_TILE), gy = cdiv(cam->height, OMFS_TILE), n_tiles = gx * gy;
-  hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, rb->tile_count, rb->tile_start,
-                     rb->tile_cursor, rb->tile_order, rb->dup_capacity, rb->status);
-  OMFS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(scatter_keys_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, (const float4*)rb->g2, gx,
-                     n_tiles, rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
-  OMFS_CHECK_HIP(hipGetLastError());
-  const int cap = rb->sort_lds_pairs ? (int)rb->sort_lds_pairs : 4096;
-  OMFS_REQUIRE(cap >= 256 && (size_t)cap * 16 + (SORT_WAVES * 256 + 8) * 4 <= 160 * 1024, "sort_lds_pairs");
-  const size_t lds = (size_t)cap * 16 + (SORT_WAVES * 256 + 8) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL(tile_sort_kernel, dim3(n_tiles), dim3(SORT_THREADS), lds, s, rb->tile_order, rb->tile_start,
-                     (uint2*)rb->keys, (uint2*)rb->keys_tmp, rb->sorted_ids, cap);
+  return OMFS_OK;
+}
+
+extern "C" int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
+  if (int rc = check_bin_args(cam, rb)) return rc;
+  const int n_tiles = cdiv(cam->width, OMFS_TILE) * cdiv(cam->height, OMFS_TILE);
+  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles, rb->tile_count,
+                     rb->tile_start, rb->tile_cursor, rb->tile_order, rb->dup_capacity, rb->status);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
+}
+
+extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb,
+                                void* stream) {
+  if (int rc = check_bin_args(cam, rb)) return rc;
+  OMFS_REQUIRE(g && g->n > 0, "gaussians");
+  const int gx = cdiv(cam->width, OMFS_TILE), n_tiles = gx * cdiv(cam->height, OMFS_TILE);
+  hipLaunchKernelGGL(scatter_keys_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, (hipStream_t)stream, g->n,
+                     (const float4*)rb->g2, gx, n_tiles, rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_tile_sort(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
+  if (int rc = check_bin_args(cam, rb)) return rc;
+  const int n_tiles = cdiv(cam->width, OMFS_TILE) * cdiv(cam->height, OMFS_TILE);
+  // short lists: 256 threads, 2048 pairs in LDS (36 KB -> 4 workgroups per CU);
+  // long lists : 1024 threads, sort_lds_pairs pairs in LDS (default 8960 = 160 KB, one workgroup per CU)
+  const int cap_large = rb->sort_lds_pairs ? (int)rb->sort_lds_pairs : SORT_LARGE_CAP_DEFAULT;
+  OMFS_REQUIRE(cap_large >= 256 && sort_lds_bytes(cap_large, SORT_LARGE_NT) <= 160 * 1024, "sort_lds_pairs");
+  const int cap_small = cap_large < SORT_SMALL_CAP ? cap_large : SORT_SMALL_CAP;
+  static bool attr_set = false;  // one process per GPU: set once
+  if (!attr_set) {
+    OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)tile_sort_kernel<SORT_LARGE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tile_sort_kernel<SORT_LARGE_NT>, dim3(n_tiles), dim3(SORT_LARGE_NT), sort_lds_bytes(cap_large, SORT_LARGE_NT), s,
+                     rb->tile_order, rb->tile_start, (uint2*)rb->keys, (uint2*)rb->keys_tmp, rb->sorted_ids, cap_large,
+                     cap_small, 0x7fffffff);
+  OMFS_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(tile_sort_kernel<SORT_SMALL_NT>, dim3(n_tiles), dim3(SORT_SMALL_NT), sort_lds_bytes(cap_small, SORT_SMALL_NT), s,
+                     rb->tile_order, rb->tile_start, (uint2*)rb->keys, (uint2*)rb->keys_tmp, rb->sorted_ids, cap_small,
+                     0, cap_small);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_bin_sort(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb,
+                             void* stream) {
+  if (int rc = omfs_bin_scan(cam, rb, stream)) return rc;
+  if (int rc = omfs_bin_scatter(g, cam, rb, stream)) return rc;
+  return omfs_tile_sort(cam, rb, stream);
 }

@@ -41,7 +41,7 @@ class Rasterizer:
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
         self.n_tiles = self.gx * self.gy
         # 288 GB of HBM: be generous rather than re-allocate; overflow is flagged by the device
-        self.dup_capacity = int(dup_capacity if dup_capacity else max(1 << 20, 24 * n))
+        self.dup_capacity = int(dup_capacity if dup_capacity else max(1 << 20, 64 * n))
         dev = self.device
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
         self.g0, self.g1, self.g2 = z(n, 4), z(n, 4), z(n, 4)

@@ -71,13 +71,26 @@ class SyntheticRig:
     lmk_bary_coords: np.ndarray  # (68,3) f32
 
 
+def _smooth_fields(rng, v: np.ndarray, k: int, std: float) -> np.ndarray:
+    """(V,3,k) blendshape directions that vary smoothly over the surface (like FLAME's PCA bases;
+    white noise per vertex would crumple the mesh): direction_k * cos(2 pi f_k . x / 0.1 + phi_k),
+    per-vertex standard deviation `std` per unit coefficient."""
+    f = rng.standard_normal((k, 3)) * 0.6
+    phi = rng.uniform(0, 2 * math.pi, k)
+    d = rng.standard_normal((k, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    phase = 2 * math.pi * (v.astype(np.float64) @ f.T) / 0.1 + phi[None, :]          # (V,k)
+    field = np.cos(phase) * (std * math.sqrt(2.0) * math.sqrt(3.0))                     # unit-variance per axis on average
+    return (field[:, None, :] * d.T[None, :, :]).astype(np.float32)
+
+
 def make_rig(seed: int = 0, shape_std: float = 1e-3, pose_std: float = 1e-4) -> SyntheticRig:
     rng = np.random.default_rng(seed)
     v, f = ellipsoid_mesh()
     V = v.shape[0]
     assert V == V_FLAME
-    shapedirs = (rng.standard_normal((V, 3, N_SHAPE + N_EXPR)) * shape_std).astype(np.float32)
-    posedirs = (rng.standard_normal((V, 3, N_POSEDIRS)) * pose_std).astype(np.float32)
+    shapedirs = _smooth_fields(rng, v, N_SHAPE + N_EXPR, shape_std)
+    posedirs = _smooth_fields(rng, v, N_POSEDIRS, pose_std)
     rx, ry, rz = HEAD_RADII
     joints = np.array([
         [0.0, -0.9 * ry, -0.2 * rz],     # root (base of neck)

@@ -1,0 +1,191 @@
+"""Training / rendering loops of the engine (what the absent `gaussian_avatars_repo/train.py` and
+`render.py` did per iteration / per frame; call sites `02_Visual_Engine/train_ghost.py:227-271`,
+`render_surgery.py:289-315`; algorithm: SURVEY.md Appendix A items 1-9).
+
+One process per GPU.  A training step of rank r is
+    FLAME(t) -> triangle frames -> project -> bin/sort -> composite -> L1+D-SSIM -> composite bwd
+    -> projection bwd (+ regularisers) -> [RCCL all-reduce of the one [59][n_pad] gradient buffer]
+    -> fused Adam
+everything enqueued on the current HIP stream without a host sync.  Views shard across ranks
+(rank r takes view `step*world + r`): the only exchange step on the path is the gradient sum.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from .flame_rig import DeviceFlame, FlameRig
+from .gaussians import GaussianModel, NPLANES
+from .rasterizer import Adam, Rasterizer, default_lr_planes, make_camera_struct
+
+STAGES = ("flame", "project", "bin_scan", "bin_scatter", "tile_sort", "composite_fwd", "loss", "composite_bwd",
+          "project_bwd", "allreduce", "adam")
+
+
+@dataclass
+class View:
+    camera: dict          # synthetic.make_camera / dataset.camera_from_frame schema
+    timestep: int
+    target: torch.Tensor | None = None   # [3][H][W] fp32 on the device (training only)
+    name: str = ""
+
+
+class StageTimer:
+    """HIP events between stages on the stream the kernels run on (torch's current stream is the
+    stream handed to every C-ABI call).  Disabled timers cost nothing."""
+
+    def __init__(self, enabled=False):
+        self.enabled = enabled
+        self.records = []   # list of (stage, start_event, end_event)
+        self._last = None
+
+    def begin(self):
+        if self.enabled:
+            self._last = torch.cuda.Event(enable_timing=True)
+            self._last.record()
+
+    def mark(self, stage: str):
+        if self.enabled:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.records.append((stage, self._last, e))
+            self._last = e
+
+    def summary(self) -> dict:
+        """stage -> (mean ms, count); call after a device sync."""
+        acc: dict = {}
+        for stage, a, b in self.records:
+            acc.setdefault(stage, []).append(a.elapsed_time(b))
+        return {k: (float(np.mean(v)), len(v)) for k, v in acc.items()}
+
+
+def expon_lr(step, lr_init, lr_final, max_steps, delay_mult=0.01, delay_steps=0):
+    """3DGS `get_expon_lr_func`: log-linear interpolation lr_init -> lr_final."""
+    if lr_init == lr_final or max_steps <= 0:
+        return lr_init
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
+class Trainer:
+    def __init__(self, rig: FlameRig, flame_params: dict, gaussians: dict, views: list, width: int, height: int,
+                 bg=(0.0, 0.0, 0.0), device="cuda", iterations: int = 30000, lambda_dssim: float = 0.2,
+                 reg=(0.01, 1.0, 1.0, 0.6), position_lr_init=5e-3, position_lr_final=5e-5,
+                 sh_degree_max: int = 3, sh_increase_every: int = 1000, start_sh_degree: int = 0,
+                 dup_capacity: int | None = None, rank: int = 0, world_size: int = 1, process_group=None):
+        self.device = torch.device(device)
+        self.rank, self.world = rank, world_size
+        self.pg = process_group
+        self.dflame = DeviceFlame(rig, flame_params, device=device)
+        self.model = GaussianModel(gaussians, device=device)
+        self.rast = Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity)
+        self.rast._ensure_bwd()
+        self.views = views
+        self.bg = tuple(bg)
+        self.iterations = iterations
+        self.lambda_dssim = lambda_dssim
+        self.reg = reg
+        self.lr_planes = default_lr_planes(position_lr=position_lr_init)
+        self.pos_lr = (position_lr_init, position_lr_final)
+        self.opt = Adam(self.model, self.lr_planes)
+        self.grads = torch.zeros(NPLANES, self.model.n_pad, device=self.device)
+        self.sh_degree_max, self.sh_every, self.sh_degree = sh_degree_max, sh_increase_every, start_sh_degree
+        self.step_idx = 0
+        self.timer = StageTimer(False)
+        self._cams = {}
+
+    def _cam(self, view: View, sh_degree: int):
+        key = (id(view), sh_degree)
+        c = self._cams.get(key)
+        if c is None:
+            c = make_camera_struct(view.camera, sh_degree=sh_degree, bg=self.bg)
+            self._cams[key] = c
+        return c
+
+    def view_for_step(self, step: int) -> View:
+        return self.views[(step * self.world + self.rank) % len(self.views)]
+
+    def step(self) -> None:
+        """One training iteration of this rank (enqueue only)."""
+        it = self.step_idx
+        view = self.view_for_step(it)
+        if it > 0 and it % self.sh_every == 0 and self.sh_degree < self.sh_degree_max:
+            self.sh_degree += 1
+        cam = self._cam(view, self.sh_degree)
+        r, tm = self.rast, self.timer
+        tm.begin()
+        _, face_xf = self.dflame.face_frames(view.timestep, 1)
+        tm.mark("flame")
+        fxf = face_xf[0]
+        r.project(self.model, fxf, cam); tm.mark("project")
+        from .. import _lib as L
+        lib = L.load()
+        g = r._gauss(self.model)
+        s = L.stream_ptr()
+        L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); tm.mark("bin_scan")
+        L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
+        L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
+        r.composite(cam); tm.mark("composite_fwd")
+        r.loss.zero_()
+        r.loss_l1_ssim(view.target, self.lambda_dssim); tm.mark("loss")
+        r.dsplat.zero_()
+        gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage))
+        L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")
+        L.check(lib.omfs_count_visible(r.rb, r.n, L.ptr(r.n_visible), s), "omfs_count_visible")
+        rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
+        L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+            tm.mark("allreduce")
+        lr = expon_lr(it, self.pos_lr[0], self.pos_lr[1], self.iterations)
+        self.lr_planes[0:3] = lr
+        self.opt.set_lr(self.lr_planes)
+        self.opt.step(self.grads, 1.0 / self.world); tm.mark("adam")
+        self.step_idx += 1
+
+    def loss_value(self) -> float:
+        """Host sync: loss of the last step on this rank."""
+        return float(self.rast.loss.item())
+
+
+class Renderer:
+    """Per-frame rendering of a (possibly FLAME-edited) sequence: render_surgery's inner loop."""
+
+    def __init__(self, rig: FlameRig, flame_params: dict, gaussians: dict, width: int, height: int,
+                 bg=(0.0, 0.0, 0.0), device="cuda", sh_degree: int = 3, dup_capacity: int | None = None,
+                 flame_batch: int = 16):
+        self.device = torch.device(device)
+        self.dflame = DeviceFlame(rig, flame_params, device=device)
+        self.model = GaussianModel(gaussians, device=device)
+        self.rast = Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity)
+        self.bg, self.sh_degree = tuple(bg), sh_degree
+        self.timer = StageTimer(False)
+        self._cams = {}
+
+    def render(self, view: View, rgb8: bool = False):
+        """Enqueue one frame; returns the reused image tensor ([3][H][W] fp32 or [H][W][3] uint8)."""
+        key = id(view)
+        cam = self._cams.get(key)
+        if cam is None:
+            cam = make_camera_struct(view.camera, sh_degree=self.sh_degree, bg=self.bg)
+            self._cams[key] = cam
+        r, tm = self.rast, self.timer
+        tm.begin()
+        _, face_xf = self.dflame.face_frames(view.timestep, 1); tm.mark("flame")
+        from .. import _lib as L
+        lib = L.load()
+        g = r._gauss(self.model)
+        s = L.stream_ptr()
+        r.project(self.model, face_xf[0], cam); tm.mark("project")
+        L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); tm.mark("bin_scan")
+        L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
+        L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
+        r.composite(cam); tm.mark("composite_fwd")
+        if rgb8:
+            out = r.to_rgb8(); tm.mark("rgb8")
+            return out
+        return r.image

@@ -46,7 +46,8 @@ def test_forward_matches_oracle(n, width, height, bg):
     fx = face_xf[0].cpu()
     # frames of the tiny pole triangles amplify 1-ulp vertex differences by 1/edge: loose here,
     # bit-exact against the C oracle in test_gpu_bitexact.py
-    assert torch.allclose(fx[:, :9].reshape(-1, 3, 3), R_f, atol=3e-3), f"R_f max err {(fx[:, :9].reshape(-1, 3, 3) - R_f).abs().max()}"
+    dR = (fx[:, :9].reshape(-1, 3, 3) - R_f).abs().amax((1, 2))
+    assert bool((dR <= 1e-4 / s_f + 1e-5).all()), f"R_f max err {dR.max()} (scaled {float((dR * s_f).max())})"
     assert torch.allclose(fx[:, 9:12], c_f, atol=1e-6)
     assert torch.allclose(fx[:, 12], s_f, rtol=1e-4)
 
