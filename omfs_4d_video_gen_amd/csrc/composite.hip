@@ -1,22 +1,92 @@
-// Front-to-back alpha compositing, forward and backward.  One 256-thread workgroup per 16x16 tile
-// (wave w owns pixel rows 4w..4w+3), tile lists staged through LDS in batches of 256 splats
-// (one coalesced id load + three 16-byte record gathers per lane, then conflict-free broadcast
-// reads).  Heavy tiles are dispatched first (tile_order).
+// Front-to-back alpha compositing, forward and backward, for gfx950 (wave64).
+//
+// Mapping: one 256-thread workgroup per 16x16 tile; wave w owns the 8x8 quadrant (w&1, w>>1), lane l
+// the pixel (l&7, l>>3) of it.  The tile's sorted list is staged through LDS in batches of 256
+// splats: each thread gathers one splat (id + three 16-byte records), pre-scales it to the log2
+// domain and decides, per quadrant, whether the splat can reach alpha >= 1/255 anywhere in that
+// quadrant (exact minimum of the conic's quadratic form over the quadrant's pixel box, with
+// slack).  The four staging waves publish those decisions as 64-bit ballots; each consumer wave
+// then walks ONLY the set bits of its own quadrant's masks with scalar bit scans, so splats that
+// cannot touch a quadrant cost it no vector instruction at all.  This is what keeps the serial
+// depth of silhouette tiles (pixels that never saturate walk the whole list) short.
+// Heavy tiles are dispatched first (tile_order).
 //
 // Spec: SURVEY.md Appendix A items 6-7: integer pixel coordinate is the sample position;
 // power = -0.5(A dx^2 + C dy^2) - B dx dy, skip power > 0; alpha = min(0.99, o exp(power)), skip
 // alpha < 1/255; stop a pixel before a splat that would take T below 1e-4; out = C + T bg.
+// Evaluated here as alpha = exp2(power*log2e + log2 o): same value to ~1e-6 relative.
 #include "common.hpp"
 
 namespace omfs {
 
 constexpr int CB = 256;  // splats per LDS batch == threads per tile
-constexpr int SB = 64;   // backward: splats per reduction sub-batch
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LOG2_INV255 = -7.994353436858858f;  // log2(1/255)
 
 struct CompCam {
   int width, height, gx;
   float bg[3];
 };
+
+// Minimum of q(d) = A dx^2 + 2 B dx dy + C dy^2 (positive definite) over the box
+// [dxl,dxh] x [dyl,dyh]; `mag` returns the magnitude of the terms at the minimiser (for slack).
+__device__ __forceinline__ float qmin_box(float A, float B, float C, float nBoC, float nBoA, float dxl, float dxh,
+                                          float dyl, float dyh, float& mag) {
+  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) { mag = 0.f; return 0.f; }
+  float best = 3.0e38f;
+  mag = 0.f;
+  auto cand = [&](float dx, float dy) {
+    const float t0 = A * dx * dx, t1 = 2.f * B * dx * dy, t2 = C * dy * dy;
+    const float q = t0 + t1 + t2;
+    if (q < best) { best = q; mag = t0 + fabsf(t1) + t2; }
+  };
+  cand(dxl, fminf(fmaxf(nBoC * dxl, dyl), dyh));
+  cand(dxh, fminf(fmaxf(nBoC * dxh, dyl), dyh));
+  cand(fminf(fmaxf(nBoA * dyl, dxl), dxh), dyl);
+  cand(fminf(fmaxf(nBoA * dyh, dxl), dxh), dyh);
+  return best;
+}
+
+// Per-splat staging: log2-domain coefficients + 4-bit quadrant mask.
+struct Staged {
+  float4 a;  // mx, my, A2 = -0.5*log2e*A, B2 = -log2e*B
+  float4 b;  // C2 = -0.5*log2e*C, lo = log2(opacity), r, g
+  float c;   // b
+  uint32_t qmask;
+};
+
+__device__ __forceinline__ Staged stage_splat(const float4 g0, const float4 g1, const float g2x, int tx0, int ty0) {
+  Staged s;
+  const float A = g0.z, B = g0.w, C = g1.x, o = g1.y;
+  const float lo = __log2f(fmaxf(o, 1e-30f));
+  s.a = make_float4(g0.x, g0.y, -0.5f * LOG2E * A, -LOG2E * B);
+  s.b = make_float4(-0.5f * LOG2E * C, lo, g1.z, g1.w);
+  s.c = g2x;
+  // contributes somewhere iff q <= qmax = 2 ln(255 o) = 2 ln2 (lo - log2(1/255))
+  const float qmax = 2.f * 0.6931471805599453f * (lo - LOG2_INV255);
+  uint32_t m = 0;
+  if (qmax >= 0.f) {
+    if (!(A > 0.f && C > 0.f)) {
+      m = 0xFu;  // degenerate conic: never cull
+    } else {
+      const float nBoC = -B / C, nBoA = -B / A;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x0 = (float)(tx0 + (q & 1) * 8), y0 = (float)(ty0 + (q >> 1) * 8);
+        float mag;
+        const float qm = qmin_box(A, B, C, nBoC, nBoA, g0.x - (x0 + 7.f), g0.x - x0, g0.y - (y0 + 7.f), g0.y - y0, mag);
+        if (qm - 4e-5f * mag - 1e-3f <= qmax) m |= 1u << q;
+      }
+    }
+  }
+  s.qmask = m;
+  return s;
+}
+
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
 
 __global__ __launch_bounds__(256) void composite_fwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
                                                             const uint32_t* __restrict__ tile_start,
@@ -26,46 +96,66 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompCam cam, const u
                                                             float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
   __shared__ float4 s0[CB];
   __shared__ float4 s1[CB];
-  __shared__ float sb[CB];
+  __shared__ float s2[CB];
+  __shared__ unsigned long long qm[4][4];  // [quadrant][staging wave]
   const uint32_t tile = tile_order[blockIdx.x];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx0 = (tile % cam.gx) * OMFS_TILE, ty0 = (tile / cam.gx) * OMFS_TILE;
-  const int px = tx0 + (tid & 15), py = ty0 + (tid >> 4);
+  const int px = tx0 + (wave & 1) * 8 + (lane & 7), py = ty0 + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < cam.width && py < cam.height;
   const float fx = (float)px, fy = (float)py;
   const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
-  uint32_t contributor = 0, last = 0;
+  uint32_t last = 0;
   bool done = !inside;
   for (uint32_t b = beg; b < end; b += CB) {
-    if (__syncthreads_count(done) == CB) break;
+    const bool wave_done = __ballot(!done) == 0ull;
+    if (__syncthreads_and(wave_done)) break;
     const uint32_t k = b + tid;
+    uint32_t mask = 0;
     if (k < end) {
       const uint32_t id = sorted_ids[k];
-      s0[tid] = g0[id];
-      s1[tid] = g1[id];
-      sb[tid] = g2[id].x;
+      const Staged st = stage_splat(g0[id], g1[id], g2[id].x, tx0, ty0);
+      s0[tid] = st.a; s1[tid] = st.b; s2[tid] = st.c;
+      mask = st.qmask;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned long long bal = __ballot((mask >> q) & 1u);
+      if (lane == 0) qm[q][wave] = bal;
     }
     __syncthreads();
-    const int cnt = (int)min((uint32_t)CB, end - b);
-    if (!done) {
-      for (int j = 0; j < cnt; ++j) {
-        ++contributor;
-        const float4 a = s0[j];
-        const float4 c = s1[j];
-        const float dx = a.x - fx, dy = a.y - fy;
-        const float power = fma_(-0.5f, fma_(a.z * dx, dx, c.x * dy * dy), -(a.w * dx) * dy);
-        if (power > 0.f) continue;
-        const float alpha = fminf(0.99f, c.y * __expf(power));
-        if (alpha < (1.f / 255.f)) continue;
-        const float Tn = T * (1.f - alpha);
-        if (Tn < 1e-4f) { done = true; break; }
-        const float w = alpha * T;
-        C0 = fma_(c.z, w, C0);
-        C1 = fma_(c.w, w, C1);
-        C2 = fma_(sb[j], w, C2);
-        T = Tn;
-        last = contributor;
+    if (!wave_done) {
+      const uint32_t base = b - beg;
+      for (int g = 0; g < 4; ++g) {
+        unsigned long long m = uniform_u64(qm[wave][g]);
+        while (m) {
+          const int j = g * 64 + __builtin_ctzll(m);
+          m &= m - 1ull;
+          const float4 a = s0[j];
+          const float4 c = s1[j];
+          const float cb = s2[j];
+          if (!done) {
+            const float dx = a.x - fx, dy = a.y - fy;
+            const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
+            const float e = p2 + c.y;
+            if (p2 <= 0.f && e >= LOG2_INV255) {
+              const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
+              const float Tn = T * (1.f - alpha);
+              if (Tn < 1e-4f) {
+                done = true;
+              } else {
+                const float w = alpha * T;
+                C0 = fma_(c.z, w, C0);
+                C1 = fma_(c.w, w, C1);
+                C2 = fma_(cb, w, C2);
+                T = Tn;
+                last = base + (uint32_t)j + 1u;
+              }
+            }
+          }
+        }
+        if (__ballot(!done) == 0ull) break;
       }
     }
   }
@@ -79,10 +169,11 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompCam cam, const u
   }
 }
 
-// Backward: same tile/pixel mapping, list walked back to front.  Per splat the 256 pixel
-// contributions are reduced with DPP wave sums, the four waves meet in LDS, and one 64-byte
-// record per (tile, splat) is added to dsplat with float atomics (16 lanes per record, so every
-// atomic wave-instruction is four whole 64-byte segments: MI355X_MICROARCH "Global float atomics").
+// Backward: same mapping, list walked back to front, same masks.  Per visited splat the 64 pixel
+// contributions of a wave are reduced with DPP, the (up to four) waves that touched the splat
+// meet in LDS, and one 64-byte record per (tile, splat) is added to dsplat with float atomics:
+// 16 lanes per record, so every atomic wave-instruction covers whole 64-byte segments
+// (MI355X_MICROARCH "Global float atomics").
 __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
                                                             const uint32_t* __restrict__ tile_start,
                                                             const uint32_t* __restrict__ sorted_ids,
@@ -93,13 +184,15 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
                                                             const float* __restrict__ dimage, float* __restrict__ dsplat) {
   __shared__ float4 s0[CB];
   __shared__ float4 s1[CB];
-  __shared__ float sb[CB];
+  __shared__ float s2[CB];
   __shared__ uint32_t sid[CB];
-  __shared__ float red[SB][4][9 + 2];  // [splat in sub-batch][wave][value], padded to 11
+  __shared__ unsigned long long qm[4][4];
+  __shared__ float red[64][4][9 + 2];  // [splat in 64-group][wave][value], padded to 11
+  __shared__ uint32_t s_max;
   const uint32_t tile = tile_order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx0 = (tile % cam.gx) * OMFS_TILE, ty0 = (tile / cam.gx) * OMFS_TILE;
-  const int px = tx0 + (tid & 15), py = ty0 + (tid >> 4);
+  const int px = tx0 + (wave & 1) * 8 + (lane & 7), py = ty0 + (wave >> 1) * 8 + (lane >> 3);
   const bool inside = px < cam.width && py < cam.height;
   const float fx = (float)px, fy = (float)py;
   const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
@@ -113,11 +206,13 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;         // colour accumulated behind the current splat
   float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;  // last alpha / colour
   const float bgdot = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];
-  // the block's maximum contributor bounds how much of the list has to be visited
-  __shared__ uint32_t s_max;
+  // wave / block maxima of the last contributor bound what has to be visited
+  uint32_t wmax = last;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
   if (tid == 0) s_max = 0;
   __syncthreads();
-  atomicMax(&s_max, last);
+  if (lane == 0) atomicMax(&s_max, wmax);
   __syncthreads();
   const uint32_t n_visit = s_max;
   if (n_visit == 0) return;
@@ -125,42 +220,47 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
   for (int bi = (int)n_batches - 1; bi >= 0; --bi) {
     const uint32_t b = beg + (uint32_t)bi * CB;
     const int cnt = (int)min((uint32_t)CB, n_visit - (uint32_t)bi * CB);
-    __syncthreads();
+    uint32_t mask = 0;
     if (tid < cnt) {
       const uint32_t id = sorted_ids[b + tid];
+      const Staged st = stage_splat(g0[id], g1[id], g2[id].x, tx0, ty0);
       sid[tid] = id;
-      s0[tid] = g0[id];
-      s1[tid] = g1[id];
-      sb[tid] = g2[id].x;
+      s0[tid] = st.a; s1[tid] = st.b; s2[tid] = st.c;
+      mask = st.qmask;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned long long bal = __ballot((mask >> q) & 1u);
+      if (lane == 0) qm[q][wave] = bal;
     }
     __syncthreads();
-    for (int sbase = ((cnt - 1) / SB) * SB; sbase >= 0; sbase -= SB) {
-      const int scnt = min(SB, cnt - sbase);
-      for (int jj = scnt - 1; jj >= 0; --jj) {
-        const int j = sbase + jj;
-        const uint32_t contributor = (uint32_t)bi * CB + (uint32_t)j + 1u;  // 1-based position in the list
-        const bool mine = contributor <= last;
-        if (__ballot(mine) == 0ull) {  // wave-uniform: nothing behind this splat for any of our pixels
-          if (lane == 63) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) red[jj][wave][q] = 0.f;
-          }
-          continue;
-        }
+    for (int g = (cnt - 1) / 64; g >= 0; --g) {
+      const uint32_t cbase = (uint32_t)bi * CB + (uint32_t)g * 64u;  // list position of bit 0, 0-based
+      unsigned long long m = uniform_u64(qm[wave][g]);
+      // drop splats behind every pixel of this wave's last contributor
+      if (wmax <= cbase) m = 0ull;
+      else if (wmax - cbase < 64u) m &= (1ull << (wmax - cbase)) - 1ull;
+      const unsigned long long m_done = m;
+      while (m) {
+        const int jb = 63 - __builtin_clzll(m);
+        m &= ~(1ull << jb);
+        const int j = g * 64 + jb;
+        const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
         float v[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) v[q] = 0.f;
-        if (mine) {
-          const float4 a = s0[j];
-          const float4 c = s1[j];
+        const float4 a = s0[j];
+        const float4 c = s1[j];
+        const float cb = s2[j];
+        if (contributor <= last) {
           const float dx = a.x - fx, dy = a.y - fy;
-          const float power = fma_(-0.5f, fma_(a.z * dx, dx, c.x * dy * dy), -(a.w * dx) * dy);
-          const float G = __expf(power);
-          const float alpha = fminf(0.99f, c.y * G);
-          if (power <= 0.f && alpha >= (1.f / 255.f)) {
+          const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
+          const float e = p2 + c.y;
+          if (p2 <= 0.f && e >= LOG2_INV255) {
+            const float oG = __builtin_amdgcn_exp2f(e);   // opacity * G
+            const float alpha = fminf(0.99f, oG);
             T = T / (1.f - alpha);
             const float w = alpha * T;
-            const float cb = sb[j];
             v[6] = w * dL0; v[7] = w * dL1; v[8] = w * dL2;  // dL/dcolour
             acc0 = fma_(la, lc0, (1.f - la) * acc0);
             acc1 = fma_(la, lc1, (1.f - la) * acc1);
@@ -169,30 +269,38 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
             float dLa = (c.z - acc0) * dL0 + (c.w - acc1) * dL1 + (cb - acc2) * dL2;
             dLa = dLa * T + (-T_final / (1.f - alpha)) * bgdot;
             // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream
-            // rasteriser does (DESIGN.md "Frozen conventions").
-            const float dLG = c.y * dLa, gdx = G * dx, gdy = G * dy;
-            v[0] = dLG * (-gdx * a.z - gdy * a.w);  // d mean2d.x (dx = mean - pixel)
-            v[1] = dLG * (-gdy * c.x - gdx * a.w);  // d mean2d.y
-            v[2] = -0.5f * gdx * dx * dLG;          // d conic.a
-            v[3] = -gdx * dy * dLG;                 // d conic.b (B multiplies dx*dy once)
-            v[4] = -0.5f * gdy * dy * dLG;          // d conic.c
-            v[5] = G * dLa;                         // d opacity
+            // rasteriser does (DESIGN.md "Frozen conventions").  With A2 = -0.5 log2e A etc.:
+            //   o*G*dL/dalpha = dL/dG * G ;  dG/ddx = -G (A dx + B dy) = G (2 A2 dx + B2 dy) / log2e
+            const float gL = oG * dLa;                     // dL/dG * G  (opacity folded in)
+            const float ix = (2.f * a.z * dx + a.w * dy) * (1.f / LOG2E), iy = (2.f * c.x * dy + a.w * dx) * (1.f / LOG2E);
+            v[0] = gL * ix;                 // d mean2d.x (dx = mean - pixel)
+            v[1] = gL * iy;                 // d mean2d.y
+            v[2] = -0.5f * gL * dx * dx;    // d conic.a
+            v[3] = -gL * dx * dy;           // d conic.b (B multiplies dx*dy once)
+            v[4] = -0.5f * gL * dy * dy;    // d conic.c
+            v[5] = __builtin_amdgcn_exp2f(p2) * dLa;  // d opacity: G * dL/dalpha
           }
         }
 #pragma unroll
         for (int q = 0; q < 9; ++q) v[q] = wave_sum_to_lane63(v[q]);
         if (lane == 63) {
 #pragma unroll
-          for (int q = 0; q < 9; ++q) red[jj][wave][q] = v[q];
+          for (int q = 0; q < 9; ++q) red[jb][wave][q] = v[q];
         }
       }
+      // publish which splats of this group this wave reduced
+      if (lane == 0) qm[wave][g] = m_done;
       __syncthreads();
       // 16 lanes per 64-byte splat record; lane q < 9 adds value q
-      for (int r = tid; r < scnt * 16; r += CB) {
+      const int gcnt = min(64, cnt - g * 64);
+      for (int r = tid; r < gcnt * 16; r += CB) {
         const int jj = r >> 4, q = r & 15;
         if (q < 9) {
-          const float sum = (red[jj][0][q] + red[jj][1][q]) + (red[jj][2][q] + red[jj][3][q]);
-          if (sum != 0.f) atomicAdd(&dsplat[(size_t)sid[sbase + jj] * 16 + q], sum);
+          float sum = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+            if ((qm[w][g] >> jj) & 1ull) sum += red[jj][w][q];
+          if (sum != 0.f) atomicAdd(&dsplat[(size_t)sid[g * 64 + jj] * 16 + q], sum);
         }
       }
       __syncthreads();
