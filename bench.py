@@ -48,8 +48,9 @@ def stage_bytes(N, n_pad, D, P, n_tiles, F, D_visit):
     return {
         "flame": 0.0,   # set by caller (basis read)
         "project": N * (59 * 4 + 4) + N * 48 + F * 64,
+        "bin_count": N * 48 + n_tiles * 4,
         "bin_scan": n_tiles * 20,
-        "bin_scatter": N * 16 + D * 8,
+        "bin_scatter": N * 48 + D * 8,
         "tile_sort": D * 8 + D * 4,
         "composite_fwd": D * 4 + D * 36 + P * 12 + P * 8,
         "loss": 3 * P * (8 + 12) + 3 * P * (12 + 8 + 4),

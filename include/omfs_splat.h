@@ -124,13 +124,16 @@ typedef struct omfs_raster_buffers {
   uint32_t* n_contrib;    /* [height][width]                                                     */
 } omfs_raster_buffers;
 
-/* deform + project + colour for one view; zeroes and fills tile_count. face_xf [n_faces][16]. */
+/* deform + project + colour for one view -> g0,g1,g2. face_xf [n_faces][16]. */
 int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_camera* cam,
                      const omfs_raster_buffers* rb, void* stream);
-/* the three binning steps, separately launchable (omfs_bin_sort = all three in order):
+/* the four binning steps, separately launchable (omfs_bin_sort = all four in order):
+ *  count   : tile_count[t] = #Gaussians whose 3-sigma rectangle contains tile t AND that can reach
+ *            alpha >= 1/255 at one of its pixel centres (frozen test, DESIGN.md "Binning")
  *  scan    : tile_count -> tile_start (exclusive scan), tile_order, zeroed tile_cursor
  *  scatter : (depth bits, id) pairs into their tile's segment of keys
  *  sort    : per-tile radix sort by depth (ties by id) -> sorted_ids                              */
+int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 int omfs_tile_sort(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);

@@ -74,6 +74,7 @@ SIGNATURES = {
     "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p]),
     "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_project_fwd": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
+    "omfs_bin_count": (C.c_int, [C.POINTER(GaussiansC), C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
     "omfs_bin_scan": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
     "omfs_bin_scatter": (C.c_int, [C.POINTER(GaussiansC), C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
     "omfs_tile_sort": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),

@@ -1,9 +1,9 @@
 // Tile binning: scan of per-tile hit counts, key scatter, per-tile radix depth sort in LDS.
 //
 // Design (DESIGN.md "Binning"): instead of the upstream single global 64-bit radix sort of
-// (tile<<32 | depth) keys the D = sum(tiles touched) pairs are
-// counting-sorted by tile (counts come from project_fwd's atomics, offsets from one small scan,
-// placement by a per-tile cursor) and each tile's segment is then sorted on its own by a 4x8-bit
+// (tile<<32 | depth) keys the D (Gaussian,tile) pairs -- the tiles of
+// each 3-sigma rectangle that pass the frozen tile_touched() test -- are counting-sorted by tile
+// (LDS-aggregated counts, offsets from one small scan, placement by a per-tile cursor) and each tile's segment is then sorted on its own by a 4x8-bit
 // LSD radix sort that lives entirely in LDS (160 KB per CU on gfx950): wave-level digit matching
 // (ballots) gives stable ranks, per-wave digit tables give the offsets.  Arrival order inside a
 // tile is arbitrary (atomics), so equal depths are finally ordered by Gaussian id: the result is
@@ -66,24 +66,89 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
   }
 }
 
-// ------------------------------------------------------------------ key scatter
-__global__ __launch_bounds__(256) void scatter_keys_kernel(int n, const float4* __restrict__ g2, int gx, int n_tiles,
-                                                           const uint32_t* __restrict__ tile_start,
-                                                           uint32_t* __restrict__ tile_cursor, uint2* __restrict__ keys) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  if (tile_start[n_tiles] == 0u) return;  // nothing visible, or capacity overflow (flagged by the scan)
-  const float4 r = g2[i];
-  const uint32_t rect = __float_as_uint(r.w);
+// ------------------------------------------------------------------ count + key scatter
+// Both walk every Gaussian's tile rectangle, apply the frozen tile_touched() test, and aggregate
+// in LDS first (one counter per tile: 32 KB at 1080p): a 1024-Gaussian block produces ~25k
+// (Gaussian,tile) pairs but touches <= n_tiles counters, so the global atomics drop from one per
+// pair to one per non-empty (block, tile) -- an order of magnitude fewer, and only the scatter's
+// are returning atomics.  Placement inside a tile segment is arbitrary; the sort fixes the order.
+constexpr int BIN_THREADS = 1024;
+
+struct PairSource {
+  const float4* g0; const float4* g1; const float4* g2;
+};
+
+// calls f(tile) for every tile of Gaussian i's rectangle that passes the test
+template <typename F>
+__device__ __forceinline__ void for_each_touched_tile(const PairSource& ps, int i, int gx, F&& f) {
+  const float4 r2 = ps.g2[i];
+  const uint32_t rect = __float_as_uint(r2.w);
   if (rect == 0u) return;
+  const float4 r0 = ps.g0[i];
+  const float4 r1 = ps.g1[i];
   const int x0 = rect & 255u, y0 = (rect >> 8) & 255u, x1 = (rect >> 16) & 255u, y1 = rect >> 24;
-  const uint32_t depth_bits = __float_as_uint(r.y);
   for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      const int t = y * gx + x;
-      const uint32_t pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+    for (int x = x0; x < x1; ++x)
+      if (tile_touched(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, x, y)) f(y * gx + x);
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSource ps, int gx, int n_tiles,
+                                                                uint32_t* __restrict__ tile_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+  for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
+  __syncthreads();
+  const int i = blockIdx.x * BIN_THREADS + threadIdx.x;
+  if (i < n) for_each_touched_tile(ps, i, gx, [&](int t) { atomicAdd(&hist[t], 1u); });
+  __syncthreads();
+  for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) {
+    const uint32_t c = hist[t];
+    if (c) atomicAdd(&tile_count[t], c);
+  }
+}
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSource ps, int gx, int n_tiles,
+                                                                  const uint32_t* __restrict__ tile_start,
+                                                                  uint32_t* __restrict__ tile_cursor,
+                                                                  uint2* __restrict__ keys) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);   // count, then this block's base slot in the tile
+  uint32_t* cur = hist + n_tiles;                       // block-local cursor
+  if (tile_start[n_tiles] == 0u) return;                // nothing visible, or capacity overflow (flagged by the scan)
+  for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) { hist[t] = 0; cur[t] = 0; }
+  __syncthreads();
+  const int i = blockIdx.x * BIN_THREADS + threadIdx.x;
+  if (i < n) for_each_touched_tile(ps, i, gx, [&](int t) { atomicAdd(&hist[t], 1u); });
+  __syncthreads();
+  for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) {
+    const uint32_t c = hist[t];
+    if (c) hist[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
+  }
+  __syncthreads();
+  if (i < n) {
+    const uint32_t depth_bits = __float_as_uint(ps.g2[i].y);
+    for_each_touched_tile(ps, i, gx, [&](int t) {
+      const uint32_t pos = hist[t] + atomicAdd(&cur[t], 1u);
       keys[pos] = make_uint2(depth_bits, (uint32_t)i);
-    }
+    });
+  }
+}
+
+// Fallback for images with more tiles than fit in LDS: one global atomic per pair.
+__global__ __launch_bounds__(256) void bin_count_direct_kernel(int n, PairSource ps, int gx, uint32_t* __restrict__ tile_count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) for_each_touched_tile(ps, i, gx, [&](int t) { atomicAdd(&tile_count[t], 1u); });
+}
+
+__global__ __launch_bounds__(256) void bin_scatter_direct_kernel(int n, PairSource ps, int gx, int n_tiles,
+                                                                 const uint32_t* __restrict__ tile_start,
+                                                                 uint32_t* __restrict__ tile_cursor, uint2* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || tile_start[n_tiles] == 0u) return;
+  const uint32_t depth_bits = __float_as_uint(ps.g2[i].y);
+  for_each_touched_tile(ps, i, gx, [&](int t) {
+    keys[tile_start[t] + atomicAdd(&tile_cursor[t], 1u)] = make_uint2(depth_bits, (uint32_t)i);
+  });
 }
 
 // ------------------------------------------------------------------ per-tile radix sort
@@ -226,6 +291,30 @@ static int check_bin_args(const omfs_camera* cam, const omfs_raster_buffers* rb)
   return OMFS_OK;
 }
 
+static constexpr size_t BIN_LDS_LIMIT = 150 * 1024;
+
+extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
+  if (int rc = check_bin_args(cam, rb)) return rc;
+  OMFS_REQUIRE(g && g->n > 0 && rb->g0 && rb->g1, "gaussians");
+  const int gx = cdiv(cam->width, OMFS_TILE), n_tiles = gx * cdiv(cam->height, OMFS_TILE);
+  hipStream_t s = (hipStream_t)stream;
+  OMFS_CHECK_HIP(hipMemsetAsync(rb->tile_count, 0, sizeof(uint32_t) * n_tiles, s));
+  PairSource ps{(const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2};
+  const size_t lds = (size_t)n_tiles * 4;
+  if (lds <= BIN_LDS_LIMIT) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles, rb->tile_count);
+  } else {
+    hipLaunchKernelGGL(bin_count_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, rb->tile_count);
+  }
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
 extern "C" int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
   if (int rc = check_bin_args(cam, rb)) return rc;
   const int n_tiles = cdiv(cam->width, OMFS_TILE) * cdiv(cam->height, OMFS_TILE);
@@ -238,10 +327,23 @@ extern "C" int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* 
 extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb,
                                 void* stream) {
   if (int rc = check_bin_args(cam, rb)) return rc;
-  OMFS_REQUIRE(g && g->n > 0, "gaussians");
+  OMFS_REQUIRE(g && g->n > 0 && rb->g0 && rb->g1, "gaussians");
   const int gx = cdiv(cam->width, OMFS_TILE), n_tiles = gx * cdiv(cam->height, OMFS_TILE);
-  hipLaunchKernelGGL(scatter_keys_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, (hipStream_t)stream, g->n,
-                     (const float4*)rb->g2, gx, n_tiles, rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
+  hipStream_t s = (hipStream_t)stream;
+  PairSource ps{(const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2};
+  const size_t lds = (size_t)n_tiles * 8;
+  if (lds <= BIN_LDS_LIMIT) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles,
+                       rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
+  } else {
+    hipLaunchKernelGGL(bin_scatter_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, n_tiles,
+                       rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
+  }
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
@@ -273,6 +375,7 @@ extern "C" int omfs_tile_sort(const omfs_camera* cam, const omfs_raster_buffers*
 
 extern "C" int omfs_bin_sort(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb,
                              void* stream) {
+  if (int rc = omfs_bin_count(g, cam, rb, stream)) return rc;
   if (int rc = omfs_bin_scan(cam, rb, stream)) return rc;
   if (int rc = omfs_bin_scatter(g, cam, rb, stream)) return rc;
   return omfs_tile_sort(cam, rb, stream);

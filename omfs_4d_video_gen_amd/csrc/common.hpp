@@ -46,6 +46,30 @@ __device__ __forceinline__ float exp_exact(float x) {
   return y * __int_as_float((e + 127) << 23);
 }
 
+// Frozen tile-inclusion test (DESIGN.md "Binning"): can the splat reach alpha >= 1/255 at any pixel
+// centre of tile (tx,ty)?  Exact minimum of q(d) = A dx^2 + 2 B dx dy + C dy^2 over the tile's
+// pixel box, relaxed by a rounding slack, then o * exp(-q/2) against 1/255.  Conservative: a pair
+// it rejects contributes to no pixel, so dropping it from the tile list leaves the image unchanged.
+// Plain IEEE operations in a fixed order: bit-identical in oracle/splat_oracle.c.
+__device__ __forceinline__ bool tile_touched(float mx, float my, float A, float B, float C, float o, int tx, int ty) {
+  if (!(A > 0.f && C > 0.f)) return true;
+  const float x0 = (float)(tx * OMFS_TILE), y0 = (float)(ty * OMFS_TILE);
+  const float dxl = mx - (x0 + 15.f), dxh = mx - x0, dyl = my - (y0 + 15.f), dyh = my - y0;
+  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;
+  const float nBoC = -B / C, nBoA = -B / A;
+  float best = 3.0e38f, mag = 0.f;
+  const float cx[4] = {dxl, dxh, fminf(fmaxf(nBoA * dyl, dxl), dxh), fminf(fmaxf(nBoA * dyh, dxl), dxh)};
+  const float cy[4] = {fminf(fmaxf(nBoC * dxl, dyl), dyh), fminf(fmaxf(nBoC * dxh, dyl), dyh), dyl, dyh};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float t0 = (A * cx[k]) * cx[k], t1 = ((2.f * B) * cx[k]) * cy[k], t2 = (C * cy[k]) * cy[k];
+    const float q = (t0 + t1) + t2;
+    if (q < best) { best = q; mag = (t0 + fabsf(t1)) + t2; }
+  }
+  const float qa = fmaxf((best - 4e-5f * mag) - 1e-3f, 0.f);
+  return o * exp_exact(-0.5f * qa) >= (1.f / 255.f) * 0.999f;
+}
+
 // ---- wave64 reductions via DPP (no LDS traffic).
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {

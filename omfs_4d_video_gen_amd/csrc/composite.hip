@@ -47,7 +47,8 @@ __device__ __forceinline__ float qmin_box(float A, float B, float C, float nBoC,
   return best;
 }
 
-// Per-splat staging: log2-domain coefficients + 4-bit quadrant mask.
+// Per-splat staging: log2-domain coefficients + 16-bit mask, bit q*4+s = quadrant q (wave), 4x4
+// sub-block s of it ((s&1) -> x half, (s>>1) -> y half).
 struct Staged {
   float4 a;  // mx, my, A2 = -0.5*log2e*A, B2 = -log2e*B
   float4 b;  // C2 = -0.5*log2e*C, lo = log2(opacity), r, g
@@ -67,15 +68,23 @@ __device__ __forceinline__ Staged stage_splat(const float4 g0, const float4 g1, 
   uint32_t m = 0;
   if (qmax >= 0.f) {
     if (!(A > 0.f && C > 0.f)) {
-      m = 0xFu;  // degenerate conic: never cull
+      m = 0xFFFFu;  // degenerate conic: never cull
     } else {
       const float nBoC = -B / C, nBoA = -B / A;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const float x0 = (float)(tx0 + (q & 1) * 8), y0 = (float)(ty0 + (q >> 1) * 8);
+        const float qx0 = (float)(tx0 + (q & 1) * 8), qy0 = (float)(ty0 + (q >> 1) * 8);
         float mag;
-        const float qm = qmin_box(A, B, C, nBoC, nBoA, g0.x - (x0 + 7.f), g0.x - x0, g0.y - (y0 + 7.f), g0.y - y0, mag);
-        if (qm - 4e-5f * mag - 1e-3f <= qmax) m |= 1u << q;
+        // whole quadrant first: most splats miss most quadrants
+        const float qq = qmin_box(A, B, C, nBoC, nBoA, g0.x - (qx0 + 7.f), g0.x - qx0, g0.y - (qy0 + 7.f), g0.y - qy0, mag);
+        if (qq - 4e-5f * mag - 1e-3f <= qmax) {
+#pragma unroll
+          for (int sb = 0; sb < 4; ++sb) {
+            const float x0 = qx0 + (float)((sb & 1) * 4), y0 = qy0 + (float)((sb >> 1) * 4);
+            const float qs = qmin_box(A, B, C, nBoC, nBoA, g0.x - (x0 + 3.f), g0.x - x0, g0.y - (y0 + 3.f), g0.y - y0, mag);
+            if (qs - 4e-5f * mag - 1e-3f <= qmax) m |= 1u << (q * 4 + sb);
+          }
+        }
       }
     }
   }
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompCam cam, const u
   __shared__ float4 s0[CB];
   __shared__ float4 s1[CB];
   __shared__ float s2[CB];
-  __shared__ unsigned long long qm[4][4];  // [quadrant][staging wave]
+  __shared__ unsigned long long qm[16][4];  // [quadrant*4 + sub-block][staging wave]
   const uint32_t tile = tile_order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx0 = (tile % cam.gx) * OMFS_TILE, ty0 = (tile / cam.gx) * OMFS_TILE;
@@ -105,36 +114,70 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompCam cam, const u
   const bool inside = px < cam.width && py < cam.height;
   const float fx = (float)px, fy = (float)py;
   const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
+  const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);  // 4x4 sub-block of this lane's pixel
+  unsigned long long sbl[4];
+#pragma unroll
+  for (int sb = 0; sb < 4; ++sb) sbl[sb] = __ballot(sidx == sb);
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
   bool done = !inside;
+  // software pipeline: the gather of batch b+1 (id -> three 16-byte records) is in flight while batch b
+  // is walked, so a long list costs one exposed gather latency, not one per 256 splats
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  float r2 = 0.f;
+  if (beg + tid < end) {
+    const uint32_t id = sorted_ids[beg + tid];
+    r0 = g0[id]; r1 = g1[id]; r2 = g2[id].x;
+  }
   for (uint32_t b = beg; b < end; b += CB) {
-    const bool wave_done = __ballot(!done) == 0ull;
-    if (__syncthreads_and(wave_done)) break;
+    unsigned long long live = __ballot(!done);
+    if (__syncthreads_and(live == 0ull)) break;
     const uint32_t k = b + tid;
     uint32_t mask = 0;
     if (k < end) {
-      const uint32_t id = sorted_ids[k];
-      const Staged st = stage_splat(g0[id], g1[id], g2[id].x, tx0, ty0);
+      const Staged st = stage_splat(r0, r1, r2, tx0, ty0);
       s0[tid] = st.a; s1[tid] = st.b; s2[tid] = st.c;
       mask = st.qmask;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 16; ++q) {
       const unsigned long long bal = __ballot((mask >> q) & 1u);
       if (lane == 0) qm[q][wave] = bal;
     }
     __syncthreads();
-    if (!wave_done) {
+    if (k + CB < end) {
+      const uint32_t id = sorted_ids[k + CB];
+      r0 = g0[id]; r1 = g1[id]; r2 = g2[id].x;
+    }
+    if (live != 0ull) {
       const uint32_t base = b - beg;
       for (int g = 0; g < 4; ++g) {
-        unsigned long long m = uniform_u64(qm[wave][g]);
+        unsigned long long ms[4];
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) ms[sb] = uniform_u64(qm[wave * 4 + sb][g]);
+        // splats worth visiting: those that can touch a sub-block which still has an unsaturated pixel
+        auto combine = [&](unsigned long long lv) {
+          unsigned long long r = 0ull;
+#pragma unroll
+          for (int sb = 0; sb < 4; ++sb)
+            if (lv & sbl[sb]) r |= ms[sb];
+          return r;
+        };
+        unsigned long long m = combine(live);
+        if (m == 0ull) continue;
+        // LDS reads of the next splat are issued before the current one is evaluated (one wave per SIMD
+        // is the common case on the long silhouette tiles, so nothing else would hide that latency)
+        int jn = g * 64 + __builtin_ctzll(m);
+        float4 an = s0[jn], cn = s1[jn];
+        float cbn = s2[jn];
         while (m) {
-          const int j = g * 64 + __builtin_ctzll(m);
+          const int j = jn;
+          const float4 a = an;
+          const float4 c = cn;
+          const float cb = cbn;
           m &= m - 1ull;
-          const float4 a = s0[j];
-          const float4 c = s1[j];
-          const float cb = s2[j];
+          jn = g * 64 + (m ? __builtin_ctzll(m) : 0);
+          an = s0[jn]; cn = s1[jn]; cbn = s2[jn];
           if (!done) {
             const float dx = a.x - fx, dy = a.y - fy;
             const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
@@ -154,8 +197,15 @@ __global__ __launch_bounds__(256) void composite_fwd_kernel(CompCam cam, const u
               }
             }
           }
+          const unsigned long long nl = __ballot(!done);
+          if (nl != live) {
+            live = nl;
+            m &= combine(live);
+            jn = g * 64 + (m ? __builtin_ctzll(m) : 0);   // the prefetched splat may have been dropped
+            an = s0[jn]; cn = s1[jn]; cbn = s2[jn];
+          }
         }
-        if (__ballot(!done) == 0ull) break;
+        if (live == 0ull) break;
       }
     }
   }
@@ -186,8 +236,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
   __shared__ float4 s1[CB];
   __shared__ float s2[CB];
   __shared__ uint32_t sid[CB];
-  __shared__ unsigned long long qm[4][4];
-  __shared__ float red[64][4][9 + 2];  // [splat in 64-group][wave][value], padded to 11
+  __shared__ unsigned long long qm[16][4];   // [quadrant*4 + sub-block][64-group]
+  __shared__ unsigned long long vis[4][4];   // [wave][64-group]: splats this wave actually reduced
+  __shared__ float red[64][4][9 + 2];        // [splat in 64-group][wave][value], padded to 11
   __shared__ uint32_t s_max;
   const uint32_t tile = tile_order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -206,10 +257,17 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;         // colour accumulated behind the current splat
   float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;  // last alpha / colour
   const float bgdot = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];
-  // wave / block maxima of the last contributor bound what has to be visited
-  uint32_t wmax = last;
+  // last contributor: maxima per 4x4 sub-block, per wave and per block bound what has to be visited
+  const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
+  uint32_t smax[4];
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) wmax = max(wmax, (uint32_t)__shfl_xor((int)wmax, d, 64));
+  for (int sb = 0; sb < 4; ++sb) {
+    uint32_t v = sidx == sb ? last : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    smax[sb] = __builtin_amdgcn_readfirstlane(v);
+  }
+  const uint32_t wmax = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
   if (tid == 0) s_max = 0;
   __syncthreads();
   if (lane == 0) atomicMax(&s_max, wmax);
@@ -217,46 +275,73 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
   const uint32_t n_visit = s_max;
   if (n_visit == 0) return;
   const uint32_t n_batches = (n_visit + CB - 1) / CB;
+  // software pipeline as in the forward kernel: batch bi-1 is gathered while batch bi is walked
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  float r2 = 0.f;
+  uint32_t rid = 0;
+  {
+    const int bi0 = (int)n_batches - 1;
+    const int cnt0 = (int)min((uint32_t)CB, n_visit - (uint32_t)bi0 * CB);
+    if (tid < cnt0) {
+      rid = sorted_ids[beg + (uint32_t)bi0 * CB + tid];
+      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+    }
+  }
   for (int bi = (int)n_batches - 1; bi >= 0; --bi) {
-    const uint32_t b = beg + (uint32_t)bi * CB;
     const int cnt = (int)min((uint32_t)CB, n_visit - (uint32_t)bi * CB);
     uint32_t mask = 0;
     if (tid < cnt) {
-      const uint32_t id = sorted_ids[b + tid];
-      const Staged st = stage_splat(g0[id], g1[id], g2[id].x, tx0, ty0);
-      sid[tid] = id;
+      const Staged st = stage_splat(r0, r1, r2, tx0, ty0);
+      sid[tid] = rid;
       s0[tid] = st.a; s1[tid] = st.b; s2[tid] = st.c;
       mask = st.qmask;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 16; ++q) {
       const unsigned long long bal = __ballot((mask >> q) & 1u);
       if (lane == 0) qm[q][wave] = bal;
     }
     __syncthreads();
+    if (bi > 0) {   // every earlier batch is full
+      rid = sorted_ids[beg + (uint32_t)(bi - 1) * CB + tid];
+      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+    }
     for (int g = (cnt - 1) / 64; g >= 0; --g) {
       const uint32_t cbase = (uint32_t)bi * CB + (uint32_t)g * 64u;  // list position of bit 0, 0-based
-      unsigned long long m = uniform_u64(qm[wave][g]);
-      // drop splats behind every pixel of this wave's last contributor
-      if (wmax <= cbase) m = 0ull;
-      else if (wmax - cbase < 64u) m &= (1ull << (wmax - cbase)) - 1ull;
-      const unsigned long long m_done = m;
+      // splats worth visiting: can touch a sub-block one of whose pixels has its last contributor at or
+      // behind the splat (list position <= that sub-block's maximum)
+      unsigned long long m = 0ull;
+#pragma unroll
+      for (int sb = 0; sb < 4; ++sb) {
+        if (smax[sb] > cbase) {
+          const uint32_t lim = smax[sb] - cbase;
+          const unsigned long long keep = lim >= 64u ? ~0ull : ((1ull << lim) - 1ull);
+          m |= uniform_u64(qm[wave * 4 + sb][g]) & keep;
+        }
+      }
+      unsigned long long m_done = 0ull;
+      int jbn = m ? 63 - __builtin_clzll(m) : 0;
+      float4 an = s0[g * 64 + jbn], cn = s1[g * 64 + jbn];
+      float cbn = s2[g * 64 + jbn];
       while (m) {
-        const int jb = 63 - __builtin_clzll(m);
+        const int jb = jbn;
         m &= ~(1ull << jb);
-        const int j = g * 64 + jb;
         const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
         float v[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) v[q] = 0.f;
-        const float4 a = s0[j];
-        const float4 c = s1[j];
-        const float cb = s2[j];
+        const float4 a = an;
+        const float4 c = cn;
+        const float cb = cbn;
+        jbn = m ? 63 - __builtin_clzll(m) : 0;     // prefetch the next splat's record
+        an = s0[g * 64 + jbn]; cn = s1[g * 64 + jbn]; cbn = s2[g * 64 + jbn];
+        bool hit = false;
         if (contributor <= last) {
           const float dx = a.x - fx, dy = a.y - fy;
           const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
           const float e = p2 + c.y;
           if (p2 <= 0.f && e >= LOG2_INV255) {
+            hit = true;
             const float oG = __builtin_amdgcn_exp2f(e);   // opacity * G
             const float alpha = fminf(0.99f, oG);
             T = T / (1.f - alpha);
@@ -270,7 +355,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
             dLa = dLa * T + (-T_final / (1.f - alpha)) * bgdot;
             // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream
             // rasteriser does (DESIGN.md "Frozen conventions").  With A2 = -0.5 log2e A etc.:
-            //   o*G*dL/dalpha = dL/dG * G ;  dG/ddx = -G (A dx + B dy) = G (2 A2 dx + B2 dy) / log2e
+            //   dG/ddx = -G (A dx + B dy) = G (2 A2 dx + B2 dy) / log2e
             const float gL = oG * dLa;                     // dL/dG * G  (opacity folded in)
             const float ix = (2.f * a.z * dx + a.w * dy) * (1.f / LOG2E), iy = (2.f * c.x * dy + a.w * dx) * (1.f / LOG2E);
             v[0] = gL * ix;                 // d mean2d.x (dx = mean - pixel)
@@ -281,6 +366,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
             v[5] = __builtin_amdgcn_exp2f(p2) * dLa;  // d opacity: G * dL/dalpha
           }
         }
+        if (__ballot(hit) == 0ull) continue;  // nobody in this quadrant was touched: nothing to reduce
+        m_done |= 1ull << jb;
 #pragma unroll
         for (int q = 0; q < 9; ++q) v[q] = wave_sum_to_lane63(v[q]);
         if (lane == 63) {
@@ -288,8 +375,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
           for (int q = 0; q < 9; ++q) red[jb][wave][q] = v[q];
         }
       }
-      // publish which splats of this group this wave reduced
-      if (lane == 0) qm[wave][g] = m_done;
+      if (lane == 0) vis[wave][g] = m_done;
       __syncthreads();
       // 16 lanes per 64-byte splat record; lane q < 9 adds value q
       const int gcnt = min(64, cnt - g * 64);
@@ -297,10 +383,11 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
         const int jj = r >> 4, q = r & 15;
         if (q < 9) {
           float sum = 0.f;
+          bool any = false;
 #pragma unroll
           for (int w = 0; w < 4; ++w)
-            if ((qm[w][g] >> jj) & 1ull) sum += red[jj][w][q];
-          if (sum != 0.f) atomicAdd(&dsplat[(size_t)sid[g * 64 + jj] * 16 + q], sum);
+            if ((vis[w][g] >> jj) & 1ull) { sum += red[jj][w][q]; any = true; }
+          if (any && sum != 0.f) atomicAdd(&dsplat[(size_t)sid[g * 64 + jj] * 16 + q], sum);
         }
       }
       __syncthreads();

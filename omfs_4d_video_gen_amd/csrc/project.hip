@@ -1,5 +1,5 @@
 // Per-Gaussian forward: triangle-bound deformation, EWA projection, SH colour, tile rectangle,
-// per-tile hit counts.  One lane per Gaussian, planar SoA loads (256 contiguous bytes per wave
+// (hit counts moved to binning.hip).  One lane per Gaussian, planar SoA loads (256 contiguous bytes per wave
 // instruction and plane), three coalesced float4 stores.  HBM-streaming kernel:
 // algorithmic bytes per Gaussian = 59*4 (params) + 4 (binding) + 48 (records) [+ 64 face record, L2].
 //
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(int n, int n_pad, cons
                                                           const int32_t* __restrict__ binding,
                                                           const float* __restrict__ face_xf, ProjCam cam,
                                                           float4* __restrict__ g0, float4* __restrict__ g1,
-                                                          float4* __restrict__ g2, uint32_t* __restrict__ tile_count) {
+                                                          float4* __restrict__ g2) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   auto P = [&](int plane) { return params[(size_t)plane * n_pad + i]; };
@@ -124,13 +124,11 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(int n, int n_pad, cons
           rgb[ch] = r + 0.5f;
         }
         uint32_t clampbits = (rgb[0] < 0.f ? 1u : 0u) | (rgb[1] < 0.f ? 2u : 0u) | (rgb[2] < 0.f ? 4u : 0u);
-        const float opac = 1.f / (1.f + __expf(-P(OMFS_P_OPACITY)));
+        const float opac = 1.f / (1.f + exp_exact(-P(OMFS_P_OPACITY)));  // frozen: feeds the tile test
         o0 = make_float4(px, py, c / det, -b / det);
         o1 = make_float4(a / det, opac, fmaxf(rgb[0], 0.f), fmaxf(rgb[1], 0.f));
         o2 = make_float4(fmaxf(rgb[2], 0.f), tz, __uint_as_float((uint32_t)radius | (clampbits << 28)),
                          __uint_as_float((uint32_t)x0 | ((uint32_t)y0 << 8) | ((uint32_t)x1 << 16) | ((uint32_t)y1 << 24)));
-        for (int yy = y0; yy < y1; ++yy)
-          for (int xx = x0; xx < x1; ++xx) atomicAdd(&tile_count[yy * cam.gx + xx], 1u);
       }
     }
   }
@@ -167,12 +165,11 @@ extern "C" int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, c
   OMFS_REQUIRE(g->n > 0 && g->n_pad >= g->n && g->params && g->binding, "gaussians");
   OMFS_REQUIRE(cam->width > 0 && cam->height > 0 && cam->width <= 4080 && cam->height <= 4080, "image size (tile coords are 8 bit)");
   OMFS_REQUIRE(cam->sh_degree >= 0 && cam->sh_degree <= 3, "sh_degree");
-  OMFS_REQUIRE(rb->g0 && rb->g1 && rb->g2 && rb->tile_count, "raster buffers");
+  OMFS_REQUIRE(rb->g0 && rb->g1 && rb->g2, "raster buffers");
   ProjCam pc = make_projcam(cam);
   hipStream_t s = (hipStream_t)stream;
-  OMFS_CHECK_HIP(hipMemsetAsync(rb->tile_count, 0, sizeof(uint32_t) * pc.gx * pc.gy, s));
   hipLaunchKernelGGL(project_fwd_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, g->n_pad, g->params, g->binding,
-                     face_xf, pc, (float4*)rb->g0, (float4*)rb->g1, (float4*)rb->g2, rb->tile_count);
+                     face_xf, pc, (float4*)rb->g0, (float4*)rb->g1, (float4*)rb->g2);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
   G(OMFS_P_SCALE + 0, dls[0]); G(OMFS_P_SCALE + 1, dls[1]); G(OMFS_P_SCALE + 2, dls[2]);
   G(OMFS_P_ROT + 0, (dqw - qw * qd) / qn); G(OMFS_P_ROT + 1, (dqx - qx * qd) / qn);
   G(OMFS_P_ROT + 2, (dqy - qy * qd) / qn); G(OMFS_P_ROT + 3, (dqz - qz * qd) / qn);
-  const float o = 1.f / (1.f + __expf(-P(OMFS_P_OPACITY)));
+  const float o = 1.f / (1.f + exp_exact(-P(OMFS_P_OPACITY)));
   G(OMFS_P_OPACITY, dop * o * (1.f - o));
 }
 

@@ -21,7 +21,7 @@ from .flame_rig import DeviceFlame, FlameRig
 from .gaussians import GaussianModel, NPLANES
 from .rasterizer import Adam, Rasterizer, default_lr_planes, make_camera_struct
 
-STAGES = ("flame", "project", "bin_scan", "bin_scatter", "tile_sort", "composite_fwd", "loss", "composite_bwd",
+STAGES = ("flame", "project", "bin_count", "bin_scan", "bin_scatter", "tile_sort", "composite_fwd", "loss", "composite_bwd",
           "project_bwd", "allreduce", "adam")
 
 
@@ -125,6 +125,7 @@ class Trainer:
         lib = L.load()
         g = r._gauss(self.model)
         s = L.stream_ptr()
+        L.check(lib.omfs_bin_count(g, cam, r.rb, s), "omfs_bin_count"); tm.mark("bin_count")
         L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); tm.mark("bin_scan")
         L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
         L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
@@ -181,6 +182,7 @@ class Renderer:
         g = r._gauss(self.model)
         s = L.stream_ptr()
         r.project(self.model, face_xf[0], cam); tm.mark("project")
+        L.check(lib.omfs_bin_count(g, cam, r.rb, s), "omfs_bin_count"); tm.mark("bin_count")
         L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); tm.mark("bin_scan")
         L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
         L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")

@@ -91,15 +91,16 @@ def project(params: np.ndarray, binding: np.ndarray, face_xf: np.ndarray, cam: O
     return o
 
 
-def bin_sort(proj: dict, width: int, height: int):
+def bin_sort(proj: dict, width: int, height: int, cull: bool = True):
+    """cull=True: the engine's rule (frozen tile test); cull=False: every tile of the 3-sigma rectangle."""
     n = proj["depth"].shape[0]
     nt = ((width + 15) // 16) * ((height + 15) // 16)
     tile_start = np.zeros(nt + 1, np.uint32)
-    D = lib().orc_bin_sort(C.c_int(n), C.c_int(width), C.c_int(height), _p(proj["depth"]), _p(proj["radius"]),
-                           _p(proj["rect"]), _p(tile_start), None)
+    args = (C.c_int(n), C.c_int(width), C.c_int(height), _p(proj["depth"]), _p(proj["radius"]), _p(proj["rect"]),
+            _p(proj["mean2d"]), _p(proj["conic"]), _p(proj["opac"]), C.c_int(1 if cull else 0), _p(tile_start))
+    D = lib().orc_bin_sort(*args, None)
     ids = np.zeros(max(int(D), 1), np.uint32)
-    lib().orc_bin_sort(C.c_int(n), C.c_int(width), C.c_int(height), _p(proj["depth"]), _p(proj["radius"]),
-                       _p(proj["rect"]), _p(tile_start), _p(ids))
+    lib().orc_bin_sort(*args, _p(ids))
     return tile_start, ids[:int(D)]
 
 
@@ -113,12 +114,12 @@ def composite(proj: dict, tile_start, ids, width: int, height: int, bg):
     return img, fT, nc
 
 
-def render(dflame, t, params, binding, n, cam: OrcCamera):
+def render(dflame, t, params, binding, n, cam: OrcCamera, cull: bool = True):
     """Whole forward for one frame: returns dict(verts, face_xf, proj, tile_start, ids, image, final_T, n_contrib)."""
     verts, jx = flame_frame(dflame, t)
     fxf = face_frames(verts, dflame.rig.faces)
     proj = project(params, binding, fxf, cam, n)
-    ts, ids = bin_sort(proj, cam.width, cam.height)
+    ts, ids = bin_sort(proj, cam.width, cam.height, cull)
     img, fT, nc = composite(proj, ts, ids, cam.width, cam.height, list(cam.bg))
     return {"verts": verts, "joint_xf": jx, "face_xf": fxf, "proj": proj, "tile_start": ts, "ids": ids,
             "image": img, "final_T": fT, "n_contrib": nc}

@@ -235,12 +235,32 @@ void orc_project(int n, int n_pad, const float* params, const int32_t* binding, 
     }
     mean2d[i * 2] = px; mean2d[i * 2 + 1] = py;
     conic[i * 3] = c / det; conic[i * 3 + 1] = -b / det; conic[i * 3 + 2] = a / det;
-    opac[i] = 1.f / (1.f + expf(-P(10)));
+    opac[i] = 1.f / (1.f + orc_exp(-P(10)));   /* frozen: feeds the tile test */
     depth[i] = tz; radius[i] = (int32_t)rad;
     rect[i * 4] = x0; rect[i * 4 + 1] = y0; rect[i * 4 + 2] = x1; rect[i * 4 + 3] = y1;
     clampbits[i] = cb;
 #undef P
   }
+}
+
+/* Frozen tile-inclusion test (DESIGN.md "Binning"): can the splat reach alpha >= 1/255 at a pixel
+ * centre of tile (tx,ty)?  Same operations in the same order as csrc/common.hpp tile_touched(). */
+int orc_tile_touched(float mx, float my, float A, float B, float C, float o, int tx, int ty) {
+  if (!(A > 0.f && C > 0.f)) return 1;
+  const float x0 = (float)(tx * TILE), y0 = (float)(ty * TILE);
+  const float dxl = mx - (x0 + 15.f), dxh = mx - x0, dyl = my - (y0 + 15.f), dyh = my - y0;
+  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return 1;
+  const float nBoC = -B / C, nBoA = -B / A;
+  float best = 3.0e38f, mag = 0.f;
+  const float cx[4] = {dxl, dxh, fminf(fmaxf(nBoA * dyl, dxl), dxh), fminf(fmaxf(nBoA * dyh, dxl), dxh)};
+  const float cy[4] = {fminf(fmaxf(nBoC * dxl, dyl), dyh), fminf(fmaxf(nBoC * dxh, dyl), dyh), dyl, dyh};
+  for (int k = 0; k < 4; ++k) {
+    const float t0 = (A * cx[k]) * cx[k], t1 = ((2.f * B) * cx[k]) * cy[k], t2 = (C * cy[k]) * cy[k];
+    const float q = (t0 + t1) + t2;
+    if (q < best) { best = q; mag = (t0 + fabsf(t1)) + t2; }
+  }
+  const float qa = fmaxf((best - 4e-5f * mag) - 1e-3f, 0.f);
+  return o * orc_exp(-0.5f * qa) >= (1.f / 255.f) * 0.999f;
 }
 
 typedef struct { uint32_t depth, id; } orc_pair;
@@ -250,16 +270,22 @@ static int pair_cmp(const void* a, const void* b) {
   return x->id < y->id ? -1 : (x->id > y->id ? 1 : 0);
 }
 
-/* Binning + per-tile order (Appendix A item 5).  tile_start [n_tiles+1], sorted_ids [D] (caller
- * sizes it from the returned D of a first call with sorted_ids == NULL). */
+/* Binning + per-tile order (Appendix A item 5).  A (Gaussian, tile) pair exists for every tile of
+ * the 3-sigma rectangle that passes orc_tile_touched() (cull != 0) -- or for every tile of the
+ * rectangle (cull == 0, the upstream rule; used by tests to show the image does not depend on it).
+ * tile_start [n_tiles+1], sorted_ids [D] (caller sizes it from the returned D of a first call
+ * with sorted_ids == NULL). */
 int64_t orc_bin_sort(int n, int width, int height, const float* depth, const int32_t* radius, const int32_t* rect,
+                     const float* mean2d, const float* conic, const float* opac, int cull,
                      uint32_t* tile_start, uint32_t* sorted_ids) {
+#define TOUCH(i, x, y) (!cull || orc_tile_touched(mean2d[(i)*2], mean2d[(i)*2 + 1], conic[(i)*3], conic[(i)*3 + 1], conic[(i)*3 + 2], opac[i], x, y))
   const int gx = (width + TILE - 1) / TILE, gy = (height + TILE - 1) / TILE, nt = gx * gy;
   uint32_t* cnt = (uint32_t*)calloc((size_t)nt + 1, 4);
   for (int i = 0; i < n; ++i) {
     if (radius[i] <= 0) continue;
     for (int y = rect[i * 4 + 1]; y < rect[i * 4 + 3]; ++y)
-      for (int x = rect[i * 4]; x < rect[i * 4 + 2]; ++x) cnt[y * gx + x]++;
+      for (int x = rect[i * 4]; x < rect[i * 4 + 2]; ++x)
+        if (TOUCH(i, x, y)) cnt[y * gx + x]++;
   }
   int64_t D = 0;
   for (int t = 0; t < nt; ++t) { tile_start[t] = (uint32_t)D; D += cnt[t]; }
@@ -271,6 +297,7 @@ int64_t orc_bin_sort(int n, int width, int height, const float* depth, const int
     if (radius[i] <= 0) continue;
     for (int y = rect[i * 4 + 1]; y < rect[i * 4 + 3]; ++y)
       for (int x = rect[i * 4]; x < rect[i * 4 + 2]; ++x) {
+        if (!TOUCH(i, x, y)) continue;
         int t = y * gx + x;
         orc_pair p = {f2u(depth[i]), (uint32_t)i};
         pairs[tile_start[t] + cnt[t]++] = p;
@@ -282,6 +309,7 @@ int64_t orc_bin_sort(int n, int width, int height, const float* depth, const int
   }
   free(pairs); free(cnt);
   return D;
+#undef TOUCH
 }
 
 /* Front-to-back composite (Appendix A item 6). image [3][H][W], final_T [H][W], n_contrib [H][W] */

@@ -191,21 +191,50 @@ def deform_project(g: dict, R_f, c_f, s_f, cam: dict, sh_degree: int = 3):
 
 
 # --------------------------------------------------------------------------- binning + composite
-def tile_lists(proj: dict, width: int, height: int):
+def tile_touched(mx, my, A, B, C, o, tx, ty):
+    """Engine's tile-inclusion rule (DESIGN.md "Binning"): exact minimum of the conic form over the
+    tile's pixel-centre box, with slack, against alpha >= 1/255.  Scalars (python floats)."""
+    if not (A > 0 and C > 0):
+        return True
+    f = torch.tensor
+    x0, y0 = float(tx * TILE), float(ty * TILE)
+    dxl, dxh, dyl, dyh = mx - (x0 + 15.0), mx - x0, my - (y0 + 15.0), my - y0
+    if dxl <= 0 <= dxh and dyl <= 0 <= dyh:
+        return True
+    nBoC, nBoA = -B / C, -B / A
+    clamp = lambda v, lo, hi: min(max(v, lo), hi)
+    cands = [(dxl, clamp(nBoC * dxl, dyl, dyh)), (dxh, clamp(nBoC * dxh, dyl, dyh)),
+             (clamp(nBoA * dyl, dxl, dxh), dyl), (clamp(nBoA * dyh, dxl, dxh), dyh)]
+    best, mag = 3.0e38, 0.0
+    for dx, dy in cands:
+        t0, t1, t2 = A * dx * dx, 2 * B * dx * dy, C * dy * dy
+        q = t0 + t1 + t2
+        if q < best:
+            best, mag = q, t0 + abs(t1) + t2
+    qa = max(best - 4e-5 * mag - 1e-3, 0.0)
+    return o * math.exp(-0.5 * qa) >= (1.0 / 255.0) * 0.999
+
+
+def tile_lists(proj: dict, width: int, height: int, cull: bool = True):
     """Per-tile sorted Gaussian id lists.  Order = ascending (depth bits, id): identical to the
-    upstream global (tile<<32|depth) stable radix sort with emission order = Gaussian index."""
+    upstream global (tile<<32|depth) stable radix sort with emission order = Gaussian index.
+    cull=True keeps only the tiles of the 3-sigma rectangle that pass tile_touched()."""
     gx, gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
     vis = torch.nonzero(proj["visible"]).squeeze(1)
     rect = proj["rect"][vis]
     depth = proj["depth"].detach()[vis]
     lists = [[] for _ in range(gx * gy)]
     order = torch.argsort(depth.contiguous().view(torch.int32).to(torch.int64) * (1 << 32) + vis, stable=True)
+    m2 = proj["mean2d"].detach()[vis].tolist()
+    con = proj["conic"].detach()[vis].tolist()
+    op = proj["opac"].detach()[vis].tolist()
     for k in order.tolist():
         x0, y0, x1, y1 = rect[k].tolist()
         gid = int(vis[k])
         for ty in range(y0, y1):
             for tx in range(x0, x1):
-                lists[ty * gx + tx].append(gid)
+                if not cull or tile_touched(m2[k][0], m2[k][1], con[k][0], con[k][1], con[k][2], op[k], tx, ty):
+                    lists[ty * gx + tx].append(gid)
     return lists
 
 

@@ -55,6 +55,7 @@ def test_bitexact_vs_c_oracle(n, width, height, yaw, seed):
     conic = np.stack([g0[:, 2], g0[:, 3], g1[:, 0]], -1)
     assert np.array_equal(conic[vis].view(np.uint32), ref["proj"]["conic"][vis].view(np.uint32)), "conics differ"
     assert np.array_equal((rb >> 28).astype(np.int32)[vis], ref["proj"]["clamp"][vis])
+    assert np.array_equal(g1[vis, 1].view(np.uint32), ref["proj"]["opac"][vis].view(np.uint32)), "opacities differ"
 
     ts = rast.tile_start.cpu().numpy().view(np.uint32)
     assert np.array_equal(ts, ref["tile_start"]), "tile offsets differ"

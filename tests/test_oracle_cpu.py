@@ -54,3 +54,22 @@ def test_oracle_identity_pose_plumbing(rig_small):
     out = O.render(H.oracle_rig(rig), H.oracle_gaussians(g), H.oracle_frame(seq, 0), cam)
     assert torch.allclose(out["verts"], torch.from_numpy(rig.v_template), atol=1e-7)
     assert out["image"].shape == (3, 64, 64) and float(out["image"].max()) > 0.05
+
+
+def test_tile_culling_does_not_change_the_image(rig_small):
+    """The engine drops (Gaussian, tile) pairs that cannot reach alpha >= 1/255 inside the tile.
+    The composite of the culled lists must be BIT-IDENTICAL to the composite of the upstream-style
+    lists (every tile of the 3-sigma rectangle): image and final T."""
+    rig = rig_small
+    n, W, Hh = 6000, 208, 160
+    g = synthetic.make_gaussians(n, rig.faces.shape[0], 9)
+    g["opacity"][: n // 3] -= 3.0      # many faint splats: the opacity-aware part of the test matters
+    seq = synthetic.make_flame_sequence(2, 9)
+    dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq, device="cpu")
+    for yaw in (0.0, 0.9):
+        ccam = make_camera_struct(synthetic.make_camera(W, Hh, yaw=yaw), sh_degree=3, bg=(0.3, 0.6, 0.9))
+        a = CO.render(dflame, 1, pack_params(g), g["binding"], n, CO.camera(ccam), cull=True)
+        b = CO.render(dflame, 1, pack_params(g), g["binding"], n, CO.camera(ccam), cull=False)
+        assert len(a["ids"]) < 0.9 * len(b["ids"]), (len(a["ids"]), len(b["ids"]))
+        assert np.array_equal(a["image"].view(np.uint32), b["image"].view(np.uint32))
+        assert np.array_equal(a["final_T"].view(np.uint32), b["final_T"].view(np.uint32))

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Profiling helper: run the bench scene's forward (and optionally training) steps a few times so
+that rocprofv3 (--kernel-trace / --pmc) sees clean dispatches.  Not part of the product path."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omfs_4d_video_gen_amd.engine import synthetic  # noqa: E402
+from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig  # noqa: E402
+from omfs_4d_video_gen_amd.engine.trainer import Renderer, Trainer, View  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=300000)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--train", action="store_true")
+ap.add_argument("--pretrain", type=int, default=100, help="training steps before the measured ones")
+a = ap.parse_args()
+srig = synthetic.make_rig(0)
+rig = FlameRig.from_synthetic(srig)
+seq = synthetic.make_flame_sequence(16, 0)
+cams = synthetic.make_camera_arc(a.width, a.height, 16)
+g0 = synthetic.make_gaussians(a.n, rig.n_faces, 0)
+g1 = synthetic.make_gaussians(a.n, rig.n_faces, 1)
+tr = Renderer(rig, seq, g1, a.width, a.height)
+views = []
+for i, c in enumerate(cams):
+    v = View(c, i)
+    v.target = tr.render(v).clone()
+    views.append(v)
+t = Trainer(rig, seq, g0, views, a.width, a.height, start_sh_degree=3)
+for _ in range(a.pretrain + (a.iters if a.train else 0)):
+    t.step()
+torch.cuda.synchronize()
+if not a.train:
+    r = Renderer(rig, seq, t.model.to_dict(), a.width, a.height)
+    for i in range(a.iters):
+        r.render(views[i % 16])
+    torch.cuda.synchronize()
+print("D", int(t.rast.tile_start[-1]))
