@@ -82,6 +82,28 @@ int omfs_flame_lbs(const omfs_flame_rig* rig, const float* coef, const float* jo
 int omfs_face_frames(const float* verts, int v_pad, const int32_t* faces, int n_faces, int n_frames,
                      float* face_xf, void* stream);
 
+/* ------------------------------------------------------------------ SimpleFLAME landmark model
+ * Replaces the tensor math of flame_fitter.py:154-197 (SimpleFLAME.forward) and its autograd pass in
+ * the fit loop :377-413.  The barycentric landmark mix (:192-195) is folded into the bases by the host:
+ * lmk_template [L][3], lmk_basis [L][3][n_shape+n_expr], lmk_lower [L] (mixed lower-face mask, :178-182). */
+typedef struct omfs_simpleflame {
+  int n_landmarks, n_shape, n_expr;
+  const float* lmk_template;
+  const float* lmk_basis;
+  const float* lmk_lower;
+} omfs_simpleflame;
+
+/* shape [B][n_shape], expr [B][n_expr], rotation/jaw/translation [B][3] -> landmarks [B][L][3];
+ * p_scratch [B][L][3] keeps the pre-rotation points for the backward pass */
+int omfs_simpleflame_fwd(const omfs_simpleflame* m, const float* shape, const float* expr, const float* rotation,
+                         const float* jaw, const float* translation, int n_frames, float* landmarks,
+                         float* p_scratch, void* stream);
+/* dlandmarks [B][L][3] -> per-frame gradients of every input (dshape [B][n_shape]: the caller sums over
+ * frames when the shape is shared); g_scratch [B][L][3] */
+int omfs_simpleflame_bwd(const omfs_simpleflame* m, const float* rotation, const float* p_scratch,
+                         const float* dlandmarks, int n_frames, float* g_scratch, float* dshape, float* dexpr,
+                         float* drotation, float* djaw, float* dtranslation, void* stream);
+
 /* ------------------------------------------------------------------ rasteriser */
 typedef struct omfs_camera {
   float view[12];   /* world->view, rows of [R|t] (3x4 row-major)                               */

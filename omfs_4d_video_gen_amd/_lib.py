@@ -34,6 +34,11 @@ class FlameRigC(C.Structure):
                 ("j_static", c_void_p), ("j_expr", c_void_p)]
 
 
+class SimpleFlameC(C.Structure):
+    _fields_ = [("n_landmarks", C.c_int), ("n_shape", C.c_int), ("n_expr", C.c_int),
+                ("lmk_template", c_void_p), ("lmk_basis", c_void_p), ("lmk_lower", c_void_p)]
+
+
 class CameraC(C.Structure):
     _fields_ = [("view", C.c_float * 12), ("cam_pos", C.c_float * 3), ("fx", C.c_float), ("fy", C.c_float),
                 ("cx", C.c_float), ("cy", C.c_float), ("limx", C.c_float), ("limy", C.c_float),
@@ -73,6 +78,8 @@ SIGNATURES = {
     "omfs_flame_joints": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p]),
     "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p]),
     "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
+    "omfs_simpleflame_fwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 5 + [C.c_int, c_void_p, c_void_p, c_void_p]),
+    "omfs_simpleflame_bwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 3 + [C.c_int] + [c_void_p] * 7),
     "omfs_project_fwd": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
     "omfs_bin_count": (C.c_int, [C.POINTER(GaussiansC), C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
     "omfs_bin_scan": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),

@@ -1,0 +1,153 @@
+// SimpleFLAME landmark model of the reference's flame_fitter, forward and backward.
+//
+// Reference: 02_Visual_Engine/flame_fitter.py:154-197 (forward) and the autograd pass of the fit
+// loop :377-413.  The reference evaluates all V vertices and then mixes three of them per
+// landmark; the mix is linear, so the host folds the barycentric weights into a per-landmark
+// basis once (lmk_template [L][3], lmk_basis [L][3][K] with K = n_shape + n_expr, lmk_lower [L])
+// and the kernels work on L landmarks instead of V vertices (68 vs 5023).  Same math, different
+// summation order: parity with the reference is at fp32 tolerance, not bit level.
+//
+//   p      = lmk_template + lmk_basis . [shape; expr];  p.y -= jaw[0] * 0.15 * lmk_lower
+//   out    = R(rotation) p + translation,  R = I + sin(t) K + (1-cos(t)) K^2, axis = aa/(|aa|+1e-8)
+#include "common.hpp"
+
+namespace omfs {
+
+__device__ __forceinline__ void rodrigues(const float* aa, float* R, float* Kout, float& theta) {
+  theta = sqrtf(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+  const float inv = 1.f / (theta + 1e-8f);
+  const float n0 = aa[0] * inv, n1 = aa[1] * inv, n2 = aa[2] * inv;
+  const float K[9] = {0.f, -n2, n1, n2, 0.f, -n0, -n1, n0, 0.f};
+  const float s = sinf(theta), c1 = 1.f - cosf(theta);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      const float k2 = K[i * 3] * K[j] + K[i * 3 + 1] * K[3 + j] + K[i * 3 + 2] * K[6 + j];
+      R[i * 3 + j] = (i == j ? 1.f : 0.f) + s * K[i * 3 + j] + c1 * k2;
+    }
+  if (Kout) for (int i = 0; i < 9; ++i) Kout[i] = K[i];
+}
+
+// one thread per (frame, landmark); writes landmarks [B][L][3] and the pre-rotation points p [B][L][3]
+__global__ void simpleflame_fwd_kernel(int B, int L, int K, int n_shape, const float* __restrict__ lmk_template,
+                                       const float* __restrict__ lmk_basis, const float* __restrict__ lmk_lower,
+                                       const float* __restrict__ shape, const float* __restrict__ expr,
+                                       const float* __restrict__ rotation, const float* __restrict__ jaw,
+                                       const float* __restrict__ translation, float* __restrict__ out, float* __restrict__ p_out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * L) return;
+  const int b = t / L, l = t % L;
+  const int n_expr = K - n_shape;
+  float p[3];
+  for (int c = 0; c < 3; ++c) {
+    const float* row = lmk_basis + ((size_t)l * 3 + c) * K;
+    float acc = lmk_template[l * 3 + c];
+    for (int k = 0; k < n_shape; ++k) acc = fma_(row[k], shape[(size_t)b * n_shape + k], acc);
+    for (int k = 0; k < n_expr; ++k) acc = fma_(row[n_shape + k], expr[(size_t)b * n_expr + k], acc);
+    p[c] = acc;
+  }
+  p[1] -= jaw[b * 3] * 0.15f * lmk_lower[l];
+  float R[9], th;
+  rodrigues(rotation + b * 3, R, nullptr, th);
+  for (int i = 0; i < 3; ++i) {
+    out[(size_t)t * 3 + i] = R[i * 3] * p[0] + R[i * 3 + 1] * p[1] + R[i * 3 + 2] * p[2] + translation[b * 3 + i];
+    p_out[(size_t)t * 3 + i] = p[i];
+  }
+}
+
+// one thread per frame: pose gradients + g = R^T dL/dout per landmark (for the basis products)
+__global__ void simpleflame_bwd_pose_kernel(int B, int L, const float* __restrict__ lmk_lower, const float* __restrict__ rotation,
+                                            const float* __restrict__ p_in, const float* __restrict__ dout,
+                                            float* __restrict__ g_out, float* __restrict__ drot, float* __restrict__ djaw,
+                                            float* __restrict__ dtrans) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float R[9], Km[9], th;
+  const float aa[3] = {rotation[b * 3], rotation[b * 3 + 1], rotation[b * 3 + 2]};
+  rodrigues(aa, R, Km, th);
+  float G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dt[3] = {0, 0, 0}, dj = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const float* d = dout + ((size_t)b * L + l) * 3;
+    const float* p = p_in + ((size_t)b * L + l) * 3;
+    float g[3];
+    for (int j = 0; j < 3; ++j) g[j] = R[j] * d[0] + R[3 + j] * d[1] + R[6 + j] * d[2];
+    for (int i = 0; i < 3; ++i) {
+      dt[i] += d[i];
+      for (int j = 0; j < 3; ++j) G[i * 3 + j] += d[i] * p[j];
+      g_out[((size_t)b * L + l) * 3 + i] = g[i];
+    }
+    dj += -0.15f * lmk_lower[l] * g[1];
+  }
+  // Rodrigues backward
+  const float s = sinf(th), c = cosf(th);
+  float K2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) K2[i * 3 + j] = Km[i * 3] * Km[j] + Km[i * 3 + 1] * Km[3 + j] + Km[i * 3 + 2] * Km[6 + j];
+  float dth = 0.f;
+  for (int i = 0; i < 9; ++i) dth += G[i] * (c * Km[i] + s * K2[i]);
+  float dK[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float gkT = 0.f, kTg = 0.f;   // (G K^T)_ij = sum_m G_im K_jm ; (K^T G)_ij = sum_m K_mi G_mj
+      for (int m = 0; m < 3; ++m) { gkT += G[i * 3 + m] * Km[j * 3 + m]; kTg += Km[m * 3 + i] * G[m * 3 + j]; }
+      dK[i * 3 + j] = s * G[i * 3 + j] + (1.f - c) * (gkT + kTg);
+    }
+  const float dn[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+  const float inv = 1.f / (th + 1e-8f);
+  const float dot = dn[0] * aa[0] + dn[1] * aa[1] + dn[2] * aa[2];
+  for (int i = 0; i < 3; ++i) {
+    const float unit = th > 0.f ? aa[i] / th : 0.f;   // d|aa|/daa, 0 at the origin (torch.norm's subgradient)
+    drot[b * 3 + i] = dn[i] * inv - dot * inv * inv * unit + dth * unit;
+    dtrans[b * 3 + i] = dt[i];
+  }
+  djaw[b * 3] = dj; djaw[b * 3 + 1] = 0.f; djaw[b * 3 + 2] = 0.f;
+}
+
+// one thread per (frame, coefficient): dcoef[b][k] = sum_l sum_c lmk_basis[l][c][k] * g[b][l][c]
+__global__ void simpleflame_bwd_coef_kernel(int B, int L, int K, int n_shape, const float* __restrict__ lmk_basis,
+                                            const float* __restrict__ g, float* __restrict__ dshape, float* __restrict__ dexpr) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * K) return;
+  const int b = t / K, k = t % K;
+  float acc = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const float* gg = g + ((size_t)b * L + l) * 3;
+    const float* row = lmk_basis + (size_t)l * 3 * K + k;
+    acc = fma_(row[0], gg[0], acc);
+    acc = fma_(row[K], gg[1], acc);
+    acc = fma_(row[2 * K], gg[2], acc);
+  }
+  if (k < n_shape) dshape[(size_t)b * n_shape + k] = acc;
+  else dexpr[(size_t)b * (K - n_shape) + (k - n_shape)] = acc;
+}
+
+}  // namespace omfs
+
+using namespace omfs;
+
+extern "C" int omfs_simpleflame_fwd(const omfs_simpleflame* m, const float* shape, const float* expr, const float* rotation,
+                                    const float* jaw, const float* translation, int n_frames, float* landmarks,
+                                    float* p_scratch, void* stream) {
+  OMFS_REQUIRE(m && shape && expr && rotation && jaw && translation && landmarks && p_scratch, "null pointer");
+  OMFS_REQUIRE(n_frames > 0 && m->n_landmarks > 0 && m->n_shape >= 0 && m->n_expr >= 0, "shape");
+  const int K = m->n_shape + m->n_expr, tot = n_frames * m->n_landmarks;
+  hipLaunchKernelGGL(simpleflame_fwd_kernel, dim3(cdiv(tot, 128)), dim3(128), 0, (hipStream_t)stream, n_frames, m->n_landmarks, K,
+                     m->n_shape, m->lmk_template, m->lmk_basis, m->lmk_lower, shape, expr, rotation, jaw, translation, landmarks, p_scratch);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_simpleflame_bwd(const omfs_simpleflame* m, const float* rotation, const float* p_scratch,
+                                    const float* dlandmarks, int n_frames, float* g_scratch, float* dshape, float* dexpr,
+                                    float* drotation, float* djaw, float* dtranslation, void* stream) {
+  OMFS_REQUIRE(m && rotation && p_scratch && dlandmarks && g_scratch && dshape && dexpr && drotation && djaw && dtranslation, "null pointer");
+  OMFS_REQUIRE(n_frames > 0, "shape");
+  const int K = m->n_shape + m->n_expr;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(simpleflame_bwd_pose_kernel, dim3(cdiv(n_frames, 64)), dim3(64), 0, s, n_frames, m->n_landmarks, m->lmk_lower,
+                     rotation, p_scratch, dlandmarks, g_scratch, drotation, djaw, dtranslation);
+  OMFS_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(simpleflame_bwd_coef_kernel, dim3(cdiv(n_frames * K, 128)), dim3(128), 0, s, n_frames, m->n_landmarks, K,
+                     m->n_shape, m->lmk_basis, g_scratch, dshape, dexpr);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}

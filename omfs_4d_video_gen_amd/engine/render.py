@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Engine entry point with the CLI of the absent upstream `gaussian_avatars_repo/render.py`, i.e. the
+argv `02_Visual_Engine/render_surgery.py:289-301` emits:
+
+  render.py --source_path D --model_path M --bind_to_mesh --skip_val --skip_test [--iteration K]
+
+Renders the TRAIN split of D (whose FLAME parameters render_surgery has edited) with the Gaussians
+of M/point_cloud/iteration_K and writes M/train/ours_K/renders/%05d.png and .../gt/%05d.png
+(`render_surgery.py:324-362`, `validation_reporting.py:60-78`).  With WORLD_SIZE>1 frames shard
+across ranks (frame f -> rank f mod world); no collective is needed.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+_PKG_ROOT = Path(__file__).resolve().parents[2]
+if str(_PKG_ROOT) not in sys.path:
+    sys.path.insert(0, str(_PKG_ROOT))
+
+import torch  # noqa: E402
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser(description="Render a FLAME-rigged Gaussian avatar (MI355X engine).")
+    p.add_argument("--source_path", "-s", required=True)
+    p.add_argument("--model_path", "-m", required=True)
+    p.add_argument("--bind_to_mesh", action="store_true")
+    p.add_argument("--iteration", type=int, default=-1)
+    p.add_argument("--skip_train", action="store_true")
+    p.add_argument("--skip_val", action="store_true")
+    p.add_argument("--skip_test", action="store_true")
+    p.add_argument("--white_background", action="store_true")
+    p.add_argument("--sh_degree", type=int, default=3)
+    p.add_argument("--png_workers", type=int, default=8)
+    args, unknown = p.parse_known_args(argv)
+    if unknown:
+        print(f"[engine] ignoring unknown arguments: {unknown}")
+    return args
+
+
+def find_iteration(model_path: str, wanted: int) -> int:
+    pc = Path(model_path) / "point_cloud"
+    have = sorted(int(d.name.split("_")[1]) for d in pc.iterdir() if d.name.startswith("iteration_")) if pc.is_dir() else []
+    if not have:
+        raise FileNotFoundError(f"no point_cloud/iteration_* under {model_path}")
+    if wanted > 0:
+        if wanted not in have:
+            raise FileNotFoundError(f"iteration {wanted} not found under {pc} (have {have})")
+        return wanted
+    return have[-1]
+
+
+def render_split(args, split_name: str, it: int, rank: int, world: int):
+    import json
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    from omfs_4d_video_gen_amd.engine.rig_loader import load_rig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, View
+    split = IO.load_split(args.source_path, split_name)
+    g = IO.load_gaussian_ply(Path(args.model_path) / "point_cloud" / f"iteration_{it}" / "point_cloud.ply")
+    cfg = Path(args.model_path) / "cfg_args.json"
+    white = args.white_background or (cfg.exists() and json.load(open(cfg)).get("white_background", False))
+    bg = (1.0, 1.0, 1.0) if white else (0.0, 0.0, 0.0)
+    cams = [IO.camera_from_frame(fr, split["top"]) for fr in split["frames"]]
+    if not cams:
+        return 0
+    w, h = cams[0]["width"], cams[0]["height"]
+    out_dir = Path(args.model_path) / split_name / f"ours_{it}"
+    (out_dir / "renders").mkdir(parents=True, exist_ok=True)
+    (out_dir / "gt").mkdir(parents=True, exist_ok=True)
+    r = Renderer(load_rig(), split["flame"], g, w, h, bg=bg, sh_degree=args.sh_degree)
+    pool = ThreadPoolExecutor(max_workers=max(1, args.png_workers))
+    pending = []
+    mine = range(rank, len(cams), world)
+    for idx in mine:
+        view = View(cams[idx], split["timestep_of_frame"][idx])
+        rgb8 = r.render(view, rgb8=True).cpu().numpy()          # sync per frame; encode overlaps the next frame
+        pending.append(pool.submit(IO.write_png, out_dir / "renders" / f"{idx:05d}.png", rgb8))
+        src = os.path.join(args.source_path, split["frames"][idx]["file_path"])
+        if os.path.exists(src):
+            pending.append(pool.submit(shutil.copyfile, src, out_dir / "gt" / f"{idx:05d}.png"))
+    for f in pending:
+        f.result()
+    pool.shutdown()
+    r.rast.check_status()
+    return len(mine)
+
+
+def main(argv=None):
+    args = parse(argv)
+    if not args.bind_to_mesh:
+        raise SystemExit("[engine] only --bind_to_mesh (FLAME-rigged) rendering is implemented")
+    if not torch.cuda.is_available():
+        raise SystemExit("[engine] no GPU visible: the engine has no CPU path")
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    it = find_iteration(args.model_path, args.iteration)
+    t0 = time.time()
+    total = 0
+    for name, skip in (("train", args.skip_train), ("val", args.skip_val), ("test", args.skip_test)):
+        if skip or not os.path.exists(os.path.join(args.source_path, f"transforms_{name}.json")):
+            continue
+        n = render_split(args, name, it, rank, world)
+        total += n
+        print(f"[engine] rendered {n} {name} frames at iteration {it} (rank {rank}/{world})", flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(f"Rendering complete: {total} frames on rank 0 in {time.time() - t0:.1f} s")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Engine entry point with the CLI of the absent upstream `gaussian_avatars_repo/train.py`, i.e. the
+argv `02_Visual_Engine/train_ghost.py:227-240` emits:
+
+  train.py --source_path D --model_path M --bind_to_mesh --iterations N --resolution R
+           --save_iterations ... --checkpoint_iterations ... [--white_background]
+
+Outputs (what `render_surgery.py:271-287` and `train_ghost.py:141-156` look for):
+  M/point_cloud/iteration_<it>/point_cloud.ply (+ flame_param.npz), M/chkpnt<it>.pth, M/cfg_args.json.
+Progress lines contain "iteration <n>" for the UI regex (`app.py:1387-1398`).
+Multi-GPU: launch with torch.distributed.run; views shard across ranks, gradients are all-reduced.
+Not implemented this round: adaptive density control, FLAME fine-tuning.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+_PKG_ROOT = Path(__file__).resolve().parents[2]
+if str(_PKG_ROOT) not in sys.path:
+    sys.path.insert(0, str(_PKG_ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser(description="Train a FLAME-rigged Gaussian avatar (MI355X engine).")
+    p.add_argument("--source_path", "-s", required=True)
+    p.add_argument("--model_path", "-m", required=True)
+    p.add_argument("--bind_to_mesh", action="store_true")
+    p.add_argument("--iterations", type=int, default=30000)
+    p.add_argument("--resolution", "-r", type=int, default=-1)
+    p.add_argument("--save_iterations", nargs="+", type=int, default=[])
+    p.add_argument("--checkpoint_iterations", nargs="+", type=int, default=[])
+    p.add_argument("--white_background", action="store_true")
+    p.add_argument("--sh_degree", type=int, default=3)
+    p.add_argument("--n_gaussians", type=int, default=0, help="fixed Gaussian count (0 = 10 per triangle)")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--log_every", type=int, default=100)
+    args, unknown = p.parse_known_args(argv)
+    if unknown:
+        print(f"[engine] ignoring unknown arguments: {unknown}")
+    return args
+
+
+def initial_gaussians(n: int, n_faces: int, seed: int) -> dict:
+    """Mesh-bound start: k Gaussians per triangle spread in its plane, triangle-sized, grey, faint."""
+    rng = np.random.default_rng(seed)
+    xyz = np.zeros((n, 3), np.float32)
+    xyz[:, 0] = rng.standard_normal(n) * 0.2
+    xyz[:, 2] = rng.standard_normal(n) * 0.2
+    sh = np.zeros((n, 16, 3), np.float32)
+    rot = np.zeros((n, 4), np.float32)
+    rot[:, 0] = 1.0
+    return {"xyz": xyz, "log_scale": np.full((n, 3), np.log(0.5), np.float32), "rot": rot,
+            "opacity": np.full(n, float(np.log(0.1 / 0.9)), np.float32), "sh": sh,
+            "binding": (np.arange(n) % n_faces).astype(np.int32)}
+
+
+def resize_nearest(img: np.ndarray, w: int, h: int) -> np.ndarray:
+    ys = (np.arange(h) * img.shape[0] / h).astype(np.int64)
+    xs = (np.arange(w) * img.shape[1] / w).astype(np.int64)
+    return img[ys][:, xs]
+
+
+def main(argv=None):
+    args = parse(argv)
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    from omfs_4d_video_gen_amd.engine.rig_loader import load_rig
+    from omfs_4d_video_gen_amd.engine.trainer import Trainer, View
+
+    if not args.bind_to_mesh:
+        raise SystemExit("[engine] only --bind_to_mesh (FLAME-rigged) training is implemented")
+    if not torch.cuda.is_available():
+        raise SystemExit("[engine] no GPU visible: the engine has no CPU path")
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        pg = dist.group.WORLD
+
+    split = IO.load_split(args.source_path, "train")
+    rig = load_rig()
+    bg = (1.0, 1.0, 1.0) if args.white_background else (0.0, 0.0, 0.0)
+    views, size = [], None
+    for fr, trow in zip(split["frames"], split["timestep_of_frame"]):
+        cam = IO.camera_from_frame(fr, split["top"])
+        img = IO.load_image_rgb(os.path.join(args.source_path, fr["file_path"]))
+        if args.resolution in (1, 2, 4, 8):
+            w, h = cam["width"] // args.resolution, cam["height"] // args.resolution
+        elif args.resolution > 8:
+            w, h = args.resolution, int(round(cam["height"] * args.resolution / cam["width"]))
+        else:
+            w, h = cam["width"], cam["height"]
+        if (w, h) != (cam["width"], cam["height"]):
+            s = w / cam["width"]
+            cam = {**cam, "width": w, "height": h, "fl_x": cam["fl_x"] * s, "fl_y": cam["fl_y"] * s}
+        if img.shape[:2] != (h, w):
+            img = resize_nearest(img, w, h)
+        if size is None:
+            size = (w, h)
+        elif size != (w, h):
+            raise SystemExit("[engine] all training views must share one resolution")
+        rgb = torch.from_numpy(img.astype(np.float32) / 255.0).permute(2, 0, 1).contiguous()
+        mask_rel = fr.get("fg_mask_path")
+        if mask_rel and os.path.exists(os.path.join(args.source_path, mask_rel)):
+            m = IO.read_png(os.path.join(args.source_path, mask_rel))[:, :, 0].astype(np.float32) / 255.0
+            if m.shape != (h, w):
+                m = resize_nearest(m, w, h)
+            mt = torch.from_numpy(m)[None]
+            rgb = rgb * mt + (1.0 - mt) * torch.tensor(bg)[:, None, None]
+        views.append(View(cam, int(trow), target=rgb.cuda(), name=os.path.basename(fr["file_path"])))
+    n = args.n_gaussians if args.n_gaussians > 0 else 10 * rig.n_faces
+    g0 = initial_gaussians(n, rig.n_faces, args.seed)
+    trainer = Trainer(rig, split["flame"], g0, views, size[0], size[1], bg=bg, iterations=args.iterations,
+                      sh_degree_max=args.sh_degree, start_sh_degree=0, rank=rank, world_size=world, process_group=pg)
+
+    out = Path(args.model_path)
+    if rank == 0:
+        out.mkdir(parents=True, exist_ok=True)
+        with open(out / "cfg_args.json", "w") as f:
+            json.dump({**vars(args), "n_gaussians": n, "n_train_views": len(views), "world_size": world}, f, indent=2)
+    save_at, ckpt_at = set(args.save_iterations) | {args.iterations}, set(args.checkpoint_iterations)
+    t0 = time.time()
+    for it in range(1, args.iterations + 1):
+        trainer.step()
+        if it % args.log_every == 0 or it == args.iterations:
+            if rank == 0:
+                print(f"Training progress: iteration {it}/{args.iterations} loss={trainer.loss_value():.5f} "
+                      f"({it / (time.time() - t0):.1f} it/s)", flush=True)
+            if it % (10 * args.log_every) == 0:
+                trainer.rast.check_status()
+        if rank == 0 and it in save_at:
+            print(f"\n[ITER {it}] Saving Gaussians", flush=True)
+            g = trainer.model.to_dict()
+            IO.save_gaussian_ply(out / "point_cloud" / f"iteration_{it}" / "point_cloud.ply", g)
+            np.savez(out / "point_cloud" / f"iteration_{it}" / "flame_param.npz", **split["flame"])
+        if rank == 0 and it in ckpt_at:
+            print(f"\n[ITER {it}] Saving Checkpoint", flush=True)
+            torch.save({"iteration": it, "params": trainer.model.params.cpu(), "binding": trainer.model.binding.cpu(),
+                        "adam_m": trainer.opt.m.cpu(), "adam_v": trainer.opt.v.cpu(), "sh_degree": trainer.sh_degree},
+                       out / f"chkpnt{it}.pth")
+    torch.cuda.synchronize()
+    trainer.rast.check_status()
+    if rank == 0:
+        print(f"\nTraining complete. [{time.time() - t0:.1f} s]")
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -106,7 +106,8 @@ class Trainer:
         return c
 
     def view_for_step(self, step: int) -> View:
-        return self.views[(step * self.world + self.rank) % len(self.views)]
+        from .distributed import view_index
+        return self.views[view_index(step, self.rank, self.world, len(self.views))]
 
     def step(self) -> None:
         """One training iteration of this rank (enqueue only)."""
@@ -139,8 +140,8 @@ class Trainer:
         rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
         L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.pg)
+            from .distributed import allreduce_sum_
+            allreduce_sum_(self.grads, self.pg)
             tm.mark("allreduce")
         lr = expon_lr(it, self.pos_lr[0], self.pos_lr[1], self.iterations)
         self.lr_planes[0:3] = lr

@@ -1,0 +1,100 @@
+"""CPU: the C-ABI library loads and exports every symbol include/omfs_splat.h declares (no compute
+calls: there is no GPU here); the ctypes table covers exactly those symbols; file formats round-trip."""
+import ctypes
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "omfs_splat.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(omfs_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from omfs_4d_video_gen_amd import _lib as L
+    lib = L.load()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/omfs_splat.h but not exported"
+    assert sorted(L.SIGNATURES) == syms, "ctypes table and header disagree"
+    assert lib.omfs_abi_version() == L.ABI_VERSION == int(re.search(r"#define OMFS_ABI_VERSION (\d+)", (ROOT / "include" / "omfs_splat.h").read_text()).group(1))
+
+
+def test_argument_validation_fails_loudly_without_touching_the_gpu():
+    from omfs_4d_video_gen_amd import _lib as L
+    lib = L.load()
+    rc = lib.omfs_adam_step(0, 0, 0, 0, 0, 0, ctypes.byref(L.AdamParamsC()), 0)
+    assert rc == -1 and b"null pointer" in lib.omfs_last_error()
+    with pytest.raises(L.OmfsError, match="omfs_adam_step failed"):
+        L.check(rc, "omfs_adam_step")
+
+
+def test_struct_layouts_match_the_header():
+    """sizeof of every ctypes struct equals what the C compiler lays out (guards silent ABI drift)."""
+    import subprocess
+    import tempfile
+    from omfs_4d_video_gen_amd import _lib as L
+    names = {"omfs_flame_rig": L.FlameRigC, "omfs_simpleflame": L.SimpleFlameC, "omfs_camera": L.CameraC, "omfs_gaussians": L.GaussiansC,
+             "omfs_raster_buffers": L.RasterBuffersC, "omfs_grad_buffers": L.GradBuffersC, "omfs_reg_params": L.RegParamsC,
+             "omfs_adam_params": L.AdamParamsC}
+    src = '#include <stdio.h>\n#include "omfs_splat.h"\nint main(){' + "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
+    with tempfile.TemporaryDirectory() as d:
+        (Path(d) / "s.c").write_text(src)
+        subprocess.check_call(["gcc", "-I", str(ROOT / "include"), "-o", f"{d}/s", f"{d}/s.c"])
+        out = subprocess.check_output([f"{d}/s"], text=True)
+    for line in out.strip().splitlines():
+        n, size = line.split()
+        assert ctypes.sizeof(names[n]) == int(size), n
+
+
+def test_png_and_ply_roundtrip(tmp_path):
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    from omfs_4d_video_gen_amd.engine import synthetic
+    rng = np.random.default_rng(1)
+    for shape in ((7, 5, 3), (16, 16, 4), (3, 9)):
+        img = rng.integers(0, 255, shape).astype(np.uint8)
+        IO.write_png(tmp_path / "a.png", img)
+        back = IO.read_png(tmp_path / "a.png")
+        assert np.array_equal(back if img.ndim == 3 else back[:, :, 0], img)
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.png").write_bytes(b"not a png")
+        IO.read_png(tmp_path / "bad.png")
+    g = synthetic.make_gaussians(257, 100, 3)
+    IO.save_gaussian_ply(tmp_path / "pc" / "point_cloud.ply", g)
+    back = IO.load_gaussian_ply(tmp_path / "pc" / "point_cloud.ply")
+    for k in g:
+        assert np.array_equal(back[k], g[k]), k
+
+
+def test_dataset_write_load_roundtrip(tmp_path):
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    from omfs_4d_video_gen_amd.engine import synthetic
+    from omfs_4d_video_gen_amd.train_ghost import validate_data, run_quality_gates
+    T = 60
+    seq = synthetic.make_flame_sequence(T, 4)
+    cams = [synthetic.make_camera(32, 24, yaw=0.01 * i) for i in range(T)]
+    imgs = [np.full((24, 32, 3), i, np.uint8) for i in range(T)]
+    IO.write_dataset(tmp_path / "ds", cams, list(range(T)), imgs, seq, fg_masks=True)
+    validate_data(str(tmp_path / "ds"))
+    run_quality_gates(str(tmp_path / "ds"))
+    sp = IO.load_split(str(tmp_path / "ds"), "train")
+    assert len(sp["frames"]) == 54 and sp["timestep_of_frame"] == list(range(54))
+    for k in ("expr", "rotation", "jaw_pose", "translation", "neck_pose", "eyes_pose"):
+        assert np.array_equal(sp["flame"][k], seq[k][:54]), k
+    assert np.array_equal(sp["flame"]["shape"], seq["shape"]) and sp["flame"]["static_offset"].shape == (1, 5143, 3)
+    cam = IO.camera_from_frame(sp["frames"][7], sp["top"])
+    assert np.allclose(cam["world_to_view"], cams[7]["world_to_view"], atol=1e-6) and cam["width"] == 32
+    assert cam["fl_x"] == pytest.approx(cams[7]["fl_x"], rel=1e-6)
+    test = IO.load_split(str(tmp_path / "ds"), "test")
+    assert len(test["frames"]) == 6 and np.array_equal(test["flame"]["expr"], seq["expr"][54:])
+    # the default VHAP transform (preprocess_video.py:370) is a camera one unit in front of the head
+    c = IO.camera_from_frame({"transform_matrix": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1], [0, 0, 0, 1]], "w": 8, "h": 8, "camera_angle_x": 0.5}, {})
+    assert np.allclose(c["cam_pos"], [0, 0, 1]) and np.allclose(c["world_to_view"][:3, :3], np.diag([1, -1, -1]))

