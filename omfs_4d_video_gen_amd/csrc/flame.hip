@@ -2,7 +2,7 @@
 //
 // Stage map (the reference's own FLAME code,
 // 02_Visual_Engine/flame_fitter.py:154-197, stops at linear blendshapes and has no LBS):
-//   flame_joints_kernel : J = J_static + JE.expr, kinematic chain -> 5 rigid transforms / frame,
+//   flame_joints_kernel : J = J_static + JE.expr (15 lanes), kinematic chain -> 5 rigid transforms / frame,
 //                         blendshape coefficient matrix coef[k_pad][b_pad] (expr | pose features)
 //   flame_lbs_kernel    : v_posed = v_static + basis.coef on f32 MFMA (16x16x4), then linear
 //                         blend skinning straight out of the accumulator registers
@@ -17,27 +17,40 @@ namespace omfs {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// One thread per frame.
-__global__ void flame_joints_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
-                                    const float* __restrict__ expr, const float* __restrict__ rotmats, int n_frames,
-                                    int n_expr, int k_pad, int b_pad, float* __restrict__ joint_xf,
-                                    float* __restrict__ coef) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= b_pad) return;
+// One 64-thread block per frame column: 15 lanes run the joint-regression chains (ascending-k fma, as
+// the oracle), all lanes write the coefficient column, lane 0 walks the 5-joint kinematic chain.
+__global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
+                                                          const float* __restrict__ expr, const float* __restrict__ rotmats,
+                                                          int n_frames, int n_expr, int k_pad, int b_pad,
+                                                          float* __restrict__ joint_xf, float* __restrict__ coef) {
+  __shared__ float sJ[15];
+  const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= n_frames) {  // padded frame columns: zero coefficients
-    for (int k = 0; k < k_pad; ++k) coef[(size_t)k * b_pad + b] = 0.f;
+    for (int k = lane; k < k_pad; k += 64) coef[(size_t)k * b_pad + b] = 0.f;
     return;
   }
   const float* e = expr + (size_t)b * n_expr;
   const float* R = rotmats + (size_t)b * 45;
-  // joints: J[j][c] = j_static + sum_k j_expr[j*3+c][k] * e[k]   (k ascending fma chain)
-  float J[5][3];
-  for (int jc = 0; jc < 15; ++jc) {
-    float acc = j_static[jc];
-    const float* row = j_expr + (size_t)jc * n_expr;
+  if (lane < 15) {  // J[j][c] = j_static + sum_k j_expr[j*3+c][k] * e[k]
+    float acc = j_static[lane];
+    const float* row = j_expr + (size_t)lane * n_expr;
     for (int k = 0; k < n_expr; ++k) acc = fma_(row[k], e[k], acc);
-    J[jc / 3][jc % 3] = acc;
+    sJ[lane] = acc;
   }
+  // coefficient column: expr, then pose features (R_j - I), j = 1..4, row-major, then zero padding
+  for (int k = lane; k < k_pad; k += 64) {
+    float v = 0.f;
+    if (k < n_expr) v = e[k];
+    else if (k < n_expr + 36) {
+      const int i = (k - n_expr) % 9;
+      v = R[9 + (k - n_expr)] - ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f);
+    }
+    coef[(size_t)k * b_pad + b] = v;
+  }
+  __syncthreads();
+  if (lane != 0) return;
+  float J[5][3];
+  for (int jc = 0; jc < 15; ++jc) J[jc / 3][jc % 3] = sJ[jc];
   // kinematic chain, parents = [-1, 0, 1, 1, 1]
   float Rw[5][9], tw[5][3];
   for (int i = 0; i < 9; ++i) Rw[0][i] = R[i];
@@ -57,12 +70,6 @@ __global__ void flame_joints_kernel(const float* __restrict__ j_static, const fl
     for (int r = 0; r < 3; ++r)
       out[j * 12 + 9 + r] = tw[j][r] - dot3_(Rw[j][r * 3 + 0], Rw[j][r * 3 + 1], Rw[j][r * 3 + 2], J[j][0], J[j][1], J[j][2]);
   }
-  // coefficient column: expr, then pose features (R_j - I), j = 1..4, row-major
-  for (int k = 0; k < n_expr; ++k) coef[(size_t)k * b_pad + b] = e[k];
-  for (int j = 1; j < 5; ++j)
-    for (int i = 0; i < 9; ++i)
-      coef[(size_t)(n_expr + (j - 1) * 9 + i) * b_pad + b] = R[j * 9 + i] - ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f);
-  for (int k = n_expr + 36; k < k_pad; ++k) coef[(size_t)k * b_pad + b] = 0.f;
 }
 
 // grid = (v_pad/16 strips, b_pad/16 column blocks), block = 64 (one wave per 16 vertices x 16 frames).
@@ -179,7 +186,7 @@ extern "C" int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, c
   OMFS_REQUIRE(rig && expr && rotmats && joint_xf && coef, "null pointer");
   OMFS_REQUIRE(n_frames > 0 && rig->n_expr > 0 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36, "shape");
   int b_pad = cdiv(n_frames, 16) * 16;
-  hipLaunchKernelGGL(flame_joints_kernel, dim3(cdiv(b_pad, 64)), dim3(64), 0, (hipStream_t)stream, rig->j_static,
+  hipLaunchKernelGGL(flame_joints_kernel, dim3(b_pad), dim3(64), 0, (hipStream_t)stream, rig->j_static,
                      rig->j_expr, expr, rotmats, n_frames, rig->n_expr, rig->k_pad, b_pad, joint_xf, coef);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;

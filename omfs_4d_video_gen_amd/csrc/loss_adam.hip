@@ -20,7 +20,7 @@ struct GaussW { float g[11]; };  // normalised 11-tap window, passed by value (s
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                        int width, int height, float w_l1, float w_ssim, GaussW gw,
                                                        float* __restrict__ map_mu1, float* __restrict__ map_xx,
-                                                       float* __restrict__ map_xy, float* __restrict__ loss_out) {
+                                                       float* __restrict__ map_xy, float* __restrict__ partials) {
   __shared__ float sx[LW][LW + 1], sy[LW][LW + 1];
   __shared__ float h[5][LW][LT + 1];
   __shared__ float wsum[4];
@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
   contrib = wave_sum_all(contrib);
   if ((tid & 63) == 0) wsum[tid >> 6] = contrib;
   __syncthreads();
-  if (tid == 0) atomicAdd(loss_out, (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]));
+  // one partial per block (24k same-address atomics would serialise at ~11 ns each)
+  if (tid == 0) partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
@@ -124,7 +125,21 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
   }
 }
 
-__global__ void add_const_kernel(float* p, float v) { p[0] += v; }
+// one block: loss_out += constant + sum(partials)   (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ partials, int n, float constant,
+                                                          float* __restrict__ loss_out) {
+  __shared__ float ws[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) acc += partials[i];
+  acc = wave_sum_all(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += ws[w];
+    loss_out[0] += constant + t;
+  }
+}
 
 struct AdamK {
   float lr_step[OMFS_NPLANES];  // lr / (1 - b1^t)
@@ -177,9 +192,10 @@ extern "C" int omfs_loss_l1_ssim(const float* image, const float* target, int wi
   const float w_l1 = (1.f - lambda_dssim) * inv, w_ssim = lambda_dssim * inv;
   float* m0 = scratch; float* m1 = scratch + n; float* m2 = scratch + 2 * n;
   dim3 grid(cdiv(width, LT), cdiv(height, LT), 3);
-  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, loss_out);
+  // block partials are parked at the head of dimage (overwritten by ssim_bwd afterwards)
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
   OMFS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(add_const_kernel, dim3(1), dim3(1), 0, s, loss_out, lambda_dssim);
+  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, dimage, (int)(grid.x * grid.y * grid.z), lambda_dssim, loss_out);
   hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;

@@ -137,11 +137,16 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(int n, int n_pad, cons
   g2[i] = o2;
 }
 
-__global__ void count_visible_kernel(const float4* __restrict__ g2, int n, uint32_t* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t vis = (i < n) && ((__float_as_uint(g2[i].z) & 0xFFFFFu) != 0u);
-  unsigned long long m = __ballot(vis);
-  if (lane_id() == 0 && m) atomicAdd(out, (uint32_t)__popcll(m));
+__global__ __launch_bounds__(1024) void count_visible_kernel(const float4* __restrict__ g2, int n, uint32_t* __restrict__ out) {
+  __shared__ uint32_t cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t vis = (i < n) && ((__float_as_uint(g2[i].z) & 0xFFFFFu) != 0u);
+  const unsigned long long m = __ballot(vis);
+  if (lane_id() == 0 && m) atomicAdd(&cnt, (uint32_t)__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0 && cnt) atomicAdd(out, cnt);   // one global atomic per 1024 Gaussians
 }
 
 ProjCam make_projcam(const omfs_camera* c) {
@@ -178,7 +183,7 @@ extern "C" int omfs_count_visible(const omfs_raster_buffers* rb, int n, uint32_t
   OMFS_REQUIRE(rb && rb->g2 && count_out && n > 0, "args");
   hipStream_t s = (hipStream_t)stream;
   OMFS_CHECK_HIP(hipMemsetAsync(count_out, 0, sizeof(uint32_t), s));
-  hipLaunchKernelGGL(count_visible_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, (const float4*)rb->g2, n, count_out);
+  hipLaunchKernelGGL(count_visible_kernel, dim3(cdiv(n, 1024)), dim3(1024), 0, s, (const float4*)rb->g2, n, count_out);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

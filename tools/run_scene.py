@@ -42,3 +42,9 @@ if not a.train:
         r.render(views[i % 16])
     torch.cuda.synchronize()
 print("D", int(t.rast.tile_start[-1]))
+if os.environ.get("OMFS_DUMP"):
+    import numpy as np
+    r = t.rast
+    t.step(); torch.cuda.synchronize()
+    np.savez_compressed(os.environ["OMFS_DUMP"], tile_start=r.tile_start.cpu().numpy(), n_contrib=r.n_contrib.cpu().numpy(),
+                        final_T=r.final_T.cpu().numpy().astype(np.float16))
