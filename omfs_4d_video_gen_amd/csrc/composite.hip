@@ -28,27 +28,53 @@ struct CompCam {
   float bg[3];
 };
 
-// Minimum of q(d) = A dx^2 + 2 B dx dy + C dy^2 (positive definite) over the box
-// [dxl,dxh] x [dyl,dyh]; `mag` returns the magnitude of the terms at the minimiser (for slack).
-__device__ __forceinline__ float qmin_box(float A, float B, float C, float nBoC, float nBoA, float dxl, float dxh,
-                                          float dyl, float dyh, float& mag) {
-  if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) { mag = 0.f; return 0.f; }
-  float best = 3.0e38f;
-  mag = 0.f;
-  auto cand = [&](float dx, float dy) {
-    const float t0 = A * dx * dx, t1 = 2.f * B * dx * dy, t2 = C * dy * dy;
-    const float q = t0 + t1 + t2;
-    if (q < best) { best = q; mag = t0 + fabsf(t1) + t2; }
-  };
-  cand(dxl, fminf(fmaxf(nBoC * dxl, dyl), dyh));
-  cand(dxh, fminf(fmaxf(nBoC * dxh, dyl), dyh));
-  cand(fminf(fmaxf(nBoA * dyl, dxl), dxh), dyl);
-  cand(fminf(fmaxf(nBoA * dyh, dxl), dxh), dyh);
-  return best;
+// 16-bit coverage mask of one splat over the tile's 4x4 grid of 4x4-pixel blocks: bit q*4+s, quadrant
+// q = (kx>>1) + 2(ky>>1) (= the wave that owns it), sub-block s = (kx&1) + 2(ky&1).  A bit is set when
+// the ellipse {q(d) <= 2 ln(255 o)} -- outside of which alpha < 1/255 -- can overlap the block.
+// Conservative by construction (blocks are widened by half a pixel, the ellipse by a rounding slack):
+// a cleared bit means no pixel of the block can receive a contribution, so skipping the splat for
+// that block changes nothing.  Cost ~170 instructions: the ellipse is cut by the 5 horizontal lines
+// that bound the 4 block rows (one sqrt each); within a row band the x-extent of the convex set is
+// attained on the two lines or at the ellipse's leftmost / rightmost point.
+__device__ __forceinline__ uint32_t block_mask(float mx, float my, float A, float B, float C, float lo, int tx0, int ty0) {
+  const float qmax = 2.f * 0.6931471805599453f * (lo - LOG2_INV255);
+  if (!(qmax >= 0.f)) return 0u;            // opacity below 1/255: never contributes
+  const float det = A * C - B * B;
+  if (!(A > 0.f && C > 0.f && det > 0.f)) return 0xFFFFu;   // degenerate conic: never cull
+  const float Q = qmax * 1.0002f + 0.02f;
+  const float idet = 1.f / det, iA = 1.f / A;
+  const float vmax = sqrtf(Q * A * idet), umax = sqrtf(Q * C * idet);
+  const float vl = B * umax / C;           // v of the leftmost point (u = -umax); the rightmost one is at -vl
+  float vline[5], ulo[5], uhi[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    vline[k] = ((float)ty0 - 0.5f + 4.f * (float)k) - my;
+    const float vc = fminf(fmaxf(vline[k], -vmax), vmax);
+    const float sq = sqrtf(fmaxf(A * Q - det * vc * vc, 0.f));
+    ulo[k] = (-B * vc - sq) * iA;
+    uhi[k] = (-B * vc + sq) * iA;
+  }
+  const float x0 = ((float)tx0 - 0.5f) - mx;   // left edge of block column 0, relative to the splat centre
+  uint32_t m = 0;
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky) {
+    const float v0 = vline[ky], v1 = vline[ky + 1];
+    if (v0 > vmax || v1 < -vmax) continue;
+    const float a = fmaxf(v0, -vmax), b = fminf(v1, vmax);
+    float xlo = (a <= vl && vl <= b) ? -umax : fminf(ulo[ky], ulo[ky + 1]);
+    float xhi = (a <= -vl && -vl <= b) ? umax : fmaxf(uhi[ky], uhi[ky + 1]);
+    xlo -= 0.02f + 1e-4f * fabsf(xlo);
+    xhi += 0.02f + 1e-4f * fabsf(xhi);
+#pragma unroll
+    for (int kx = 0; kx < 4; ++kx) {
+      const float L = x0 + 4.f * (float)kx;
+      if (xhi >= L && xlo <= L + 4.f) m |= 1u << (((kx >> 1) + 2 * (ky >> 1)) * 4 + ((kx & 1) + 2 * (ky & 1)));
+    }
+  }
+  return m;
 }
 
-// Per-splat staging: log2-domain coefficients + 16-bit mask, bit q*4+s = quadrant q (wave), 4x4
-// sub-block s of it ((s&1) -> x half, (s>>1) -> y half).
+// Per-splat staging: log2-domain coefficients + the 16-bit block mask.
 struct Staged {
   float4 a;  // mx, my, A2 = -0.5*log2e*A, B2 = -log2e*B
   float4 b;  // C2 = -0.5*log2e*C, lo = log2(opacity), r, g
@@ -63,32 +89,7 @@ __device__ __forceinline__ Staged stage_splat(const float4 g0, const float4 g1, 
   s.a = make_float4(g0.x, g0.y, -0.5f * LOG2E * A, -LOG2E * B);
   s.b = make_float4(-0.5f * LOG2E * C, lo, g1.z, g1.w);
   s.c = g2x;
-  // contributes somewhere iff q <= qmax = 2 ln(255 o) = 2 ln2 (lo - log2(1/255))
-  const float qmax = 2.f * 0.6931471805599453f * (lo - LOG2_INV255);
-  uint32_t m = 0;
-  if (qmax >= 0.f) {
-    if (!(A > 0.f && C > 0.f)) {
-      m = 0xFFFFu;  // degenerate conic: never cull
-    } else {
-      const float nBoC = -B / C, nBoA = -B / A;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float qx0 = (float)(tx0 + (q & 1) * 8), qy0 = (float)(ty0 + (q >> 1) * 8);
-        float mag;
-        // whole quadrant first: most splats miss most quadrants
-        const float qq = qmin_box(A, B, C, nBoC, nBoA, g0.x - (qx0 + 7.f), g0.x - qx0, g0.y - (qy0 + 7.f), g0.y - qy0, mag);
-        if (qq - 4e-5f * mag - 1e-3f <= qmax) {
-#pragma unroll
-          for (int sb = 0; sb < 4; ++sb) {
-            const float x0 = qx0 + (float)((sb & 1) * 4), y0 = qy0 + (float)((sb >> 1) * 4);
-            const float qs = qmin_box(A, B, C, nBoC, nBoA, g0.x - (x0 + 3.f), g0.x - x0, g0.y - (y0 + 3.f), g0.y - y0, mag);
-            if (qs - 4e-5f * mag - 1e-3f <= qmax) m |= 1u << (q * 4 + sb);
-          }
-        }
-      }
-    }
-  }
-  s.qmask = m;
+  s.qmask = block_mask(g0.x, g0.y, A, B, C, lo, tx0, ty0);
   return s;
 }
 
@@ -97,7 +98,7 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
   return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(256) void composite_fwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
+__global__ __launch_bounds__(256, 8) void composite_fwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
                                                             const uint32_t* __restrict__ tile_start,
                                                             const uint32_t* __restrict__ sorted_ids,
                                                             const float4* __restrict__ g0, const float4* __restrict__ g1,
@@ -234,11 +235,12 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
                                                             const float* __restrict__ dimage, float* __restrict__ dsplat) {
   __shared__ float4 s0[CB];
   __shared__ float4 s1[CB];
-  __shared__ float s2[CB];
+  __shared__ float2 s2[CB];   // (blue, opacity)
   __shared__ uint32_t sid[CB];
   __shared__ unsigned long long qm[16][4];   // [quadrant*4 + sub-block][64-group]
-  __shared__ unsigned long long vis[4][4];   // [wave][64-group]: splats this wave actually reduced
-  __shared__ float red[64][4][9 + 2];        // [splat in 64-group][wave][value], padded to 11
+  constexpr int PEND = 16;                   // reduced splats a wave parks before it flushes them
+  __shared__ float red[4][PEND][8][9];       // [wave][pending slot][8-lane group][value]: private to each wave
+  __shared__ uint32_t pend_j[4][PEND];       // batch-local index of the splat in each pending slot
   __shared__ uint32_t s_max;
   const uint32_t tile = tile_order[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -287,13 +289,28 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
       r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
     }
   }
+  int n_pending = 0;
+  // wave-local flush (no workgroup barrier: the four quadrant waves run independently inside a batch):
+  // four pending splats per wave-instruction, 16 lanes per 64-byte dsplat record, lane q < 9 adds value q
+  auto flush_pending = [&]() {
+    for (int base = 0; base < n_pending; base += 4) {
+      const int slot = base + (lane >> 4), q = lane & 15;
+      if (slot < n_pending && q < 9) {
+        const float* src = &red[wave][slot][0][q];
+        float sum = 0.f;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) sum += src[p8 * 9];
+        if (sum != 0.f) atomicAdd(&dsplat[(size_t)sid[pend_j[wave][slot]] * 16 + q], sum);
+      }
+    }
+  };
   for (int bi = (int)n_batches - 1; bi >= 0; --bi) {
     const int cnt = (int)min((uint32_t)CB, n_visit - (uint32_t)bi * CB);
     uint32_t mask = 0;
     if (tid < cnt) {
       const Staged st = stage_splat(r0, r1, r2, tx0, ty0);
       sid[tid] = rid;
-      s0[tid] = st.a; s1[tid] = st.b; s2[tid] = st.c;
+      s0[tid] = st.a; s1[tid] = st.b; s2[tid] = make_float2(st.c, r1.y);
       mask = st.qmask;
     }
 #pragma unroll
@@ -319,10 +336,9 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
           m |= uniform_u64(qm[wave * 4 + sb][g]) & keep;
         }
       }
-      unsigned long long m_done = 0ull;
       int jbn = m ? 63 - __builtin_clzll(m) : 0;
       float4 an = s0[g * 64 + jbn], cn = s1[g * 64 + jbn];
-      float cbn = s2[g * 64 + jbn];
+      float2 cbn = s2[g * 64 + jbn];
       while (m) {
         const int jb = jbn;
         m &= ~(1ull << jb);
@@ -332,8 +348,8 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
         for (int q = 0; q < 9; ++q) v[q] = 0.f;
         const float4 a = an;
         const float4 c = cn;
-        const float cb = cbn;
-        jbn = m ? 63 - __builtin_clzll(m) : 0;     // prefetch the next splat's record
+        const float2 cb = cbn;                   // (blue, opacity)
+        jbn = m ? 63 - __builtin_clzll(m) : 0;   // prefetch the next splat's record
         an = s0[g * 64 + jbn]; cn = s1[g * 64 + jbn]; cbn = s2[g * 64 + jbn];
         bool hit = false;
         if (contributor <= last) {
@@ -342,56 +358,55 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
           const float e = p2 + c.y;
           if (p2 <= 0.f && e >= LOG2_INV255) {
             hit = true;
-            const float oG = __builtin_amdgcn_exp2f(e);   // opacity * G
+            const float G = __builtin_amdgcn_exp2f(p2);
+            const float oG = cb.y * G;                              // opacity * G
             const float alpha = fminf(0.99f, oG);
-            T = T / (1.f - alpha);
+            const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
+            T = T * r1a;
             const float w = alpha * T;
             v[6] = w * dL0; v[7] = w * dL1; v[8] = w * dL2;  // dL/dcolour
             acc0 = fma_(la, lc0, (1.f - la) * acc0);
             acc1 = fma_(la, lc1, (1.f - la) * acc1);
             acc2 = fma_(la, lc2, (1.f - la) * acc2);
-            lc0 = c.z; lc1 = c.w; lc2 = cb; la = alpha;
-            float dLa = (c.z - acc0) * dL0 + (c.w - acc1) * dL1 + (cb - acc2) * dL2;
-            dLa = dLa * T + (-T_final / (1.f - alpha)) * bgdot;
+            lc0 = c.z; lc1 = c.w; lc2 = cb.x; la = alpha;
+            float dLa = (c.z - acc0) * dL0 + (c.w - acc1) * dL1 + (cb.x - acc2) * dL2;
+            dLa = fma_(dLa, T, -(T_final * r1a) * bgdot);
             // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream
             // rasteriser does (DESIGN.md "Frozen conventions").  With A2 = -0.5 log2e A etc.:
             //   dG/ddx = -G (A dx + B dy) = G (2 A2 dx + B2 dy) / log2e
             const float gL = oG * dLa;                     // dL/dG * G  (opacity folded in)
-            const float ix = (2.f * a.z * dx + a.w * dy) * (1.f / LOG2E), iy = (2.f * c.x * dy + a.w * dx) * (1.f / LOG2E);
-            v[0] = gL * ix;                 // d mean2d.x (dx = mean - pixel)
-            v[1] = gL * iy;                 // d mean2d.y
-            v[2] = -0.5f * gL * dx * dx;    // d conic.a
-            v[3] = -gL * dx * dy;           // d conic.b (B multiplies dx*dy once)
-            v[4] = -0.5f * gL * dy * dy;    // d conic.c
-            v[5] = __builtin_amdgcn_exp2f(p2) * dLa;  // d opacity: G * dL/dalpha
+            const float gs = gL * (1.f / LOG2E);
+            v[0] = gs * fma_(2.f * a.z, dx, a.w * dy);      // d mean2d.x (dx = mean - pixel)
+            v[1] = gs * fma_(2.f * c.x, dy, a.w * dx);      // d mean2d.y
+            const float hx = -0.5f * gL * dx;
+            v[2] = hx * dx;                                 // d conic.a
+            v[3] = 2.f * hx * dy;                           // d conic.b (B multiplies dx*dy once)
+            v[4] = -0.5f * gL * dy * dy;                    // d conic.c
+            v[5] = G * dLa;                                 // d opacity
           }
         }
         if (__ballot(hit) == 0ull) continue;  // nobody in this quadrant was touched: nothing to reduce
-        m_done |= 1ull << jb;
+        // partial reduction: three DPP steps leave the sums of 8-lane groups in lanes 7, 15, ..., 63; the
+        // 8 partials per value go to this wave's pending slot and are summed by the flush
 #pragma unroll
-        for (int q = 0; q < 9; ++q) v[q] = wave_sum_to_lane63(v[q]);
-        if (lane == 63) {
-#pragma unroll
-          for (int q = 0; q < 9; ++q) red[jb][wave][q] = v[q];
+        for (int q = 0; q < 9; ++q) {
+          float x = v[q];
+          x += dpp_mov<0x111>(x);  // row_shr:1
+          x += dpp_mov<0x112>(x);  // row_shr:2
+          x += dpp_mov<0x114>(x);  // row_shr:4
+          v[q] = x;
         }
-      }
-      if (lane == 0) vis[wave][g] = m_done;
-      __syncthreads();
-      // 16 lanes per 64-byte splat record; lane q < 9 adds value q
-      const int gcnt = min(64, cnt - g * 64);
-      for (int r = tid; r < gcnt * 16; r += CB) {
-        const int jj = r >> 4, q = r & 15;
-        if (q < 9) {
-          float sum = 0.f;
-          bool any = false;
+        if ((lane & 7) == 7) {
+          float* dst = &red[wave][n_pending][lane >> 3][0];
 #pragma unroll
-          for (int w = 0; w < 4; ++w)
-            if ((vis[w][g] >> jj) & 1ull) { sum += red[jj][w][q]; any = true; }
-          if (any && sum != 0.f) atomicAdd(&dsplat[(size_t)sid[g * 64 + jj] * 16 + q], sum);
+          for (int q = 0; q < 9; ++q) dst[q] = v[q];
         }
+        if (lane == 0) pend_j[wave][n_pending] = (uint32_t)(g * 64 + jb);
+        if (++n_pending == PEND) { flush_pending(); n_pending = 0; }
       }
-      __syncthreads();
     }
+    if (n_pending) { flush_pending(); n_pending = 0; }
+    __syncthreads();   // every wave is done with this batch's LDS before it is restaged
   }
 }
 
