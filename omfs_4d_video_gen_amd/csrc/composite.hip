@@ -1,14 +1,12 @@
 // Front-to-back alpha compositing, forward and backward, for gfx950 (wave64).
 //
-// Mapping: one 256-thread workgroup per 16x16 tile; wave w owns the 8x8 quadrant (w&1, w>>1), lane l
-// the pixel (l&7, l>>3) of it.  The tile's sorted list is staged through LDS in batches of 256
-// splats: each thread gathers one splat (id + three 16-byte records), pre-scales it to the log2
-// domain and decides, per quadrant, whether the splat can reach alpha >= 1/255 anywhere in that
-// quadrant (exact minimum of the conic's quadratic form over the quadrant's pixel box, with
-// slack).  The four staging waves publish those decisions as 64-bit ballots; each consumer wave
-// then walks ONLY the set bits of its own quadrant's masks with scalar bit scans, so splats that
-// cannot touch a quadrant cost it no vector instruction at all.  This is what keeps the serial
-// depth of silhouette tiles (pixels that never saturate walk the whole list) short.
+// Mapping: one 64-lane workgroup (one wave) per (16x16 tile, 8x8 quadrant); lane l owns pixel
+// (l&7, l>>3) of the quadrant.  Waves are fully independent -- no workgroup barrier anywhere -- so a
+// saturated quadrant retires at once and a silhouette quadrant (pixels that never saturate walk the
+// whole list) holds exactly one wave slot.  Each wave streams the tile's sorted list in steps of 64
+// entries through a private LDS page (gather software-pipelined one step ahead), decides per entry
+// which of its four 4x4 sub-blocks the splat can reach with alpha >= 1/255 (exact ellipse-vs-band
+// test with slack) and walks only those entries, with scalar bit scans over 64-bit ballots.
 // Heavy tiles are dispatched first (tile_order).
 //
 // Spec: SURVEY.md Appendix A items 6-7: integer pixel coordinate is the sample position;
@@ -19,7 +17,6 @@
 
 namespace omfs {
 
-constexpr int CB = 256;  // splats per LDS batch == threads per tile
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LOG2_INV255 = -7.994353436858858f;  // log2(1/255)
 
@@ -28,36 +25,35 @@ struct CompCam {
   float bg[3];
 };
 
-// 16-bit coverage mask of one splat over the tile's 4x4 grid of 4x4-pixel blocks: bit q*4+s, quadrant
-// q = (kx>>1) + 2(ky>>1) (= the wave that owns it), sub-block s = (kx&1) + 2(ky&1).  A bit is set when
-// the ellipse {q(d) <= 2 ln(255 o)} -- outside of which alpha < 1/255 -- can overlap the block.
-// Conservative by construction (blocks are widened by half a pixel, the ellipse by a rounding slack):
-// a cleared bit means no pixel of the block can receive a contribution, so skipping the splat for
-// that block changes nothing.  Cost ~170 instructions: the ellipse is cut by the 5 horizontal lines
-// that bound the 4 block rows (one sqrt each); within a row band the x-extent of the convex set is
-// attained on the two lines or at the ellipse's leftmost / rightmost point.
-__device__ __forceinline__ uint32_t block_mask(float mx, float my, float A, float B, float C, float lo, int tx0, int ty0) {
+// 4-bit coverage mask of one splat over the four 4x4-pixel sub-blocks of ONE 8x8 quadrant: bit
+// s = (kx&1) + 2(ky&1).  A bit is set when the ellipse {q(d) <= 2 ln(255 o)} -- outside of which
+// alpha < 1/255 -- can overlap the sub-block.  Conservative by construction (blocks are widened by half a
+// pixel, the ellipse by a rounding slack): a cleared bit means no pixel of the sub-block can receive a
+// contribution, so skipping the splat for it changes nothing.  The ellipse is cut by the 3 horizontal
+// lines that bound the quadrant's 2 block rows (one sqrt each); inside a row band the x-extent of the
+// convex set is attained on the two lines or at the ellipse's leftmost / rightmost point.
+__device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, float B, float C, float lo, int qx0, int qy0) {
   const float qmax = 2.f * 0.6931471805599453f * (lo - LOG2_INV255);
   if (!(qmax >= 0.f)) return 0u;            // opacity below 1/255: never contributes
   const float det = A * C - B * B;
-  if (!(A > 0.f && C > 0.f && det > 0.f)) return 0xFFFFu;   // degenerate conic: never cull
+  if (!(A > 0.f && C > 0.f && det > 0.f)) return 0xFu;   // degenerate conic: never cull
   const float Q = qmax * 1.0002f + 0.02f;
-  const float idet = 1.f / det, iA = 1.f / A;
-  const float vmax = sqrtf(Q * A * idet), umax = sqrtf(Q * C * idet);
-  const float vl = B * umax / C;           // v of the leftmost point (u = -umax); the rightmost one is at -vl
-  float vline[5], ulo[5], uhi[5];
+  const float idet = __builtin_amdgcn_rcpf(det), iA = __builtin_amdgcn_rcpf(A);
+  const float vmax = sqrtf(Q * A * idet) * 1.0001f, umax = sqrtf(Q * C * idet) * 1.0001f;
+  const float vl = B * umax * __builtin_amdgcn_rcpf(C);   // v of the leftmost point (u = -umax); the rightmost is at -vl
+  float vline[3], ulo[3], uhi[3];
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    vline[k] = ((float)ty0 - 0.5f + 4.f * (float)k) - my;
+  for (int k = 0; k < 3; ++k) {
+    vline[k] = ((float)qy0 - 0.5f + 4.f * (float)k) - my;
     const float vc = fminf(fmaxf(vline[k], -vmax), vmax);
     const float sq = sqrtf(fmaxf(A * Q - det * vc * vc, 0.f));
     ulo[k] = (-B * vc - sq) * iA;
     uhi[k] = (-B * vc + sq) * iA;
   }
-  const float x0 = ((float)tx0 - 0.5f) - mx;   // left edge of block column 0, relative to the splat centre
+  const float x0 = ((float)qx0 - 0.5f) - mx;   // left edge of block column 0, relative to the splat centre
   uint32_t m = 0;
 #pragma unroll
-  for (int ky = 0; ky < 4; ++ky) {
+  for (int ky = 0; ky < 2; ++ky) {
     const float v0 = vline[ky], v1 = vline[ky + 1];
     if (v0 > vmax || v1 < -vmax) continue;
     const float a = fmaxf(v0, -vmax), b = fminf(v1, vmax);
@@ -66,53 +62,39 @@ __device__ __forceinline__ uint32_t block_mask(float mx, float my, float A, floa
     xlo -= 0.02f + 1e-4f * fabsf(xlo);
     xhi += 0.02f + 1e-4f * fabsf(xhi);
 #pragma unroll
-    for (int kx = 0; kx < 4; ++kx) {
+    for (int kx = 0; kx < 2; ++kx) {
       const float L = x0 + 4.f * (float)kx;
-      if (xhi >= L && xlo <= L + 4.f) m |= 1u << (((kx >> 1) + 2 * (ky >> 1)) * 4 + ((kx & 1) + 2 * (ky & 1)));
+      if (xhi >= L && xlo <= L + 4.f) m |= 1u << (kx + 2 * ky);
     }
   }
   return m;
 }
 
-// Per-splat staging: log2-domain coefficients + the 16-bit block mask.
-struct Staged {
-  float4 a;  // mx, my, A2 = -0.5*log2e*A, B2 = -log2e*B
-  float4 b;  // C2 = -0.5*log2e*C, lo = log2(opacity), r, g
-  float c;   // b
-  uint32_t qmask;
-};
+constexpr int WB = 64;   // splats staged per wave and step
 
-__device__ __forceinline__ Staged stage_splat(const float4 g0, const float4 g1, const float g2x, int tx0, int ty0) {
-  Staged s;
-  const float A = g0.z, B = g0.w, C = g1.x, o = g1.y;
-  const float lo = __log2f(fmaxf(o, 1e-30f));
-  s.a = make_float4(g0.x, g0.y, -0.5f * LOG2E * A, -LOG2E * B);
-  s.b = make_float4(-0.5f * LOG2E * C, lo, g1.z, g1.w);
-  s.c = g2x;
-  s.qmask = block_mask(g0.x, g0.y, A, B, C, lo, tx0, ty0);
-  return s;
-}
-
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-__global__ __launch_bounds__(256, 8) void composite_fwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
-                                                            const uint32_t* __restrict__ tile_start,
-                                                            const uint32_t* __restrict__ sorted_ids,
-                                                            const float4* __restrict__ g0, const float4* __restrict__ g1,
-                                                            const float4* __restrict__ g2, float* __restrict__ image,
-                                                            float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
-  __shared__ float4 s0[CB];
-  __shared__ float4 s1[CB];
-  __shared__ float s2[CB];
-  __shared__ unsigned long long qm[16][4];  // [quadrant*4 + sub-block][staging wave]
-  const uint32_t tile = tile_order[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx0 = (tile % cam.gx) * OMFS_TILE, ty0 = (tile / cam.gx) * OMFS_TILE;
-  const int px = tx0 + (wave & 1) * 8 + (lane & 7), py = ty0 + (wave >> 1) * 8 + (lane >> 3);
+// Forward.  One 64-lane workgroup (= one wave) per (tile, 8x8 quadrant); lane l owns pixel (l&7, l>>3) of
+// the quadrant.  No workgroup barrier exists: a wave whose pixels have all saturated simply exits and
+// frees its slot, silhouette quadrants take as long as they need without holding three idle partners.
+// Per step the wave gathers 64 list entries (id -> three 16-byte records; the next step's gather is in
+// flight while this one is walked), converts them to the log2 domain, computes their 4-bit sub-block
+// masks, publishes the records in its private LDS page and turns the mask bits into four 64-bit ballots
+// held in scalar registers; it then walks ONLY the set bits (scalar bit scans) of the sub-blocks that
+// still hold an unsaturated pixel.
+__global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
+                                                           const uint32_t* __restrict__ tile_start,
+                                                           const uint32_t* __restrict__ sorted_ids,
+                                                           const float4* __restrict__ g0, const float4* __restrict__ g1,
+                                                           const float4* __restrict__ g2, float* __restrict__ image,
+                                                           float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+  __shared__ float4 s0[WB];
+  __shared__ float4 s1[WB];
+  __shared__ float s2[WB];
+  const uint32_t tile = tile_order[blockIdx.x >> 2];
+  const int quad = blockIdx.x & 3, lane = threadIdx.x;
+  const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const bool inside = px < cam.width && py < cam.height;
+  if (__ballot(inside) == 0ull) return;
   const float fx = (float)px, fy = (float)py;
   const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);  // 4x4 sub-block of this lane's pixel
@@ -122,91 +104,82 @@ __global__ __launch_bounds__(256, 8) void composite_fwd_kernel(CompCam cam, cons
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
   bool done = !inside;
-  // software pipeline: the gather of batch b+1 (id -> three 16-byte records) is in flight while batch b
-  // is walked, so a long list costs one exposed gather latency, not one per 256 splats
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
   float r2 = 0.f;
-  if (beg + tid < end) {
-    const uint32_t id = sorted_ids[beg + tid];
+  if (beg + lane < end) {
+    const uint32_t id = sorted_ids[beg + lane];
     r0 = g0[id]; r1 = g1[id]; r2 = g2[id].x;
   }
-  for (uint32_t b = beg; b < end; b += CB) {
-    unsigned long long live = __ballot(!done);
-    if (__syncthreads_and(live == 0ull)) break;
-    const uint32_t k = b + tid;
+  unsigned long long live = __ballot(!done);
+  for (uint32_t b = beg; b < end && live != 0ull; b += WB) {
+    // ---- stage this step's 64 entries
+    const uint32_t k = b + lane;
     uint32_t mask = 0;
+    __builtin_amdgcn_wave_barrier();
     if (k < end) {
-      const Staged st = stage_splat(r0, r1, r2, tx0, ty0);
-      s0[tid] = st.a; s1[tid] = st.b; s2[tid] = st.c;
-      mask = st.qmask;
+      const float A = r0.z, B = r0.w, C = r1.x;
+      const float lo = __log2f(fmaxf(r1.y, 1e-30f));
+      s0[lane] = make_float4(r0.x, r0.y, -0.5f * LOG2E * A, -LOG2E * B);
+      s1[lane] = make_float4(-0.5f * LOG2E * C, lo, r1.z, r1.w);
+      s2[lane] = r2;
+      mask = quadrant_mask(r0.x, r0.y, A, B, C, lo, qx0, qy0);
     }
+    unsigned long long ms[4];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const unsigned long long bal = __ballot((mask >> q) & 1u);
-      if (lane == 0) qm[q][wave] = bal;
-    }
-    __syncthreads();
-    if (k + CB < end) {
-      const uint32_t id = sorted_ids[k + CB];
+    for (int sb = 0; sb < 4; ++sb) ms[sb] = __ballot((mask >> sb) & 1u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (k + WB < end) {   // next step's gather, in flight during the walk
+      const uint32_t id = sorted_ids[k + WB];
       r0 = g0[id]; r1 = g1[id]; r2 = g2[id].x;
     }
-    if (live != 0ull) {
-      const uint32_t base = b - beg;
-      for (int g = 0; g < 4; ++g) {
-        unsigned long long ms[4];
+    // ---- walk: splats that can touch a sub-block which still has an unsaturated pixel
+    auto combine = [&](unsigned long long lv) {
+      unsigned long long r = 0ull;
 #pragma unroll
-        for (int sb = 0; sb < 4; ++sb) ms[sb] = uniform_u64(qm[wave * 4 + sb][g]);
-        // splats worth visiting: those that can touch a sub-block which still has an unsaturated pixel
-        auto combine = [&](unsigned long long lv) {
-          unsigned long long r = 0ull;
-#pragma unroll
-          for (int sb = 0; sb < 4; ++sb)
-            if (lv & sbl[sb]) r |= ms[sb];
-          return r;
-        };
-        unsigned long long m = combine(live);
-        if (m == 0ull) continue;
-        // LDS reads of the next splat are issued before the current one is evaluated (one wave per SIMD
-        // is the common case on the long silhouette tiles, so nothing else would hide that latency)
-        int jn = g * 64 + __builtin_ctzll(m);
-        float4 an = s0[jn], cn = s1[jn];
-        float cbn = s2[jn];
-        while (m) {
-          const int j = jn;
-          const float4 a = an;
-          const float4 c = cn;
-          const float cb = cbn;
-          m &= m - 1ull;
-          jn = g * 64 + (m ? __builtin_ctzll(m) : 0);
-          an = s0[jn]; cn = s1[jn]; cbn = s2[jn];
-          if (!done) {
-            const float dx = a.x - fx, dy = a.y - fy;
-            const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
-            const float e = p2 + c.y;
-            if (p2 <= 0.f && e >= LOG2_INV255) {
-              const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
-              const float Tn = T * (1.f - alpha);
-              if (Tn < 1e-4f) {
-                done = true;
-              } else {
-                const float w = alpha * T;
-                C0 = fma_(c.z, w, C0);
-                C1 = fma_(c.w, w, C1);
-                C2 = fma_(cb, w, C2);
-                T = Tn;
-                last = base + (uint32_t)j + 1u;
-              }
-            }
-          }
-          const unsigned long long nl = __ballot(!done);
-          if (nl != live) {
-            live = nl;
-            m &= combine(live);
-            jn = g * 64 + (m ? __builtin_ctzll(m) : 0);   // the prefetched splat may have been dropped
-            an = s0[jn]; cn = s1[jn]; cbn = s2[jn];
+      for (int sb = 0; sb < 4; ++sb)
+        if (lv & sbl[sb]) r |= ms[sb];
+      return r;
+    };
+    unsigned long long m = combine(live);
+    if (m == 0ull) continue;
+    const uint32_t base = b - beg;
+    int jn = __builtin_ctzll(m);
+    float4 an = s0[jn], cn = s1[jn];   // LDS reads of the next splat are issued before the current one is evaluated
+    float cbn = s2[jn];
+    while (m) {
+      const int j = jn;
+      const float4 a = an;
+      const float4 c = cn;
+      const float cb = cbn;
+      m &= m - 1ull;
+      jn = m ? __builtin_ctzll(m) : 0;
+      an = s0[jn]; cn = s1[jn]; cbn = s2[jn];
+      if (!done) {
+        const float dx = a.x - fx, dy = a.y - fy;
+        const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
+        const float e = p2 + c.y;
+        if (p2 <= 0.f && e >= LOG2_INV255) {
+          const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
+          const float Tn = T * (1.f - alpha);
+          if (Tn < 1e-4f) {
+            done = true;
+          } else {
+            const float w = alpha * T;
+            C0 = fma_(c.z, w, C0);
+            C1 = fma_(c.w, w, C1);
+            C2 = fma_(cb, w, C2);
+            T = Tn;
+            last = base + (uint32_t)j + 1u;
           }
         }
-        if (live == 0ull) break;
+      }
+      const unsigned long long nl = __ballot(!done);
+      if (nl != live) {
+        live = nl;
+        m &= combine(live);
+        jn = m ? __builtin_ctzll(m) : 0;   // the prefetched splat may have been dropped
+        an = s0[jn]; cn = s1[jn]; cbn = s2[jn];
       }
     }
   }
@@ -220,46 +193,38 @@ __global__ __launch_bounds__(256, 8) void composite_fwd_kernel(CompCam cam, cons
   }
 }
 
-// Backward: same mapping, list walked back to front, same masks.  Per visited splat the 64 pixel
-// contributions of a wave are reduced with DPP, the (up to four) waves that touched the splat
-// meet in LDS, and one 64-byte record per (tile, splat) is added to dsplat with float atomics:
-// 16 lanes per record, so every atomic wave-instruction covers whole 64-byte segments
-// (MI355X_MICROARCH "Global float atomics").
-__global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
-                                                            const uint32_t* __restrict__ tile_start,
-                                                            const uint32_t* __restrict__ sorted_ids,
-                                                            const float4* __restrict__ g0, const float4* __restrict__ g1,
-                                                            const float4* __restrict__ g2,
-                                                            const float* __restrict__ final_T,
-                                                            const uint32_t* __restrict__ n_contrib,
-                                                            const float* __restrict__ dimage, float* __restrict__ dsplat) {
-  __shared__ float4 s0[CB];
-  __shared__ float4 s1[CB];
-  __shared__ float2 s2[CB];   // (blue, opacity)
-  __shared__ uint32_t sid[CB];
-  __shared__ unsigned long long qm[16][4];   // [quadrant*4 + sub-block][64-group]
-  constexpr int PEND = 16;                   // reduced splats a wave parks before it flushes them
-  __shared__ float red[4][PEND][8][9];       // [wave][pending slot][8-lane group][value]: private to each wave
-  __shared__ uint32_t pend_j[4][PEND];       // batch-local index of the splat in each pending slot
-  __shared__ uint32_t s_max;
-  const uint32_t tile = tile_order[blockIdx.x];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tx0 = (tile % cam.gx) * OMFS_TILE, ty0 = (tile / cam.gx) * OMFS_TILE;
-  const int px = tx0 + (wave & 1) * 8 + (lane & 7), py = ty0 + (wave >> 1) * 8 + (lane >> 3);
-  const bool inside = px < cam.width && py < cam.height;
-  const float fx = (float)px, fy = (float)py;
+// Backward.  Same mapping (one wave per tile quadrant, no workgroup barrier), list walked back to front
+// starting at the last contributor of the quadrant's own pixels.  Per visited splat the 64 pixel
+// contributions are reduced with three DPP steps to 8 partials per value, parked in one of PEND wave-private
+// slots, and flushed 4 splats per wave-instruction: 16 lanes per 64-byte dsplat record, lane q < 9 sums the 8
+// partials of value q and adds them with one float atomic, so every atomic wave-instruction covers whole
+// 64-byte segments (MI355X_MICROARCH "Global float atomics").
+__global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
+                                                           const uint32_t* __restrict__ tile_start,
+                                                           const uint32_t* __restrict__ sorted_ids,
+                                                           const float4* __restrict__ g0, const float4* __restrict__ g1,
+                                                           const float4* __restrict__ g2, const float* __restrict__ final_T,
+                                                           const uint32_t* __restrict__ n_contrib,
+                                                           const float* __restrict__ dimage, float* __restrict__ dsplat) {
+  constexpr int PEND = 16;                // reduced splats parked before a flush
+  __shared__ float4 s0[WB];
+  __shared__ float4 s1[WB];
+  __shared__ float2 s2[WB];               // (blue, opacity)
+  __shared__ uint32_t sid[WB];
+  __shared__ float red[PEND][8][9];       // [pending slot][8-lane group][value]
+  __shared__ uint32_t pend_id[PEND];      // Gaussian id of each pending slot
+  const uint32_t tile = tile_order[blockIdx.x >> 2];
+  const int quad = blockIdx.x & 3, lane = threadIdx.x;
   const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
   if (beg == end) return;
+  const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const bool inside = px < cam.width && py < cam.height;
+  const float fx = (float)px, fy = (float)py;
   const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
   const float T_final = inside ? final_T[o] : 0.f;
   const uint32_t last = inside ? n_contrib[o] : 0u;
-  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
-  if (inside) { dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o]; }
-  float T = T_final;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;         // colour accumulated behind the current splat
-  float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;  // last alpha / colour
-  const float bgdot = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];
-  // last contributor: maxima per 4x4 sub-block, per wave and per block bound what has to be visited
+  // last contributor: maxima per 4x4 sub-block and for the quadrant bound what has to be visited
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
   uint32_t smax[4];
 #pragma unroll
@@ -269,145 +234,140 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(CompCam cam, const u
     for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
     smax[sb] = __builtin_amdgcn_readfirstlane(v);
   }
-  const uint32_t wmax = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
-  if (tid == 0) s_max = 0;
-  __syncthreads();
-  if (lane == 0) atomicMax(&s_max, wmax);
-  __syncthreads();
-  const uint32_t n_visit = s_max;
+  const uint32_t n_visit = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
   if (n_visit == 0) return;
-  const uint32_t n_batches = (n_visit + CB - 1) / CB;
-  // software pipeline as in the forward kernel: batch bi-1 is gathered while batch bi is walked
+  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
+  if (inside) { dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o]; }
+  float T = T_final;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;         // colour accumulated behind the current splat
+  float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;  // last alpha / colour
+  const float bgdot = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];
+  int n_pending = 0;
+  auto flush_pending = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < n_pending; base += 4) {
+      const int slot = base + (lane >> 4), q = lane & 15;
+      if (slot < n_pending && q < 9) {
+        const float* src = &red[slot][0][q];
+        float sum = 0.f;
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) sum += src[p8 * 9];
+        if (sum != 0.f) atomicAdd(&dsplat[(size_t)pend_id[slot] * 16 + q], sum);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  const int n_steps = (int)((n_visit + WB - 1) / WB);
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
   float r2 = 0.f;
   uint32_t rid = 0;
   {
-    const int bi0 = (int)n_batches - 1;
-    const int cnt0 = (int)min((uint32_t)CB, n_visit - (uint32_t)bi0 * CB);
-    if (tid < cnt0) {
-      rid = sorted_ids[beg + (uint32_t)bi0 * CB + tid];
+    const int cnt0 = (int)min((uint32_t)WB, n_visit - (uint32_t)(n_steps - 1) * WB);
+    if (lane < cnt0) {
+      rid = sorted_ids[beg + (uint32_t)(n_steps - 1) * WB + lane];
       r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
     }
   }
-  int n_pending = 0;
-  // wave-local flush (no workgroup barrier: the four quadrant waves run independently inside a batch):
-  // four pending splats per wave-instruction, 16 lanes per 64-byte dsplat record, lane q < 9 adds value q
-  auto flush_pending = [&]() {
-    for (int base = 0; base < n_pending; base += 4) {
-      const int slot = base + (lane >> 4), q = lane & 15;
-      if (slot < n_pending && q < 9) {
-        const float* src = &red[wave][slot][0][q];
-        float sum = 0.f;
-#pragma unroll
-        for (int p8 = 0; p8 < 8; ++p8) sum += src[p8 * 9];
-        if (sum != 0.f) atomicAdd(&dsplat[(size_t)sid[pend_j[wave][slot]] * 16 + q], sum);
-      }
-    }
-  };
-  for (int bi = (int)n_batches - 1; bi >= 0; --bi) {
-    const int cnt = (int)min((uint32_t)CB, n_visit - (uint32_t)bi * CB);
+  for (int st = n_steps - 1; st >= 0; --st) {
+    const uint32_t cbase = (uint32_t)st * WB;                       // list position of bit 0, 0-based
+    const int cnt = (int)min((uint32_t)WB, n_visit - cbase);
     uint32_t mask = 0;
-    if (tid < cnt) {
-      const Staged st = stage_splat(r0, r1, r2, tx0, ty0);
-      sid[tid] = rid;
-      s0[tid] = st.a; s1[tid] = st.b; s2[tid] = make_float2(st.c, r1.y);
-      mask = st.qmask;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cnt) {
+      const float A = r0.z, B = r0.w, C = r1.x;
+      const float lo = __log2f(fmaxf(r1.y, 1e-30f));
+      s0[lane] = make_float4(r0.x, r0.y, -0.5f * LOG2E * A, -LOG2E * B);
+      s1[lane] = make_float4(-0.5f * LOG2E * C, lo, r1.z, r1.w);
+      s2[lane] = make_float2(r2, r1.y);
+      sid[lane] = rid;
+      mask = quadrant_mask(r0.x, r0.y, A, B, C, lo, qx0, qy0);
     }
+    // splats worth visiting: can touch a sub-block one of whose pixels has its last contributor at or
+    // behind the splat (list position <= that sub-block's maximum)
+    unsigned long long m = 0ull;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const unsigned long long bal = __ballot((mask >> q) & 1u);
-      if (lane == 0) qm[q][wave] = bal;
+    for (int sb = 0; sb < 4; ++sb) {
+      const unsigned long long bal = __ballot((mask >> sb) & 1u);
+      if (smax[sb] > cbase) {
+        const uint32_t lim = smax[sb] - cbase;
+        m |= bal & (lim >= 64u ? ~0ull : ((1ull << lim) - 1ull));
+      }
     }
-    __syncthreads();
-    if (bi > 0) {   // every earlier batch is full
-      rid = sorted_ids[beg + (uint32_t)(bi - 1) * CB + tid];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (st > 0) {   // every earlier step is full
+      rid = sorted_ids[beg + cbase - WB + lane];
       r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
     }
-    for (int g = (cnt - 1) / 64; g >= 0; --g) {
-      const uint32_t cbase = (uint32_t)bi * CB + (uint32_t)g * 64u;  // list position of bit 0, 0-based
-      // splats worth visiting: can touch a sub-block one of whose pixels has its last contributor at or
-      // behind the splat (list position <= that sub-block's maximum)
-      unsigned long long m = 0ull;
+    int jbn = m ? 63 - __builtin_clzll(m) : 0;
+    float4 an = s0[jbn], cn = s1[jbn];
+    float2 cbn = s2[jbn];
+    while (m) {
+      const int jb = jbn;
+      m &= ~(1ull << jb);
+      const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
+      float v[9];
 #pragma unroll
-      for (int sb = 0; sb < 4; ++sb) {
-        if (smax[sb] > cbase) {
-          const uint32_t lim = smax[sb] - cbase;
-          const unsigned long long keep = lim >= 64u ? ~0ull : ((1ull << lim) - 1ull);
-          m |= uniform_u64(qm[wave * 4 + sb][g]) & keep;
+      for (int q = 0; q < 9; ++q) v[q] = 0.f;
+      const float4 a = an;
+      const float4 c = cn;
+      const float2 cb = cbn;
+      jbn = m ? 63 - __builtin_clzll(m) : 0;   // prefetch the next splat's record
+      an = s0[jbn]; cn = s1[jbn]; cbn = s2[jbn];
+      bool hit = false;
+      if (contributor <= last) {
+        const float dx = a.x - fx, dy = a.y - fy;
+        const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
+        const float e = p2 + c.y;
+        if (p2 <= 0.f && e >= LOG2_INV255) {
+          hit = true;
+          const float G = __builtin_amdgcn_exp2f(p2);
+          const float oG = cb.y * G;                              // opacity * G
+          const float alpha = fminf(0.99f, oG);
+          const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
+          T = T * r1a;
+          const float w = alpha * T;
+          v[6] = w * dL0; v[7] = w * dL1; v[8] = w * dL2;  // dL/dcolour
+          acc0 = fma_(la, lc0, (1.f - la) * acc0);
+          acc1 = fma_(la, lc1, (1.f - la) * acc1);
+          acc2 = fma_(la, lc2, (1.f - la) * acc2);
+          lc0 = c.z; lc1 = c.w; lc2 = cb.x; la = alpha;
+          float dLa = (c.z - acc0) * dL0 + (c.w - acc1) * dL1 + (cb.x - acc2) * dL2;
+          dLa = fma_(dLa, T, -(T_final * r1a) * bgdot);
+          // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream
+          // rasteriser does (DESIGN.md "Frozen conventions").  With A2 = -0.5 log2e A etc.:
+          //   dG/ddx = -G (A dx + B dy) = G (2 A2 dx + B2 dy) / log2e
+          const float gL = oG * dLa;                     // dL/dG * G  (opacity folded in)
+          const float gs = gL * (1.f / LOG2E);
+          v[0] = gs * fma_(2.f * a.z, dx, a.w * dy);      // d mean2d.x (dx = mean - pixel)
+          v[1] = gs * fma_(2.f * c.x, dy, a.w * dx);      // d mean2d.y
+          const float hx = -0.5f * gL * dx;
+          v[2] = hx * dx;                                 // d conic.a
+          v[3] = 2.f * hx * dy;                           // d conic.b (B multiplies dx*dy once)
+          v[4] = -0.5f * gL * dy * dy;                    // d conic.c
+          v[5] = G * dLa;                                 // d opacity
         }
       }
-      int jbn = m ? 63 - __builtin_clzll(m) : 0;
-      float4 an = s0[g * 64 + jbn], cn = s1[g * 64 + jbn];
-      float2 cbn = s2[g * 64 + jbn];
-      while (m) {
-        const int jb = jbn;
-        m &= ~(1ull << jb);
-        const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
-        float v[9];
+      if (__ballot(hit) == 0ull) continue;  // nobody in this quadrant was touched: nothing to reduce
 #pragma unroll
-        for (int q = 0; q < 9; ++q) v[q] = 0.f;
-        const float4 a = an;
-        const float4 c = cn;
-        const float2 cb = cbn;                   // (blue, opacity)
-        jbn = m ? 63 - __builtin_clzll(m) : 0;   // prefetch the next splat's record
-        an = s0[g * 64 + jbn]; cn = s1[g * 64 + jbn]; cbn = s2[g * 64 + jbn];
-        bool hit = false;
-        if (contributor <= last) {
-          const float dx = a.x - fx, dy = a.y - fy;
-          const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
-          const float e = p2 + c.y;
-          if (p2 <= 0.f && e >= LOG2_INV255) {
-            hit = true;
-            const float G = __builtin_amdgcn_exp2f(p2);
-            const float oG = cb.y * G;                              // opacity * G
-            const float alpha = fminf(0.99f, oG);
-            const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
-            T = T * r1a;
-            const float w = alpha * T;
-            v[6] = w * dL0; v[7] = w * dL1; v[8] = w * dL2;  // dL/dcolour
-            acc0 = fma_(la, lc0, (1.f - la) * acc0);
-            acc1 = fma_(la, lc1, (1.f - la) * acc1);
-            acc2 = fma_(la, lc2, (1.f - la) * acc2);
-            lc0 = c.z; lc1 = c.w; lc2 = cb.x; la = alpha;
-            float dLa = (c.z - acc0) * dL0 + (c.w - acc1) * dL1 + (cb.x - acc2) * dL2;
-            dLa = fma_(dLa, T, -(T_final * r1a) * bgdot);
-            // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream
-            // rasteriser does (DESIGN.md "Frozen conventions").  With A2 = -0.5 log2e A etc.:
-            //   dG/ddx = -G (A dx + B dy) = G (2 A2 dx + B2 dy) / log2e
-            const float gL = oG * dLa;                     // dL/dG * G  (opacity folded in)
-            const float gs = gL * (1.f / LOG2E);
-            v[0] = gs * fma_(2.f * a.z, dx, a.w * dy);      // d mean2d.x (dx = mean - pixel)
-            v[1] = gs * fma_(2.f * c.x, dy, a.w * dx);      // d mean2d.y
-            const float hx = -0.5f * gL * dx;
-            v[2] = hx * dx;                                 // d conic.a
-            v[3] = 2.f * hx * dy;                           // d conic.b (B multiplies dx*dy once)
-            v[4] = -0.5f * gL * dy * dy;                    // d conic.c
-            v[5] = G * dLa;                                 // d opacity
-          }
-        }
-        if (__ballot(hit) == 0ull) continue;  // nobody in this quadrant was touched: nothing to reduce
-        // partial reduction: three DPP steps leave the sums of 8-lane groups in lanes 7, 15, ..., 63; the
-        // 8 partials per value go to this wave's pending slot and are summed by the flush
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          float x = v[q];
-          x += dpp_mov<0x111>(x);  // row_shr:1
-          x += dpp_mov<0x112>(x);  // row_shr:2
-          x += dpp_mov<0x114>(x);  // row_shr:4
-          v[q] = x;
-        }
-        if ((lane & 7) == 7) {
-          float* dst = &red[wave][n_pending][lane >> 3][0];
-#pragma unroll
-          for (int q = 0; q < 9; ++q) dst[q] = v[q];
-        }
-        if (lane == 0) pend_j[wave][n_pending] = (uint32_t)(g * 64 + jb);
-        if (++n_pending == PEND) { flush_pending(); n_pending = 0; }
+      for (int q = 0; q < 9; ++q) {
+        float x = v[q];
+        x += dpp_mov<0x111>(x);  // row_shr:1
+        x += dpp_mov<0x112>(x);  // row_shr:2
+        x += dpp_mov<0x114>(x);  // row_shr:4  -> lanes 7, 15, ..., 63 hold the sums of their 8-lane groups
+        v[q] = x;
       }
+      if ((lane & 7) == 7) {
+        float* dst = &red[n_pending][lane >> 3][0];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) dst[q] = v[q];
+      }
+      if (lane == 0) pend_id[n_pending] = sid[jb];
+      if (++n_pending == PEND) { flush_pending(); n_pending = 0; }
     }
-    if (n_pending) { flush_pending(); n_pending = 0; }
-    __syncthreads();   // every wave is done with this batch's LDS before it is restaged
   }
+  if (n_pending) flush_pending();
 }
 
 __global__ void image_to_rgb8_kernel(const float* __restrict__ image, int width, int height, uint8_t* __restrict__ rgb8) {
@@ -438,7 +398,7 @@ extern "C" int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buff
                    rb->final_T && rb->n_contrib, "raster buffers");
   CompCam cc = make_compcam(cam);
   const int n_tiles = cc.gx * cdiv(cam->height, OMFS_TILE);
-  hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, cc, rb->tile_order,
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_tiles * 4), dim3(64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
                      (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib);
   OMFS_CHECK_HIP(hipGetLastError());
@@ -452,7 +412,7 @@ extern "C" int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buff
                    rb->n_contrib && gb->dimage && gb->dsplat, "buffers");
   CompCam cc = make_compcam(cam);
   const int n_tiles = cc.gx * cdiv(cam->height, OMFS_TILE);
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, cc, rb->tile_order,
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_tiles * 4), dim3(64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
                      (const float4*)rb->g2, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat);
   OMFS_CHECK_HIP(hipGetLastError());
