@@ -125,11 +125,17 @@ def main():
     if not torch.cuda.is_available():
         print(json.dumps({"error": "bench.py needs a GPU (MI355X); no CPU fallback exists"}))
         sys.exit(2)
-    torch.cuda.set_device(local_rank)
+    # one process per GPU; OMFS_DIST_BACKEND=gloo lets several ranks share one card (functional rehearsal only)
+    backend = os.environ.get("OMFS_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
     pg = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
@@ -277,6 +283,9 @@ def main():
                       f"(D={D_s} tile pairs) took {sec:.2f} s; value extrapolated to the bench workload by the "
                       f"tile-pair ratio D_sample/D = {scale:.5f}",
             "sample_seconds": round(sec, 3)}
+    if world > 1:
+        from omfs_4d_video_gen_amd.engine.distributed import replicas_in_sync
+        out["replicas_in_sync"] = replicas_in_sync(trainer.model.params)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -79,11 +79,16 @@ def main(argv=None):
     if not torch.cuda.is_available():
         raise SystemExit("[engine] no GPU visible: the engine has no CPU path")
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     pg = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("OMFS_DIST_BACKEND", "nccl")   # gloo: functional rehearsal with ranks sharing a card
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     split = IO.load_split(args.source_path, "train")

@@ -25,7 +25,7 @@ STAGES = ("flame", "project", "bin_count", "bin_scan", "bin_scatter", "tile_sort
           "project_bwd", "allreduce", "adam")
 
 
-@dataclass
+@dataclass(eq=False)
 class View:
     camera: dict          # synthetic.make_camera / dataset.camera_from_frame schema
     timestep: int
