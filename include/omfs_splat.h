@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMFS_ABI_VERSION 1
+#define OMFS_ABI_VERSION 2
 #define OMFS_TILE 16
 #define OMFS_NPLANES 59
 #define OMFS_P_XYZ 0      /* 3 planes: local position in the parent triangle frame          */
@@ -171,6 +171,8 @@ typedef struct omfs_grad_buffers {
                              dmean2d.xy, dconic.abc, dopacity, drgb, |dmean2d| ... ; caller zeroes */
   float* grads;           /* [59][n_pad] parameter gradients (overwritten)                         */
   const float* dimage;    /* [3][H][W] dL/dimage                                                   */
+  float* densify_stats;   /* optional [2][n_pad]: += |d mean2d| in NDC-scaled units (x W/2, y H/2) and += 1
+                             for every Gaussian visible in this view (adaptive density control); may be NULL */
 } omfs_grad_buffers;
 
 int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, const omfs_grad_buffers* gb, void* stream);

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see module d
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 NPLANES = 59
 TILE = 16
 
@@ -58,7 +58,7 @@ class RasterBuffersC(C.Structure):
 
 
 class GradBuffersC(C.Structure):
-    _fields_ = [("dsplat", c_void_p), ("grads", c_void_p), ("dimage", c_void_p)]
+    _fields_ = [("dsplat", c_void_p), ("grads", c_void_p), ("dimage", c_void_p), ("densify_stats", c_void_p)]
 
 
 class RegParamsC(C.Structure):

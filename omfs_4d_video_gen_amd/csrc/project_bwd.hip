@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
                                                           const float4* __restrict__ g2,
                                                           const float4* __restrict__ dsplat, RegK reg,
                                                           const uint32_t* __restrict__ n_visible,
-                                                          float* __restrict__ grads) {
+                                                          float* __restrict__ grads, float* __restrict__ densify_stats,
+                                                          float half_w, float half_h) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   auto P = [&](int plane) { return params[(size_t)plane * n_pad + i]; };
@@ -44,6 +45,11 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
   const uint32_t clampbits = rbits >> 28;
   const float4 d0 = dsplat[(size_t)i * 4 + 0], d1 = dsplat[(size_t)i * 4 + 1], d2 = dsplat[(size_t)i * 4 + 2];
   const float dpx = d0.x, dpy = d0.y, dA = d0.z, dB = d0.w, dC = d1.x, dop = d1.y;
+  if (densify_stats) {   // adaptive density control statistics
+    const float gx = dpx * half_w, gy = dpy * half_h;
+    densify_stats[i] += sqrtf(gx * gx + gy * gy);
+    densify_stats[(size_t)n_pad + i] += 1.f;
+  }
   float drgb[3] = {d1.z, d1.w, d2.x};
 
   const float4* fr = reinterpret_cast<const float4*>(face_xf) + (size_t)binding[i] * 4;
@@ -239,7 +245,7 @@ extern "C" int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, c
   RegK rk{reg->lambda_xyz, reg->thr_xyz, reg->lambda_scale, reg->thr_scale};
   hipLaunchKernelGGL(project_bwd_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, (hipStream_t)stream, g->n, g->n_pad,
                      g->params, g->binding, face_xf, pc, (const float4*)rb->g2, (const float4*)gb->dsplat, rk,
-                     reg->n_visible, gb->grads);
+                     reg->n_visible, gb->grads, gb->densify_stats, 0.5f * (float)cam->width, 0.5f * (float)cam->height);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

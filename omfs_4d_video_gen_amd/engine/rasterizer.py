@@ -35,8 +35,13 @@ def make_camera_struct(cam: dict, sh_degree: int = 3, bg=(0.0, 0.0, 0.0)) -> L.C
 
 class Rasterizer:
     def __init__(self, n: int, width: int, height: int, device="cuda", dup_capacity: int | None = None,
-                 sort_lds_pairs: int = 0):
+                 sort_lds_pairs: int = 0, n_capacity: int | None = None):
+        """n_capacity: per-Gaussian buffers are sized for this many Gaussians (densification grows N)."""
         self.device = torch.device(device)
+        self.n_capacity = int(n_capacity if n_capacity else n)
+        if n > self.n_capacity:
+            raise ValueError("n exceeds n_capacity")
+        n = self.n_capacity
         self.n, self.width, self.height = int(n), int(width), int(height)
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
         self.n_tiles = self.gx * self.gy
@@ -71,8 +76,9 @@ class Rasterizer:
 
     # ------------------------------------------------------------------ forward
     def _gauss(self, model: GaussianModel) -> L.GaussiansC:
-        if model.n != self.n:
-            raise ValueError(f"rasterizer was sized for {self.n} Gaussians, model has {model.n}")
+        if model.n > self.n_capacity:
+            raise ValueError(f"rasterizer was sized for {self.n_capacity} Gaussians, model has {model.n}")
+        self.n = model.n
         return L.GaussiansC(model.n, model.n_pad, L.ptr(model.params), L.ptr(model.binding))
 
     def project(self, model: GaussianModel, face_xf: torch.Tensor, cam: L.CameraC):
@@ -113,7 +119,7 @@ class Rasterizer:
     def _ensure_bwd(self):
         if self.dsplat is None:
             dev = self.device
-            self.dsplat = torch.zeros(self.n, 16, device=dev)
+            self.dsplat = torch.zeros(self.n_capacity, 16, device=dev)
             self.dimage = torch.zeros(3, self.height, self.width, device=dev)
             self.loss = torch.zeros(1, device=dev)
             self.loss_scratch = torch.zeros(3, 3, self.height, self.width, device=dev)
@@ -140,7 +146,7 @@ class Rasterizer:
         if grads.shape != (NPLANES, model.n_pad) or grads.dtype != torch.float32 or not grads.is_contiguous():
             raise ValueError("grads must be a contiguous float32 [59][n_pad] tensor")
         self.dsplat.zero_()
-        gb = L.GradBuffersC(L.ptr(self.dsplat), L.ptr(grads), L.ptr(dimg))
+        gb = L.GradBuffersC(L.ptr(self.dsplat), L.ptr(grads), L.ptr(dimg), 0)
         L.check(lib.omfs_composite_bwd(cam, self.rb, gb, s), "omfs_composite_bwd")
         L.check(lib.omfs_count_visible(self.rb, self.n, L.ptr(self.n_visible), s), "omfs_count_visible")
         rp = L.RegParamsC(float(reg[0]), float(reg[1]), float(reg[2]), float(reg[3]), L.ptr(self.n_visible))

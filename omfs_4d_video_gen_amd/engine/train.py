@@ -9,7 +9,7 @@ Outputs (what `render_surgery.py:271-287` and `train_ghost.py:141-156` look for)
   M/point_cloud/iteration_<it>/point_cloud.ply (+ flame_param.npz), M/chkpnt<it>.pth, M/cfg_args.json.
 Progress lines contain "iteration <n>" for the UI regex (`app.py:1387-1398`).
 Multi-GPU: launch with torch.distributed.run; views shard across ranks, gradients are all-reduced.
-Not implemented this round: adaptive density control, FLAME fine-tuning.
+Not implemented this round: FLAME fine-tuning, resume from a checkpoint.
 """
 from __future__ import annotations
 
@@ -41,6 +41,14 @@ def parse(argv=None):
     p.add_argument("--sh_degree", type=int, default=3)
     p.add_argument("--n_gaussians", type=int, default=0, help="fixed Gaussian count (0 = 10 per triangle)")
     p.add_argument("--seed", type=int, default=0)
+    # adaptive density control, GaussianAvatars' schedule
+    p.add_argument("--densify_from_iter", type=int, default=10000)
+    p.add_argument("--densify_until_iter", type=int, default=600000)
+    p.add_argument("--densification_interval", type=int, default=2000)
+    p.add_argument("--densify_grad_threshold", type=float, default=2e-4)
+    p.add_argument("--opacity_reset_interval", type=int, default=60000)
+    p.add_argument("--max_gaussians", type=int, default=0, help="capacity for densification (0 = 4x the initial count)")
+    p.add_argument("--no_densify", action="store_true")
     p.add_argument("--log_every", type=int, default=100)
     args, unknown = p.parse_known_args(argv)
     if unknown:
@@ -124,8 +132,17 @@ def main(argv=None):
         views.append(View(cam, int(trow), target=rgb.cuda(), name=os.path.basename(fr["file_path"])))
     n = args.n_gaussians if args.n_gaussians > 0 else 10 * rig.n_faces
     g0 = initial_gaussians(n, rig.n_faces, args.seed)
+    densify = not args.no_densify and args.iterations > args.densify_from_iter
+    cap = (args.max_gaussians if args.max_gaussians > 0 else 4 * n) if densify else n
     trainer = Trainer(rig, split["flame"], g0, views, size[0], size[1], bg=bg, iterations=args.iterations,
-                      sh_degree_max=args.sh_degree, start_sh_degree=0, rank=rank, world_size=world, process_group=pg)
+                      sh_degree_max=args.sh_degree, start_sh_degree=0, rank=rank, world_size=world, process_group=pg,
+                      n_capacity=cap)
+    controller = None
+    if densify:
+        from omfs_4d_video_gen_amd.engine.densify import DensityController, scene_extent
+        controller = DensityController(trainer, scene_extent(views), args.densify_from_iter, args.densify_until_iter,
+                                       args.densification_interval, args.densify_grad_threshold,
+                                       opacity_reset_interval=args.opacity_reset_interval, max_gaussians=cap, seed=args.seed)
 
     out = Path(args.model_path)
     if rank == 0:
@@ -136,6 +153,11 @@ def main(argv=None):
     t0 = time.time()
     for it in range(1, args.iterations + 1):
         trainer.step()
+        if controller is not None:
+            n_before = trainer.model.n
+            controller.after_step(it)
+            if rank == 0 and trainer.model.n != n_before:
+                print(f"[ITER {it}] densify: {controller.log[-1]}", flush=True)
         if it % args.log_every == 0 or it == args.iterations:
             if rank == 0:
                 print(f"Training progress: iteration {it}/{args.iterations} loss={trainer.loss_value():.5f} "

@@ -75,13 +75,14 @@ class Trainer:
                  bg=(0.0, 0.0, 0.0), device="cuda", iterations: int = 30000, lambda_dssim: float = 0.2,
                  reg=(0.01, 1.0, 1.0, 0.6), position_lr_init=5e-3, position_lr_final=5e-5,
                  sh_degree_max: int = 3, sh_increase_every: int = 1000, start_sh_degree: int = 0,
-                 dup_capacity: int | None = None, rank: int = 0, world_size: int = 1, process_group=None):
+                 dup_capacity: int | None = None, rank: int = 0, world_size: int = 1, process_group=None,
+                 n_capacity: int | None = None):
         self.device = torch.device(device)
         self.rank, self.world = rank, world_size
         self.pg = process_group
         self.dflame = DeviceFlame(rig, flame_params, device=device)
         self.model = GaussianModel(gaussians, device=device)
-        self.rast = Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity)
+        self.rast = Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity, n_capacity=n_capacity)
         self.rast._ensure_bwd()
         self.views = views
         self.bg = tuple(bg)
@@ -96,6 +97,7 @@ class Trainer:
         self.step_idx = 0
         self.timer = StageTimer(False)
         self._cams = {}
+        self.densify_stats = None      # [2][n_pad] when adaptive density control is on (engine/densify.py)
 
     def _cam(self, view: View, sh_degree: int):
         key = (id(view), sh_degree)
@@ -134,7 +136,7 @@ class Trainer:
         r.loss.zero_()
         r.loss_l1_ssim(view.target, self.lambda_dssim); tm.mark("loss")
         r.dsplat.zero_()
-        gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage))
+        gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats))
         L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")
         L.check(lib.omfs_count_visible(r.rb, r.n, L.ptr(r.n_visible), s), "omfs_count_visible")
         rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
