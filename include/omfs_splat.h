@@ -31,6 +31,7 @@ extern "C" {
 
 #define OMFS_ABI_VERSION 2
 #define OMFS_TILE 16
+#define OMFS_SEG 128     /* list entries per backward segment                                          */
 #define OMFS_NPLANES 59
 #define OMFS_P_XYZ 0      /* 3 planes: local position in the parent triangle frame          */
 #define OMFS_P_SCALE 3    /* 3 planes: log scale (triangle-relative)                         */
@@ -140,6 +141,11 @@ typedef struct omfs_raster_buffers {
   uint32_t sort_lds_pairs; /* longest tile list sorted inside LDS (0 = default 8960 pairs = 160 KB; 16 B of LDS
                               each); longer lists are sorted through keys/keys_tmp in global memory */
   uint32_t* status;       /* [1] OMFS_STATUS_* bits, OR-ed by kernels (caller zeroes)            */
+  /* forward checkpoints for the depth-parallel backward pass: per pixel (T, C.rgb) on entering list segment k
+   * (k >= 1) of tile t, stored at slot tile_start[t]/OMFS_SEG + t + k; seg_capacity >= n_tiles + dup_capacity/OMFS_SEG */
+  float* seg_ckpt;        /* [seg_capacity][256][4]                                               */
+  uint32_t* order_seg0;   /* [n_tiles+1] segments owned by the tiles before each launch-order position     */
+  uint32_t seg_capacity;
   /* per pixel */
   float* image;           /* [3][height][width]                                                  */
   float* final_T;         /* [height][width]                                                     */

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
 ABI_VERSION = 2
 NPLANES = 59
 TILE = 16
+SEG = 128
 
 c_float_p = C.POINTER(C.c_float)
 c_u32_p = C.POINTER(C.c_uint32)
@@ -54,6 +55,7 @@ class RasterBuffersC(C.Structure):
                 ("tile_count", c_void_p), ("tile_start", c_void_p), ("tile_cursor", c_void_p),
                 ("tile_order", c_void_p), ("keys", c_void_p), ("keys_tmp", c_void_p), ("sorted_ids", c_void_p),
                 ("dup_capacity", C.c_uint32), ("sort_lds_pairs", C.c_uint32), ("status", c_void_p),
+                ("seg_ckpt", c_void_p), ("order_seg0", c_void_p), ("seg_capacity", C.c_uint32),
                 ("image", c_void_p), ("final_T", c_void_p), ("n_contrib", c_void_p)]
 
 

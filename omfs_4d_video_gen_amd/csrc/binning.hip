@@ -18,7 +18,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
                                                          uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ tile_cursor,
                                                          uint32_t* __restrict__ tile_order, uint32_t dup_capacity,
-                                                         uint32_t* __restrict__ status) {
+                                                         uint32_t* __restrict__ status, uint32_t* __restrict__ order_seg0) {
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t bucket_cnt[33];
   __shared__ uint32_t bucket_off[33];
@@ -64,6 +64,27 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
     uint32_t pos = atomicAdd(&bucket_off[32 - bucket], 1u);
     tile_order[pos] = (uint32_t)t;
   }
+  // ---- backward segments: order_seg0[p] = number of OMFS_SEG-entry list segments owned by the tiles before
+  // position p of the launch order (heavy tiles first); order_seg0[n_tiles] = total.  The backward pass
+  // launches one wave per (segment, quadrant) and finds its tile by bisection in this array.
+  __syncthreads();
+  uint32_t ssum = 0;
+  for (int p = beg; p < end; ++p) ssum += (tile_count[tile_order[p]] + OMFS_SEG - 1) / OMFS_SEG;
+  const uint32_t sincl = wave_incl_scan_u32(ssum, lane);
+  if (lane == 63) wave_tot[wave] = sincl;
+  __syncthreads();
+  uint32_t sbase = 0, stotal = 0;
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t v = wave_tot[w];
+    if (w < wave) sbase += v;
+    stotal += v;
+  }
+  uint32_t srun = sbase + sincl - ssum;
+  for (int p = beg; p < end; ++p) {
+    order_seg0[p] = srun;
+    srun += (tile_count[tile_order[p]] + OMFS_SEG - 1) / OMFS_SEG;
+  }
+  if (tid == 0) order_seg0[n_tiles] = stotal;
 }
 
 // ------------------------------------------------------------------ count + key scatter
@@ -318,8 +339,9 @@ extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, c
 extern "C" int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
   if (int rc = check_bin_args(cam, rb)) return rc;
   const int n_tiles = cdiv(cam->width, OMFS_TILE) * cdiv(cam->height, OMFS_TILE);
+  OMFS_REQUIRE(rb->order_seg0, "order_seg0");
   hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles, rb->tile_count,
-                     rb->tile_start, rb->tile_cursor, rb->tile_order, rb->dup_capacity, rb->status);
+                     rb->tile_start, rb->tile_cursor, rb->tile_order, rb->dup_capacity, rb->status, rb->order_seg0);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -85,7 +85,8 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
                                                            const uint32_t* __restrict__ sorted_ids,
                                                            const float4* __restrict__ g0, const float4* __restrict__ g1,
                                                            const float4* __restrict__ g2, float* __restrict__ image,
-                                                           float* __restrict__ final_T, uint32_t* __restrict__ n_contrib) {
+                                                           float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                                                           float4* __restrict__ seg_ckpt) {
   __shared__ float4 s0[WB];
   __shared__ float4 s1[WB];
   __shared__ float s2[WB];
@@ -112,6 +113,9 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
   }
   unsigned long long live = __ballot(!done);
   for (uint32_t b = beg; b < end && live != 0ull; b += WB) {
+    // entering a new segment: checkpoint (T, C) so the backward pass can start there (see composite_bwd_kernel)
+    if (b != beg && ((b - beg) & (OMFS_SEG - 1)) == 0u)
+      seg_ckpt[((size_t)(beg / OMFS_SEG) + tile + (b - beg) / OMFS_SEG) * 256 + quad * 64 + lane] = make_float4(T, C0, C1, C2);
     // ---- stage this step's 64 entries
     const uint32_t k = b + lane;
     uint32_t mask = 0;
@@ -193,17 +197,22 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
   }
 }
 
-// Backward.  Same mapping (one wave per tile quadrant, no workgroup barrier), list walked back to front
-// starting at the last contributor of the quadrant's own pixels.  Per visited splat the 64 pixel
-// contributions are reduced with three DPP steps to 8 partials per value, parked in one of PEND wave-private
-// slots, and flushed 4 splats per wave-instruction: 16 lanes per 64-byte dsplat record, lane q < 9 sums the 8
-// partials of value q and adds them with one float atomic, so every atomic wave-instruction covers whole
-// 64-byte segments (MI355X_MICROARCH "Global float atomics").
-__global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
+// Backward.  One wave per (OMFS_SEG-entry list segment, quadrant), no workgroup barrier: the serial depth
+// of a silhouette quadrant is bounded by the segment length.  A pixel whose last contributor lies behind this
+// segment enters it with the (T, C) the forward pass checkpointed at the next segment's start: T directly,
+// and the colour behind the boundary as (C_final - C_checkpoint) / T.  The segment is walked back to front;
+// per visited splat the 64 pixel contributions are reduced with three DPP steps to 8 partials per value,
+// parked in one of PEND wave-private slots, and flushed 4 splats per wave-instruction: 16 lanes per 64-byte
+// dsplat record, lane q < 9 sums the 8 partials of value q and adds them with one float atomic, so every
+// atomic wave-instruction covers whole 64-byte segments (MI355X_MICROARCH "Global float atomics").
+__global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order,
+                                                           const uint32_t* __restrict__ order_seg0,
+                                                           const float4* __restrict__ seg_ckpt,
                                                            const uint32_t* __restrict__ tile_start,
                                                            const uint32_t* __restrict__ sorted_ids,
                                                            const float4* __restrict__ g0, const float4* __restrict__ g1,
-                                                           const float4* __restrict__ g2, const float* __restrict__ final_T,
+                                                           const float4* __restrict__ g2, const float* __restrict__ image,
+                                                           const float* __restrict__ final_T,
                                                            const uint32_t* __restrict__ n_contrib,
                                                            const float* __restrict__ dimage, float* __restrict__ dsplat) {
   constexpr int PEND = 16;                // reduced splats parked before a flush
@@ -213,17 +222,33 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, const ui
   __shared__ uint32_t sid[WB];
   __shared__ float red[PEND][8][9];       // [pending slot][8-lane group][value]
   __shared__ uint32_t pend_id[PEND];      // Gaussian id of each pending slot
-  const uint32_t tile = tile_order[blockIdx.x >> 2];
+  const uint32_t seg = blockIdx.x >> 2;
+  if (seg >= order_seg0[n_tiles]) return;
+  // launch-order position p with order_seg0[p] <= seg < order_seg0[p+1] (bisection, ~13 L2-resident loads)
+  int lo = 0, hi = n_tiles;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (order_seg0[mid] <= seg) lo = mid; else hi = mid;
+  }
+  const uint32_t tile = tile_order[lo], kseg = seg - order_seg0[lo];
   const int quad = blockIdx.x & 3, lane = threadIdx.x;
-  const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
-  if (beg == end) return;
+  const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
   const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const bool inside = px < cam.width && py < cam.height;
   const float fx = (float)px, fy = (float)py;
   const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
   const float T_final = inside ? final_T[o] : 0.f;
-  const uint32_t last = inside ? n_contrib[o] : 0u;
+  const uint32_t last_g = inside ? n_contrib[o] : 0u;     // tile-wide, 1-based
+  if (__ballot(last_g > kseg * OMFS_SEG) == 0ull) return;   // nothing of this quadrant reaches this segment
+  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f, Cf0 = 0.f, Cf1 = 0.f, Cf2 = 0.f;
+  if (inside) {
+    dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
+    Cf0 = image[o] - T_final * cam.bg[0]; Cf1 = image[plane + o] - T_final * cam.bg[1]; Cf2 = image[2 * plane + o] - T_final * cam.bg[2];
+  }
+  const float bgdot = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];
+  const uint32_t beg = tbeg + kseg * OMFS_SEG, seg_len = min(tend, beg + OMFS_SEG) - beg;
+  const uint32_t last = last_g > kseg * OMFS_SEG ? min(last_g - kseg * OMFS_SEG, seg_len) : 0u;  // segment-local
   // last contributor: maxima per 4x4 sub-block and for the quadrant bound what has to be visited
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
   uint32_t smax[4];
@@ -236,12 +261,17 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, const ui
   }
   const uint32_t n_visit = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
   if (n_visit == 0) return;
-  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f;
-  if (inside) { dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o]; }
   float T = T_final;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;         // colour accumulated behind the current splat
   float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;  // last alpha / colour
-  const float bgdot = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];
+  if (last_g > (kseg + 1) * OMFS_SEG) {             // the pixel goes on behind this segment
+    const float4 ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
+    const float inv = __builtin_amdgcn_rcpf(ck.x);
+    T = ck.x;
+    acc0 = (Cf0 - ck.y) * inv;
+    acc1 = (Cf1 - ck.z) * inv;
+    acc2 = (Cf2 - ck.w) * inv;
+  }
   int n_pending = 0;
   auto flush_pending = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -395,12 +425,13 @@ using namespace omfs;
 extern "C" int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
   OMFS_REQUIRE(cam && rb, "null pointer");
   OMFS_REQUIRE(rb->g0 && rb->g1 && rb->g2 && rb->tile_order && rb->tile_start && rb->sorted_ids && rb->image &&
-                   rb->final_T && rb->n_contrib, "raster buffers");
+                   rb->final_T && rb->n_contrib && rb->seg_ckpt, "raster buffers");
   CompCam cc = make_compcam(cam);
   const int n_tiles = cc.gx * cdiv(cam->height, OMFS_TILE);
+  OMFS_REQUIRE(rb->seg_capacity >= (uint32_t)n_tiles + rb->dup_capacity / OMFS_SEG, "seg_capacity < n_tiles + dup_capacity/OMFS_SEG");
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_tiles * 4), dim3(64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
-                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib);
+                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
@@ -408,13 +439,16 @@ extern "C" int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buff
 extern "C" int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, const omfs_grad_buffers* gb,
                                   void* stream) {
   OMFS_REQUIRE(cam && rb && gb, "null pointer");
-  OMFS_REQUIRE(rb->g0 && rb->g1 && rb->g2 && rb->tile_order && rb->tile_start && rb->sorted_ids && rb->final_T &&
-                   rb->n_contrib && gb->dimage && gb->dsplat, "buffers");
+  OMFS_REQUIRE(rb->g0 && rb->g1 && rb->g2 && rb->tile_order && rb->tile_start && rb->sorted_ids && rb->image &&
+                   rb->final_T && rb->n_contrib && rb->seg_ckpt && gb->dimage && gb->dsplat, "buffers");
   CompCam cc = make_compcam(cam);
   const int n_tiles = cc.gx * cdiv(cam->height, OMFS_TILE);
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3(n_tiles * 4), dim3(64), 0, (hipStream_t)stream, cc, rb->tile_order,
-                     rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
-                     (const float4*)rb->g2, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat);
+  OMFS_REQUIRE(rb->order_seg0 && rb->seg_capacity >= (uint32_t)n_tiles + rb->dup_capacity / OMFS_SEG, "segment buffers");
+  // one wave per (list segment, quadrant); the grid covers the segment capacity, waves beyond the device-side
+  // total (order_seg0[n_tiles]) exit at once
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
+                     rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
+                     (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

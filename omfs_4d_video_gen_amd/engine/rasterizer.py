@@ -46,7 +46,7 @@ class Rasterizer:
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
         self.n_tiles = self.gx * self.gy
         # 288 GB of HBM: be generous rather than re-allocate; overflow is flagged by the device
-        self.dup_capacity = int(dup_capacity if dup_capacity else max(1 << 20, 64 * n))
+        self.dup_capacity = int(dup_capacity if dup_capacity else max(1 << 20, 48 * n))
         dev = self.device
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
         self.g0, self.g1, self.g2 = z(n, 4), z(n, 4), z(n, 4)
@@ -58,6 +58,9 @@ class Rasterizer:
         self.keys_tmp = z(self.dup_capacity, 2, dt=torch.int32)
         self.sorted_ids = z(self.dup_capacity, dt=torch.int32)
         self.status = z(1, dt=torch.int32)
+        self.seg_capacity = self.n_tiles + self.dup_capacity // L.SEG + 1
+        self.seg_ckpt = z(self.seg_capacity, 256, 4)
+        self.order_seg0 = z(self.n_tiles + 1, dt=torch.int32)
         self.image = z(3, height, width)
         self.final_T = z(height, width)
         self.n_contrib = z(height, width, dt=torch.int32)
@@ -65,7 +68,8 @@ class Rasterizer:
         self.rb = L.RasterBuffersC(L.ptr(self.g0), L.ptr(self.g1), L.ptr(self.g2), L.ptr(self.tile_count),
                                    L.ptr(self.tile_start), L.ptr(self.tile_cursor), L.ptr(self.tile_order),
                                    L.ptr(self.keys), L.ptr(self.keys_tmp), L.ptr(self.sorted_ids),
-                                   self.dup_capacity, int(sort_lds_pairs), L.ptr(self.status), L.ptr(self.image),
+                                   self.dup_capacity, int(sort_lds_pairs), L.ptr(self.status),
+                                   L.ptr(self.seg_ckpt), L.ptr(self.order_seg0), self.seg_capacity, L.ptr(self.image),
                                    L.ptr(self.final_T), L.ptr(self.n_contrib))
         # backward-side buffers are created on first use
         self.dsplat = None
