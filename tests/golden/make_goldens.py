@@ -271,8 +271,56 @@ def golden_flame_fitter(out):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+def make_vhap_export(root: Path, n_frames=11):
+    """Synthetic VHAP export (what `preprocess_video.py:212-300` reads); byte-stable."""
+    (root / "images").mkdir(parents=True, exist_ok=True)
+    (root / "fg_masks").mkdir(exist_ok=True)
+    (root / "flame_param").mkdir(exist_ok=True)
+    seq = synthetic.make_flame_sequence(n_frames, seed=31)
+    frames = []
+    for i in range(n_frames):
+        tiny_png(root / "images" / f"{i:05d}_00.png", i * 7 % 255)
+        tiny_png(root / "fg_masks" / f"{i:05d}_00.png", 255)
+        per = {k: (v[i:i + 1] if v.ndim > 1 and v.shape[0] == n_frames else v) for k, v in seq.items()}
+        if i == 4:
+            continue                      # a frame whose FLAME file is missing is skipped in the batched file
+        np.savez(root / "flame_param" / f"{i:05d}.npz", **per)
+    for i in range(n_frames):
+        fr = {"file_path": f"images/{i:05d}_00.png", "fg_mask_path": f"fg_masks/{i:05d}_00.png",
+              "flame_param_path": f"flame_param/{i:05d}.npz", "timestep_index": i, "camera_index": 0,
+              "transform_matrix": [[1, 0, 0, 0.01 * i], [0, 1, 0, 0], [0, 0, 1, 1], [0, 0, 0, 1]]}
+        if i == 0:
+            fr.update({"fl_x": 1234.5, "fl_y": 1230.0, "cx": 256.0, "cy": 200.0, "w": 512, "h": 400})
+        if i == 2:
+            del fr["fg_mask_path"]
+        frames.append(fr)
+    (root / "transforms.json").write_text(json.dumps({"camera_angle_x": 9.9, "frames": frames}, indent=2))
+
+
+def golden_preprocess(out):
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    pv = importlib.import_module("preprocess_video")
+    tmp = Path(tempfile.mkdtemp())
+    make_vhap_export(tmp / "export")
+    with redirect_stdout(io.StringIO()):
+        res = pv.convert_to_gaussianavatars_format(tmp / "export", tmp / "out")
+    o = tmp / "out"
+    out["convert"] = {"result": {**res, "output_dir": "<OUT>", "image_size": list(res["image_size"])},
+                      "files": sorted(str(p.relative_to(o)) for p in o.rglob("*") if p.is_file()),
+                      "transforms_train": json.loads((o / "transforms_train.json").read_text()),
+                      "n_test": len(json.loads((o / "transforms_test.json").read_text())["frames"]),
+                      "val_equals_test": (o / "transforms_val.json").read_text() == (o / "transforms_test.json").read_text()}
+    b, c = np.load(o / "flame_param.npz"), np.load(o / "canonical_flame_param.npz")
+    np.savez_compressed(HERE / "preprocess_convert_golden.npz", **{f"batched_{k}": b[k] for k in b.files if k != "dynamic_offset"},
+                        batched_dynamic_offset_shape=np.array(b["dynamic_offset"].shape), batched_dynamic_offset_absmax=np.abs(b["dynamic_offset"]).max(),
+                        **{f"canonical_{k}_shape": np.array(c[k].shape) for k in c.files},
+                        canonical_nonzero=np.array([float(np.abs(c[k]).max()) for k in sorted(c.files) if k not in ("shape", "static_offset")]))
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     out = {}
+    golden_preprocess(out)
     golden_render_surgery(out)
     golden_train_ghost(out)
     golden_flame_fitter(out)

@@ -99,6 +99,17 @@ def test_train_render_validate_pipeline(dataset, tmp_path, monkeypatch, capfd):
         shutil.rmtree(mod, ignore_errors=True)
 
 
+def test_single_frame_experiment(dataset, tmp_path, monkeypatch):
+    from omfs_4d_video_gen_amd import single_frame_experiment as sfe
+    from omfs_4d_video_gen_amd import train_ghost as tg
+    monkeypatch.setenv("OMFS_SYNTHETIC_RIG", "1")
+    real_run = subprocess.run
+    monkeypatch.setattr(tg.subprocess, "run", lambda cmd, **kw: real_run(list(cmd) + (["--n_gaussians", "20000"] if str(cmd[1]).endswith("train.py") else []), **kw))
+    res = sfe.run(str(dataset), str(tmp_path / "work"), iterations=300, copies=50)
+    assert Path(res["gt"]).exists() and Path(res["render"]).exists()
+    assert res["psnr"] > 14.0          # 300 iterations on one white-background view: clearly better than a blank frame
+
+
 def test_engine_failure_surfaces_as_runtime_error(dataset, tmp_path, monkeypatch):
     from omfs_4d_video_gen_amd import render_surgery as rs
     monkeypatch.setenv("OMFS_SYNTHETIC_RIG", "1")

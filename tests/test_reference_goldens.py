@@ -229,3 +229,37 @@ def test_simpleflame_oracle_fit_matches_reference(ff_gold, rig_small, iters):
         assert np.allclose(res[k], ff_gold[f"fit{iters}_{k}"], atol=2e-6), k
     assert np.all(ff_gold[f"fit{iters}_shape"][100:] == 0) and np.all(ff_gold[f"fit{iters}_expr"][:, 50:] == 0)
     assert tuple(ff_gold["fit_static_offset_shape"]) == (1, 5143, 3)
+
+
+# ------------------------------------------------------------------ preprocess_video (converter, §8f-1)
+def test_convert_to_gaussianavatars_format_matches_reference(tmp_path):
+    import importlib.util
+    from omfs_4d_video_gen_amd import preprocess_video as pv
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    spec = importlib.util.spec_from_file_location("make_goldens2", GOLD / "make_goldens.py")
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    mg.make_vhap_export(tmp_path / "export")
+    with redirect_stdout(io.StringIO()):
+        res = pv.convert_to_gaussianavatars_format(tmp_path / "export", tmp_path / "out")
+    want = G["convert"]
+    o = tmp_path / "out"
+    assert {**res, "output_dir": "<OUT>", "image_size": list(res["image_size"])} == want["result"]
+    assert sorted(str(p.relative_to(o)) for p in o.rglob("*") if p.is_file()) == want["files"]
+    assert json.loads((o / "transforms_train.json").read_text()) == want["transforms_train"]
+    assert len(json.loads((o / "transforms_test.json").read_text())["frames"]) == want["n_test"]
+    assert ((o / "transforms_val.json").read_text() == (o / "transforms_test.json").read_text()) == want["val_equals_test"]
+    gold = np.load(GOLD / "preprocess_convert_golden.npz")
+    b, c = np.load(o / "flame_param.npz"), np.load(o / "canonical_flame_param.npz")
+    for k in b.files:
+        if k == "dynamic_offset":
+            assert tuple(b[k].shape) == tuple(gold["batched_dynamic_offset_shape"]) and float(np.abs(b[k]).max()) == float(gold["batched_dynamic_offset_absmax"])
+        else:
+            assert b[k].dtype == gold[f"batched_{k}"].dtype and np.array_equal(b[k], gold[f"batched_{k}"]), k
+    for k in c.files:
+        assert tuple(c[k].shape) == tuple(gold[f"canonical_{k}_shape"]), k
+    # and the engine's own reader accepts what the converter wrote
+    sp = IO.load_split(str(o), "train")
+    assert len(sp["frames"]) == len(want["transforms_train"]["frames"])
+    with pytest.raises(FileNotFoundError):
+        pv.convert_to_gaussianavatars_format(tmp_path / "nope", tmp_path / "o2")
