@@ -2,7 +2,7 @@
 //
 // Loss spec: SURVEY.md Appendix A item 8: (1-l) L1 + l (1 - SSIM), SSIM with an 11x11 Gaussian
 // window (sigma 1.5), zero padding, per channel, C1 = 0.01^2, C2 = 0.03^2, mean over 3HW.
-// Two kernels, each a separable 11-tap convolution through LDS on 16x16 tiles with a 5-pixel halo:
+// Two kernels, each a streaming separable 11-tap convolution (64-column strips, register ring of rows):
 //   ssim_fwd : moments -> SSIM value + the three partial-derivative maps (d/dmu1, d/dE[xx], d/dE[xy])
 //   ssim_bwd : convolve the maps back, add the L1 sign term -> dL/dimage
 // Adam spec: SURVEY.md Appendix A item 9, torch.optim.Adam semantics; one pass over [59][n_pad],
@@ -11,117 +11,154 @@
 
 namespace omfs {
 
-constexpr int LT = 16;        // output tile
 constexpr int HALO = 5;
-constexpr int LW = LT + 2 * HALO;  // 26
+constexpr int SW = 64;                 // output columns per wave
+#ifndef OMFS_SSIM_ROWS
+#define OMFS_SSIM_ROWS 34              // output rows per wave; rows + 10 must be a multiple of 11
+#endif
+constexpr int SRH = OMFS_SSIM_ROWS;
+constexpr int SROWS = SRH + 2 * HALO;  // input rows streamed per wave
+static_assert(SROWS % 11 == 0, "the register ring is unrolled by the 11 window taps");
 
 struct GaussW { float g[11]; };  // normalised 11-tap window, passed by value (scalar registers)
 
-__global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
-                                                       int width, int height, float w_l1, float w_ssim, GaussW gw,
-                                                       float* __restrict__ map_mu1, float* __restrict__ map_xx,
-                                                       float* __restrict__ map_xy, float* __restrict__ partials) {
-  __shared__ float sx[LW][LW + 1], sy[LW][LW + 1];
-  __shared__ float h[5][LW][LT + 1];
-  __shared__ float wsum[4];
-  const int ch = blockIdx.z, tid = threadIdx.x;
-  const int ox = blockIdx.x * LT, oy = blockIdx.y * LT;
+// Streaming separable window: one wave owns a 64-column strip and walks SROWS input rows top to bottom.
+// Each row goes through LDS once for the horizontal taps; the vertical taps read a ring of the last 11
+// horizontally filtered rows that lives in registers (the row loop is unrolled by 11 so every ring index is
+// static). Global loads are issued two rows ahead.
+__global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+                                                      int width, int height, float w_l1, float w_ssim, GaussW gw,
+                                                      float* __restrict__ map_mu1, float* __restrict__ map_xx,
+                                                      float* __restrict__ map_xy, float* __restrict__ partials) {
+  __shared__ float sx[SW + 2 * HALO], sy[SW + 2 * HALO];
+  const int l = threadIdx.x, ch = blockIdx.z;
+  const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH;
   const size_t plane = (size_t)width * height;
   const float* ip = img + ch * plane;
   const float* gp = gt + ch * plane;
-  for (int k = tid; k < LW * LW; k += 256) {
-    const int r = k / LW, c = k % LW;
-    const int y = oy + r - HALO, x = ox + c - HALO;
-    const bool in = x >= 0 && x < width && y >= 0 && y < height;
-    sx[r][c] = in ? ip[(size_t)y * width + x] : 0.f;
-    sy[r][c] = in ? gp[(size_t)y * width + x] : 0.f;
-  }
-  __syncthreads();
-  for (int k = tid; k < LW * LT; k += 256) {
-    const int r = k / LT, c = k % LT;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 11; ++t) {
-      const float g = gw.g[t], x = sx[r][c + t], y = sy[r][c + t];
-      a0 = fma_(g, x, a0); a1 = fma_(g, y, a1); a2 = fma_(g, x * x, a2); a3 = fma_(g, y * y, a3); a4 = fma_(g, x * y, a4);
+  const int xa = ox - HALO + l, xb = ox + SW - HALO + l, xo = ox + l;
+  const bool ina = xa >= 0 && xa < width, inb = l < 2 * HALO && xb < width, ino = xo < width;
+  auto load_row = [&](int iy, float (&v)[4]) {
+    const int y = oy - HALO + iy;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (iy < SROWS && y >= 0 && y < height) {
+      const size_t ro = (size_t)y * width;
+      if (ina) { v[0] = ip[ro + xa]; v[1] = gp[ro + xa]; }
+      if (inb) { v[2] = ip[ro + xb]; v[3] = gp[ro + xb]; }
     }
-    h[0][r][c] = a0; h[1][r][c] = a1; h[2][r][c] = a2; h[3][r][c] = a3; h[4][r][c] = a4;
-  }
-  __syncthreads();
-  const int lx = tid & 15, ly = tid >> 4;
-  const int x = ox + lx, y = oy + ly;
+  };
+  float ring[11][5];
+  float cur[4], nxt[4], nn[4];
+  load_row(0, cur);
+  load_row(1, nxt);
   float contrib = 0.f;
-  if (x < width && y < height) {
-    float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+  for (int base = 0; base < SROWS; base += 11) {
 #pragma unroll
-    for (int t = 0; t < 11; ++t) {
-      const float g = gw.g[t];
-      mu1 = fma_(g, h[0][ly + t][lx], mu1); mu2 = fma_(g, h[1][ly + t][lx], mu2);
-      exx = fma_(g, h[2][ly + t][lx], exx); eyy = fma_(g, h[3][ly + t][lx], eyy); exy = fma_(g, h[4][ly + t][lx], exy);
+    for (int r = 0; r < 11; ++r) {
+      const int iy = base + r;
+      sx[l] = cur[0]; sy[l] = cur[1];
+      if (l < 2 * HALO) { sx[SW + l] = cur[2]; sy[SW + l] = cur[3]; }
+      __syncthreads();
+      load_row(iy + 2, nn);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 11; ++t) {
+        const float g = gw.g[t], x = sx[l + t], y = sy[l + t];
+        a0 = fma_(g, x, a0); a1 = fma_(g, y, a1); a2 = fma_(g, x * x, a2); a3 = fma_(g, y * y, a3); a4 = fma_(g, x * y, a4);
+      }
+      ring[r][0] = a0; ring[r][1] = a1; ring[r][2] = a2; ring[r][3] = a3; ring[r][4] = a4;
+      const int yin = oy - HALO + iy;
+      if (iy >= HALO && iy < HALO + SRH && yin < height && ino) contrib += w_l1 * fabsf(sx[l + HALO] - sy[l + HALO]);
+      const int yout = oy + iy - 2 * HALO;
+      if (iy >= 2 * HALO && yout < height && ino) {
+        float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+          const float g = gw.g[t];
+          const int q = (r + 1 + t) % 11;
+          mu1 = fma_(g, ring[q][0], mu1); mu2 = fma_(g, ring[q][1], mu2);
+          exx = fma_(g, ring[q][2], exx); eyy = fma_(g, ring[q][3], eyy); exy = fma_(g, ring[q][4], exy);
+        }
+        const float C1 = 0.0001f, C2 = 0.0009f;
+        const float s11 = exx - mu1 * mu1, s22 = eyy - mu2 * mu2, s12 = exy - mu1 * mu2;
+        const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+        const float iB = 1.f / (B1 * B2);
+        const float ssim = A1 * A2 * iB;
+        const size_t o = ch * plane + (size_t)yout * width + xo;
+        map_mu1[o] = (2.f * mu2 * (A2 - A1)) * iB - 2.f * mu1 * ssim / B1 + 2.f * mu1 * ssim / B2;
+        map_xx[o] = -ssim / B2;
+        map_xy[o] = 2.f * A1 * iB;
+        contrib -= w_ssim * ssim;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { cur[k] = nxt[k]; nxt[k] = nn[k]; }
     }
-    const float C1 = 0.0001f, C2 = 0.0009f;
-    const float s11 = exx - mu1 * mu1, s22 = eyy - mu2 * mu2, s12 = exy - mu1 * mu2;
-    const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
-    const float iB = 1.f / (B1 * B2);
-    const float ssim = A1 * A2 * iB;
-    const size_t o = ch * plane + (size_t)y * width + x;
-    map_mu1[o] = (2.f * mu2 * (A2 - A1)) * iB - 2.f * mu1 * ssim / B1 + 2.f * mu1 * ssim / B2;
-    map_xx[o] = -ssim / B2;
-    map_xy[o] = 2.f * A1 * iB;
-    const float d = sx[ly + HALO][lx + HALO] - sy[ly + HALO][lx + HALO];
-    contrib = w_l1 * fabsf(d) - w_ssim * ssim;
   }
   contrib = wave_sum_all(contrib);
-  if ((tid & 63) == 0) wsum[tid >> 6] = contrib;
-  __syncthreads();
-  // one partial per block (24k same-address atomics would serialise at ~11 ns each)
-  if (tid == 0) partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  // one partial per wave (24k same-address atomics would serialise at ~11 ns each)
+  if (l == 0) partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = contrib;
 }
 
-__global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
-                                                       int width, int height, float w_l1, float w_ssim, GaussW gw,
-                                                       const float* __restrict__ map_mu1, const float* __restrict__ map_xx,
-                                                       const float* __restrict__ map_xy, float* __restrict__ dimage) {
-  __shared__ float s[3][LW][LW + 1];
-  __shared__ float h[3][LW][LT + 1];
-  const int ch = blockIdx.z, tid = threadIdx.x;
-  const int ox = blockIdx.x * LT, oy = blockIdx.y * LT;
+__global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+                                                      int width, int height, float w_l1, float w_ssim, GaussW gw,
+                                                      const float* __restrict__ map_mu1, const float* __restrict__ map_xx,
+                                                      const float* __restrict__ map_xy, float* __restrict__ dimage) {
+  __shared__ float s0[SW + 2 * HALO], s1[SW + 2 * HALO], s2[SW + 2 * HALO];
+  const int l = threadIdx.x, ch = blockIdx.z;
+  const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH;
   const size_t plane = (size_t)width * height;
-  for (int k = tid; k < LW * LW; k += 256) {
-    const int r = k / LW, c = k % LW;
-    const int y = oy + r - HALO, x = ox + c - HALO;
-    const bool in = x >= 0 && x < width && y >= 0 && y < height;
-    const size_t o = ch * plane + (size_t)y * width + x;
-    s[0][r][c] = in ? map_mu1[o] : 0.f;
-    s[1][r][c] = in ? map_xx[o] : 0.f;
-    s[2][r][c] = in ? map_xy[o] : 0.f;
-  }
-  __syncthreads();
-  for (int k = tid; k < LW * LT; k += 256) {
-    const int r = k / LT, c = k % LT;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  const size_t co = ch * plane;
+  const int xa = ox - HALO + l, xb = ox + SW - HALO + l, xo = ox + l;
+  const bool ina = xa >= 0 && xa < width, inb = l < 2 * HALO && xb < width, ino = xo < width;
+  auto load_row = [&](int iy, float (&v)[8]) {
+    const int y = oy - HALO + iy;
 #pragma unroll
-    for (int t = 0; t < 11; ++t) {
-      const float g = gw.g[t];
-      a0 = fma_(g, s[0][r][c + t], a0); a1 = fma_(g, s[1][r][c + t], a1); a2 = fma_(g, s[2][r][c + t], a2);
+    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    if (iy < SROWS && y >= 0 && y < height) {
+      const size_t ro = co + (size_t)y * width;
+      if (ina) { v[0] = map_mu1[ro + xa]; v[1] = map_xx[ro + xa]; v[2] = map_xy[ro + xa]; }
+      if (inb) { v[3] = map_mu1[ro + xb]; v[4] = map_xx[ro + xb]; v[5] = map_xy[ro + xb]; }
     }
-    h[0][r][c] = a0; h[1][r][c] = a1; h[2][r][c] = a2;
-  }
-  __syncthreads();
-  const int lx = tid & 15, ly = tid >> 4;
-  const int x = ox + lx, y = oy + ly;
-  if (x < width && y < height) {
-    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    // the pixel pair of the output row this input row completes two iterations later (row iy - 10)
+    const int yo = oy + iy - 2 * HALO;
+    if (iy >= 2 * HALO && iy < SROWS && yo < height && ino) { v[6] = img[co + (size_t)yo * width + xo]; v[7] = gt[co + (size_t)yo * width + xo]; }
+  };
+  float ring[11][3];
+  float cur[8], nxt[8], nn[8];
+  load_row(0, cur);
+  load_row(1, nxt);
+  for (int base = 0; base < SROWS; base += 11) {
 #pragma unroll
-    for (int t = 0; t < 11; ++t) {
-      const float g = gw.g[t];
-      c0 = fma_(g, h[0][ly + t][lx], c0); c1 = fma_(g, h[1][ly + t][lx], c1); c2 = fma_(g, h[2][ly + t][lx], c2);
+    for (int r = 0; r < 11; ++r) {
+      const int iy = base + r;
+      s0[l] = cur[0]; s1[l] = cur[1]; s2[l] = cur[2];
+      if (l < 2 * HALO) { s0[SW + l] = cur[3]; s1[SW + l] = cur[4]; s2[SW + l] = cur[5]; }
+      __syncthreads();
+      load_row(iy + 2, nn);
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 11; ++t) {
+        const float g = gw.g[t];
+        a0 = fma_(g, s0[l + t], a0); a1 = fma_(g, s1[l + t], a1); a2 = fma_(g, s2[l + t], a2);
+      }
+      ring[r][0] = a0; ring[r][1] = a1; ring[r][2] = a2;
+      const int yout = oy + iy - 2 * HALO;
+      if (iy >= 2 * HALO && yout < height && ino) {
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+          const float g = gw.g[t];
+          const int q = (r + 1 + t) % 11;
+          c0 = fma_(g, ring[q][0], c0); c1 = fma_(g, ring[q][1], c1); c2 = fma_(g, ring[q][2], c2);
+        }
+        const float xv = cur[6], yv = cur[7];
+        const float d = xv - yv;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        dimage[co + (size_t)yout * width + xo] = w_l1 * sgn - w_ssim * (c0 + 2.f * xv * c1 + yv * c2);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { cur[k] = nxt[k]; nxt[k] = nn[k]; }
     }
-    const size_t o = ch * plane + (size_t)y * width + x;
-    const float xv = img[o], yv = gt[o];
-    const float d = xv - yv;
-    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-    dimage[o] = w_l1 * sgn - w_ssim * (c0 + 2.f * xv * c1 + yv * c2);
   }
 }
 
@@ -191,12 +228,12 @@ extern "C" int omfs_loss_l1_ssim(const float* image, const float* target, int wi
   const float inv = 1.f / (float)n;
   const float w_l1 = (1.f - lambda_dssim) * inv, w_ssim = lambda_dssim * inv;
   float* m0 = scratch; float* m1 = scratch + n; float* m2 = scratch + 2 * n;
-  dim3 grid(cdiv(width, LT), cdiv(height, LT), 3);
-  // block partials are parked at the head of dimage (overwritten by ssim_bwd afterwards)
-  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
+  dim3 grid(cdiv(width, SW), cdiv(height, SRH), 3);
+  // per-wave partials are parked at the head of dimage (overwritten by ssim_bwd afterwards)
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(64), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
   OMFS_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, dimage, (int)(grid.x * grid.y * grid.z), lambda_dssim, loss_out);
-  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(256), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
+  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(64), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

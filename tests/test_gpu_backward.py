@@ -65,10 +65,11 @@ def test_backward_matches_autograd(n, width, height, bg, big):
         assert np.abs(got[name] - r).sum() <= 2e-4 * np.abs(r).sum() + 1e-6, name
 
 
-def test_loss_l1_ssim_value_and_gradient():
+@pytest.mark.parametrize("W,Hh", [(75, 50), (200, 121), (64, 34)])
+def test_loss_l1_ssim_value_and_gradient(W, Hh):
+    # sizes that are not multiples of the 64-column x 34-row strips exercise the zero-padded borders
     from oracle import torch_splat as O
     from omfs_4d_video_gen_amd.engine.rasterizer import Rasterizer
-    W, Hh = 75, 50   # not multiples of 16: exercises the zero-padded borders
     rast = Rasterizer(256, W, Hh)
     gen = torch.Generator().manual_seed(3)
     img = torch.rand(3, Hh, W, generator=gen)
