@@ -89,17 +89,37 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
 
 // ------------------------------------------------------------------ count + key scatter
 // Both walk every Gaussian's tile rectangle, apply the frozen tile_touched() test, and aggregate
-// in LDS first (one counter per tile: 32 KB at 1080p): a 1024-Gaussian block produces ~25k
+// in LDS first (one counter per tile: 32 KB at 1080p): a 512-Gaussian block produces ~6k
 // (Gaussian,tile) pairs but touches <= n_tiles counters, so the global atomics drop from one per
 // pair to one per non-empty (block, tile) -- an order of magnitude fewer, and only the scatter's
 // are returning atomics.  Placement inside a tile segment is arbitrary; the sort fixes the order.
-constexpr int BIN_THREADS = 1024;
+//
+// Load balance: rectangles range from 1 to >100 tiles, so a lane-per-Gaussian loop runs at the pace of the
+// largest rectangle in each wave (measured 4-5x the mean).  Instead every wave publishes its 64 rectangles
+// in LDS, prefix-sums their areas and walks the CONCATENATED list of rectangle tiles 64 at a time: lane l
+// takes flat index p = 64 k + l, finds the owning Gaussian by a 6-step bisection of the prefix sums and
+// tests that one tile.  Adjacent lanes mostly test adjacent tiles of the same Gaussian, so the LDS counter
+// atomics rarely collide.
+#ifndef OMFS_BIN_THREADS
+#define OMFS_BIN_THREADS 512
+#endif
+constexpr int BIN_THREADS = OMFS_BIN_THREADS;
+constexpr int BIN_WAVES = BIN_THREADS / 64;
 
 struct PairSource {
   const float4* g0; const float4* g1; const float4* g2;
 };
 
-// calls f(tile) for every tile of Gaussian i's rectangle that passes the test
+struct WaveRects {            // one wave's published rectangles (36 B per lane)
+  float4 r0[64];              // mean2d.xy, conic a, b
+  float2 r1[64];              // conic c, opacity
+  uint32_t scan[64];          // inclusive prefix sum of rectangle areas
+  uint32_t rect[64];          // packed x0 | y0<<8 | x1<<16 | y1<<24
+  uint32_t depth[64];         // depth bits
+};
+constexpr size_t BIN_SCRATCH_BYTES = sizeof(WaveRects) * BIN_WAVES;
+
+// calls f(tile) for every tile of Gaussian i's rectangle that passes the test (lane-per-Gaussian form, fallback kernels)
 template <typename F>
 __device__ __forceinline__ void for_each_touched_tile(const PairSource& ps, int i, int gx, F&& f) {
   const float4 r2 = ps.g2[i];
@@ -113,14 +133,57 @@ __device__ __forceinline__ void for_each_touched_tile(const PairSource& ps, int 
       if (tile_touched(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, x, y)) f(y * gx + x);
 }
 
+// Every lane of the wave must call this (i >= n publishes an empty rectangle).  Returns the wave's rectangle-tile total.
+__device__ __forceinline__ uint32_t publish_rects(const PairSource& ps, int i, int n, WaveRects* wr) {
+  const int lane = lane_id();
+  uint32_t rect = 0u, depth = 0u;
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float2 r1 = make_float2(0.f, 0.f);
+  if (i < n) {
+    const float4 r2 = ps.g2[i];
+    rect = __float_as_uint(r2.w);
+    depth = __float_as_uint(r2.y);
+    if (rect) { r0 = ps.g0[i]; const float4 t = ps.g1[i]; r1 = make_float2(t.x, t.y); }
+  }
+  const uint32_t area = (((rect >> 16) & 255u) - (rect & 255u)) * ((rect >> 24) - ((rect >> 8) & 255u));
+  const uint32_t incl = wave_incl_scan_u32(area, lane);
+  wr->r0[lane] = r0; wr->r1[lane] = r1; wr->scan[lane] = incl; wr->rect[lane] = rect; wr->depth[lane] = depth;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+}
+
+// f(tile, owner lane) for every rectangle tile of the wave's 64 Gaussians that passes the frozen tile test.
+template <typename F>
+__device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* wr, uint32_t total, int gx, F&& f) {
+  for (uint32_t p = lane_id(); p < total; p += 64) {
+    int j = 0;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1)
+      if (wr->scan[j + s - 1] <= p) j += s;          // first j with scan[j] > p
+    const uint32_t rect = wr->rect[j];
+    const int x0 = rect & 255u, y0 = (rect >> 8) & 255u, x1 = (rect >> 16) & 255u, y1 = rect >> 24;
+    const int w = x1 - x0;
+    const int k = (int)(p - (wr->scan[j] - (uint32_t)(w * (y1 - y0))));
+    // k / w for k < 2^15, w < 2^8: (k + 0.5) / w is at least 0.5/w away from an integer, far above the rounding error
+    const int q = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+    const int tx = x0 + (k - q * w), ty = y0 + q;
+    const float4 r0 = wr->r0[j];
+    const float2 r1 = wr->r1[j];
+    if (tile_touched(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty)) f(ty * gx + tx, j);
+  }
+}
+
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSource ps, int gx, int n_tiles,
                                                                 uint32_t* __restrict__ tile_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);
+  WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
-  __syncthreads();
   const int i = blockIdx.x * BIN_THREADS + threadIdx.x;
-  if (i < n) for_each_touched_tile(ps, i, gx, [&](int t) { atomicAdd(&hist[t], 1u); });
+  const uint32_t total = publish_rects(ps, i, n, wr);
+  __syncthreads();
+  for_each_touched_tile_balanced(wr, total, gx, [&](int t, int) { atomicAdd(&hist[t], 1u); });
   __syncthreads();
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) {
     const uint32_t c = hist[t];
@@ -133,26 +196,25 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSou
                                                                   uint32_t* __restrict__ tile_cursor,
                                                                   uint2* __restrict__ keys) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint32_t* hist = reinterpret_cast<uint32_t*>(smem);   // count, then this block's base slot in the tile
-  uint32_t* cur = hist + n_tiles;                       // block-local cursor
+  WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);  // count, then this block's next slot in the tile
   if (tile_start[n_tiles] == 0u) return;                // nothing visible, or capacity overflow (flagged by the scan)
-  for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) { hist[t] = 0; cur[t] = 0; }
-  __syncthreads();
+  for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
   const int i = blockIdx.x * BIN_THREADS + threadIdx.x;
-  if (i < n) for_each_touched_tile(ps, i, gx, [&](int t) { atomicAdd(&hist[t], 1u); });
+  const uint32_t total = publish_rects(ps, i, n, wr);
+  __syncthreads();
+  for_each_touched_tile_balanced(wr, total, gx, [&](int t, int) { atomicAdd(&hist[t], 1u); });
   __syncthreads();
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) {
     const uint32_t c = hist[t];
     if (c) hist[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
   }
   __syncthreads();
-  if (i < n) {
-    const uint32_t depth_bits = __float_as_uint(ps.g2[i].y);
-    for_each_touched_tile(ps, i, gx, [&](int t) {
-      const uint32_t pos = hist[t] + atomicAdd(&cur[t], 1u);
-      keys[pos] = make_uint2(depth_bits, (uint32_t)i);
-    });
-  }
+  const uint32_t id0 = (uint32_t)(i - lane_id());
+  for_each_touched_tile_balanced(wr, total, gx, [&](int t, int j) {
+    const uint32_t pos = atomicAdd(&hist[t], 1u);
+    keys[pos] = make_uint2(wr->depth[j], id0 + (uint32_t)j);
+  });
 }
 
 // Fallback for images with more tiles than fit in LDS: one global atomic per pair.
@@ -321,7 +383,7 @@ extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, c
   hipStream_t s = (hipStream_t)stream;
   OMFS_CHECK_HIP(hipMemsetAsync(rb->tile_count, 0, sizeof(uint32_t) * n_tiles, s));
   PairSource ps{(const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2};
-  const size_t lds = (size_t)n_tiles * 4;
+  const size_t lds = (size_t)n_tiles * 4 + BIN_SCRATCH_BYTES;
   if (lds <= BIN_LDS_LIMIT) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -353,7 +415,7 @@ extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam,
   const int gx = cdiv(cam->width, OMFS_TILE), n_tiles = gx * cdiv(cam->height, OMFS_TILE);
   hipStream_t s = (hipStream_t)stream;
   PairSource ps{(const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2};
-  const size_t lds = (size_t)n_tiles * 8;
+  const size_t lds = (size_t)n_tiles * 4 + BIN_SCRATCH_BYTES;
   if (lds <= BIN_LDS_LIMIT) {
     static bool attr_set = false;
     if (!attr_set) {
