@@ -71,6 +71,14 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
 }
 
 constexpr int WB = 64;   // splats staged per wave and step
+#ifndef OMFS_FWD_SEQ_SEGS
+#define OMFS_FWD_SEQ_SEGS 4
+#endif
+#ifndef OMFS_DEEP_WAVES
+#define OMFS_DEEP_WAVES 8
+#endif
+constexpr int FWD_SEQ_SEGS = OMFS_FWD_SEQ_SEGS;   // list segments the one-wave forward walks before handing over
+constexpr int DEEP_WAVES = OMFS_DEEP_WAVES;       // segments evaluated in parallel per deep quadrant
 
 // Forward.  One 64-lane workgroup (= one wave) per (tile, 8x8 quadrant); lane l owns pixel (l&7, l>>3) of
 // the quadrant.  No workgroup barrier exists: a wave whose pixels have all saturated simply exits and
@@ -112,7 +120,10 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
     r0 = g0[id]; r1 = g1[id]; r2 = g2[id].x;
   }
   unsigned long long live = __ballot(!done);
-  for (uint32_t b = beg; b < end && live != 0ull; b += WB) {
+  // lists longer than FWD_SEQ_SEGS segments are finished by composite_fwd_deep_kernel (segment-parallel)
+  const bool deep = end - beg > (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG);
+  const uint32_t lim = deep ? beg + (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG) : end;
+  for (uint32_t b = beg; b < lim && live != 0ull; b += WB) {
     // entering a new segment: checkpoint (T, C) so the backward pass can start there (see composite_bwd_kernel)
     if (b != beg && ((b - beg) & (OMFS_SEG - 1)) == 0u)
       seg_ckpt[((size_t)(beg / OMFS_SEG) + tile + (b - beg) / OMFS_SEG) * 256 + quad * 64 + lane] = make_float4(T, C0, C1, C2);
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
     for (int sb = 0; sb < 4; ++sb) ms[sb] = __ballot((mask >> sb) & 1u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (k + WB < end) {   // next step's gather, in flight during the walk
+    if (k + WB < lim) {   // next step's gather, in flight during the walk
       const uint32_t id = sorted_ids[k + WB];
       r0 = g0[id]; r1 = g1[id]; r2 = g2[id].x;
     }
@@ -187,8 +198,245 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
       }
     }
   }
+  if (deep) {
+    // hand-over: the state at boundary FWD_SEQ_SEGS and, in the tile's unused boundary-0 slot, the live mask
+    const size_t slot0 = (size_t)(beg / OMFS_SEG) + tile;
+    if (live) seg_ckpt[(slot0 + FWD_SEQ_SEGS) * 256 + quad * 64 + lane] = make_float4(T, C0, C1, C2);
+    if (lane == 0)
+      seg_ckpt[slot0 * 256 + quad * 64] = make_float4(__uint_as_float((uint32_t)live), __uint_as_float((uint32_t)(live >> 32)), 0.f, 0.f);
+  }
   if (inside) {
     const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
+    image[o] = fma_(T, cam.bg[0], C0);
+    image[plane + o] = fma_(T, cam.bg[1], C1);
+    image[2 * plane + o] = fma_(T, cam.bg[2], C2);
+    final_T[o] = T;
+    n_contrib[o] = last;
+  }
+}
+
+// Forward, deep part.  Lists longer than FWD_SEQ_SEGS segments: one workgroup of DEEP_WAVES waves per (tile,
+// quadrant) that composite_fwd_kernel left unfinished.  Compositing is associative per pixel -- a segment acts on
+// the incoming (T, C) as T' = T P, C' = C + T A with its own transmittance product P and colour A -- so the
+// waves evaluate DEEP_WAVES consecutive segments in parallel (each from T = 1) and then every wave composes
+// the partials in order (all waves hold the same pixel state in registers, so nothing is broadcast).  Only the
+// stop rule is not associative: a pixel whose composed T would fall below 1e-4 inside a segment is resolved
+// exactly by ONE wave in transposed form -- lanes are the segment's entries, a wave-wide prefix product of
+// (1 - alpha) finds the first entry that would take T below the threshold.  Checkpoints for the backward pass
+// fall out of the composition.
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(v, d, 64);
+    if (lane >= d) v *= t;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
+    CompCam cam, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_start,
+    const uint32_t* __restrict__ sorted_ids, const float4* __restrict__ g0, const float4* __restrict__ g1,
+    const float4* __restrict__ g2, float* __restrict__ image, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib, float4* __restrict__ seg_ckpt) {
+  __shared__ float4 pg0[DEEP_WAVES][WB];
+  __shared__ float4 pg1[DEEP_WAVES][WB];
+  __shared__ float pg2[DEEP_WAVES][WB];
+  __shared__ float4 comp[DEEP_WAVES][64];     // per segment and pixel: (P, A.rgb)
+  __shared__ uint32_t comp_last[DEEP_WAVES][64];
+  __shared__ float4 res[64];                  // exactly resolved pixels: (T, C.rgb)
+  __shared__ uint32_t res_last[64];           // last contributor | terminated << 31
+  const uint32_t tile = tile_order[blockIdx.x >> 2];
+  const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
+  if (tend - tbeg <= (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG)) return;
+  const int quad = blockIdx.x & 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t slot0 = (size_t)(tbeg / OMFS_SEG) + tile;
+  const float4 hand = seg_ckpt[slot0 * 256 + quad * 64];
+  unsigned long long live = (unsigned long long)__float_as_uint(hand.x) | ((unsigned long long)__float_as_uint(hand.y) << 32);
+  live = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)live) |
+         ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(live >> 32)) << 32);   // wave-uniform
+  if (live == 0ull) return;
+  const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const float fx = (float)px, fy = (float)py;
+  const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
+  const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
+  unsigned long long sbl[4];
+#pragma unroll
+  for (int sb = 0; sb < 4; ++sb) sbl[sb] = __ballot(sidx == sb);
+  bool done = ((live >> lane) & 1ull) == 0ull;
+  const bool mine = !done;                     // pixels that stopped in the first kernel keep its output
+  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
+  uint32_t last = 0;
+  if (!done) {
+    const float4 ck = seg_ckpt[(slot0 + FWD_SEQ_SEGS) * 256 + quad * 64 + lane];
+    T = ck.x; C0 = ck.y; C1 = ck.z; C2 = ck.w;
+    last = n_contrib[o];
+  }
+  const uint32_t n_seg = (tend - tbeg + OMFS_SEG - 1) / OMFS_SEG;
+  for (uint32_t sbatch = FWD_SEQ_SEGS; sbatch < n_seg && live != 0ull; sbatch += DEEP_WAVES) {
+    const int nb = (int)min((uint32_t)DEEP_WAVES, n_seg - sbatch);
+    // ---- phase A: wave w evaluates segment sbatch + w from (T, C) = (1, 0) for the pixels still live
+    if (wave < nb) {
+      const uint32_t sb0 = tbeg + (sbatch + wave) * OMFS_SEG, se = min(tend, sb0 + OMFS_SEG);
+      float P = 1.f, A0 = 0.f, A1 = 0.f, A2 = 0.f;
+      uint32_t lw = 0;
+      float4 q0[2], q1[2];
+      float q2[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        q0[h] = make_float4(0.f, 0.f, 0.f, 0.f); q1[h] = q0[h]; q2[h] = 0.f;
+        const uint32_t k = sb0 + h * WB + lane;
+        if (k < se) { const uint32_t id = sorted_ids[k]; q0[h] = g0[id]; q1[h] = g1[id]; q2[h] = g2[id].x; }
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t b = sb0 + h * WB;
+        if (b >= se) break;
+        const uint32_t k = b + lane;
+        uint32_t mask = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (k < se) {
+          const float A = q0[h].z, B = q0[h].w, C = q1[h].x;
+          const float lo = __log2f(fmaxf(q1[h].y, 1e-30f));
+          pg0[wave][lane] = make_float4(q0[h].x, q0[h].y, -0.5f * LOG2E * A, -LOG2E * B);
+          pg1[wave][lane] = make_float4(-0.5f * LOG2E * C, lo, q1[h].z, q1[h].w);
+          pg2[wave][lane] = q2[h];
+          mask = quadrant_mask(q0[h].x, q0[h].y, A, B, C, lo, qx0, qy0);
+        }
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int sb = 0; sb < 4; ++sb) {
+          const unsigned long long bal = __ballot((mask >> sb) & 1u);
+          if (live & sbl[sb]) m |= bal;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t base = b - tbeg;
+        int jn = m ? __builtin_ctzll(m) : 0;
+        float4 an = pg0[wave][jn], cn = pg1[wave][jn];
+        float cbn = pg2[wave][jn];
+        while (m) {
+          const int j = jn;
+          const float4 a = an;
+          const float4 c = cn;
+          const float cb = cbn;
+          m &= m - 1ull;
+          jn = m ? __builtin_ctzll(m) : 0;
+          an = pg0[wave][jn]; cn = pg1[wave][jn]; cbn = pg2[wave][jn];
+          const float dx = a.x - fx, dy = a.y - fy;
+          const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
+          const float e = p2 + c.y;
+          if (!done && p2 <= 0.f && e >= LOG2_INV255) {
+            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
+            const float w = alpha * P;
+            A0 = fma_(c.z, w, A0);
+            A1 = fma_(c.w, w, A1);
+            A2 = fma_(cb, w, A2);
+            P = P * (1.f - alpha);
+            lw = base + (uint32_t)j + 1u;
+          }
+        }
+      }
+      comp[wave][lane] = make_float4(P, A0, A1, A2);
+      comp_last[wave][lane] = lw;
+    }
+    __syncthreads();
+    // ---- phase B/C: compose in order (every wave, identically); resolve stops exactly; repeat until nothing is pending
+    int nw = 0;                 // next segment of the batch this pixel has to take
+    float bT = 0.f, bC0 = 0.f, bC1 = 0.f, bC2 = 0.f;
+    bool have_boundary = false;
+    while (true) {
+      int pend = -1;
+      for (int w = 0; w < nb; ++w) {
+        const bool active = !done && pend < 0 && w >= nw;
+        if (w == wave && active) { bT = T; bC0 = C0; bC1 = C1; bC2 = C2; have_boundary = true; }
+        const float4 pc = comp[w][lane];
+        const uint32_t lw = comp_last[w][lane];
+        if (active) {
+          const float Tn = T * pc.x;
+          if (Tn < 1e-4f) {
+            pend = w;                                   // stops somewhere inside this segment
+          } else {
+            C0 = fma_(T, pc.y, C0); C1 = fma_(T, pc.z, C1); C2 = fma_(T, pc.w, C2);
+            T = Tn;
+            if (lw) last = lw;
+          }
+        }
+      }
+      if (pend < 0) nw = nb;                          // took every segment of the batch (or is done)
+      const unsigned long long pending = __ballot(pend >= 0);
+      if (pending == 0ull) break;
+      // phase C: the k-th pending pixel is resolved by wave k mod DEEP_WAVES
+      unsigned long long pm = pending;
+      for (int kth = 0; pm; ++kth) {
+        const int pl = __builtin_ctzll(pm);
+        pm &= pm - 1ull;
+        if (kth % DEEP_WAVES != wave) continue;
+        const int pw = __builtin_amdgcn_readlane(pend, pl);
+        float Trun = readlane_f(T, pl);
+        float R0 = readlane_f(C0, pl), R1 = readlane_f(C1, pl), R2 = readlane_f(C2, pl);
+        uint32_t rlast = (uint32_t)__builtin_amdgcn_readlane((int)last, pl);
+        const float pfx = (float)(qx0 + (pl & 7)), pfy = (float)(qy0 + (pl >> 3));
+        const uint32_t sb0 = tbeg + (sbatch + (uint32_t)pw) * OMFS_SEG, se = min(tend, sb0 + OMFS_SEG);
+        bool found = false;
+        for (uint32_t b = sb0; b < se && !found; b += WB) {
+          const uint32_t k = b + lane;
+          float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+          bool hit = false;
+          if (k < se) {
+            const uint32_t id = sorted_ids[k];
+            const float4 a = g0[id], c = g1[id];
+            const float dx = a.x - pfx, dy = a.y - pfy;
+            const float p2 = fma_((-0.5f * LOG2E * a.z) * dx, dx, fma_((-0.5f * LOG2E * c.x) * dy, dy, (-LOG2E * a.w) * dx * dy));
+            const float e = p2 + __log2f(fmaxf(c.y, 1e-30f));
+            if (p2 <= 0.f && e >= LOG2_INV255) {
+              hit = true;
+              alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
+              c0 = c.z; c1 = c.w; c2 = g2[id].x;
+            }
+          }
+          const float om = 1.f - alpha;
+          const float incl = wave_incl_prod(om, lane);
+          float excl = __shfl_up(incl, 1, 64);
+          if (lane == 0) excl = 1.f;
+          const float Tb = Trun * excl;                   // T in front of this entry
+          const bool term = hit && Tb * om < 1e-4f;
+          const unsigned long long tb = __ballot(term);
+          const int first = tb ? __builtin_ctzll(tb) : 64;
+          const bool contrib = hit && lane < first;
+          const float w = contrib ? alpha * Tb : 0.f;
+          R0 += wave_sum_all(c0 * w); R1 += wave_sum_all(c1 * w); R2 += wave_sum_all(c2 * w);
+          const unsigned long long cbal = __ballot(contrib);
+          if (cbal) rlast = (b - tbeg) + (uint32_t)(63 - __builtin_clzll(cbal)) + 1u;
+          if (tb) { found = true; Trun = readlane_f(Tb, first); }
+          else Trun = Trun * readlane_f(incl, 63);
+        }
+        if (lane == 0) {
+          res[pl] = make_float4(Trun, R0, R1, R2);
+          res_last[pl] = rlast | (found ? 0x80000000u : 0u);
+        }
+      }
+      __syncthreads();
+      if (pend >= 0) {
+        const float4 r = res[lane];
+        const uint32_t rl = res_last[lane];
+        T = r.x; C0 = r.y; C1 = r.z; C2 = r.w;
+        last = rl & 0x7FFFFFFFu;
+        if (rl >> 31) done = true; else nw = pend + 1;
+      }
+      __syncthreads();   // res is reused by the next round
+    }
+    // boundary checkpoints of this batch (the state in front of segment sbatch + wave)
+    if (wave < nb && have_boundary)
+      seg_ckpt[(slot0 + sbatch + wave) * 256 + quad * 64 + lane] = make_float4(bT, bC0, bC1, bC2);
+    live = __ballot(!done);
+    __syncthreads();     // comp is rewritten by the next batch
+  }
+  if (wave == 0 && mine) {
     image[o] = fma_(T, cam.bg[0], C0);
     image[plane + o] = fma_(T, cam.bg[1], C1);
     image[2 * plane + o] = fma_(T, cam.bg[2], C2);
@@ -430,6 +678,11 @@ extern "C" int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buff
   const int n_tiles = cc.gx * cdiv(cam->height, OMFS_TILE);
   OMFS_REQUIRE(rb->seg_capacity >= (uint32_t)n_tiles + rb->dup_capacity / OMFS_SEG, "seg_capacity < n_tiles + dup_capacity/OMFS_SEG");
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_tiles * 4), dim3(64), 0, (hipStream_t)stream, cc, rb->tile_order,
+                     rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
+                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt);
+  OMFS_CHECK_HIP(hipGetLastError());
+  // quadrants whose list is longer than FWD_SEQ_SEGS segments and still unsaturated (the rest exit at once)
+  hipLaunchKernelGGL(composite_fwd_deep_kernel, dim3(n_tiles * 4), dim3(DEEP_WAVES * 64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
                      (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt);
   OMFS_CHECK_HIP(hipGetLastError());

@@ -35,7 +35,8 @@ def _grads_to_groups(grads, n):
             "sh": gh[11:].T.reshape(n, 16, 3)}
 
 
-@pytest.mark.parametrize("n,width,height,bg,big", [(1200, 80, 64, (1.0, 1.0, 1.0), False), (3000, 128, 96, (0.1, 0.2, 0.3), True)])
+@pytest.mark.parametrize("n,width,height,bg,big", [(1200, 80, 64, (1.0, 1.0, 1.0), False), (3000, 128, 96, (0.1, 0.2, 0.3), True),
+                                                   (16000, 64, 48, (0.3, 0.1, 0.2), False)])   # last: deep lists
 def test_backward_matches_autograd(n, width, height, bg, big):
     from oracle import torch_splat as O
     rig, g, seq, cam, dflame, model, rast, mk = _scene(n, width, height, seed=4, big_scale=big)

@@ -27,7 +27,8 @@ def _setup(n, width, height, T=3, seed=0, yaw=0.2):
     return rig, g, seq, cam, dflame, model, rast, make_camera_struct
 
 
-@pytest.mark.parametrize("n,width,height,bg", [(1500, 96, 80, (1.0, 1.0, 1.0)), (6000, 200, 152, (0.0, 0.0, 0.0))])
+@pytest.mark.parametrize("n,width,height,bg", [(1500, 96, 80, (1.0, 1.0, 1.0)), (6000, 200, 152, (0.0, 0.0, 0.0)),
+                                               (30000, 96, 80, (0.2, 0.3, 0.1))])   # last: lists of thousands (deep forward)
 def test_forward_matches_oracle(n, width, height, bg):
     from oracle import torch_splat as O
     rig, g, seq, cam, dflame, model, rast, mk = _setup(n, width, height)
@@ -83,17 +84,27 @@ def test_forward_matches_oracle(n, width, height, bg):
         if got != lst:
             n_list_diff += 1
     if n_rect_diff == 0:   # order can still flip where the torch oracle's depths differ in the last bit
-        assert n_list_diff <= max(2, len(ref["lists"]) // 50), f"{n_list_diff} tile lists differ"
+        if n < 30000:      # lists of thousands of entries always hold a last-bit flip somewhere; the bit-exact
+            # comparison of every list is test_gpu_bitexact.py
+            assert n_list_diff <= max(2, len(ref["lists"]) // 50), f"{n_list_diff} tile lists differ"
+
+    if n >= 30000:   # the segment-parallel forward (lists longer than 4 x 128 entries) must be exercised
+        assert int(np.diff(tile_start).max()) > 2048
 
     # image
     out = img.cpu()
     l1 = (out - ref["image"]).abs().mean().item()
     assert l1 < 1e-3, f"per-pixel mean L1 {l1}"
-    assert (out - ref["image"]).abs().max().item() < 2e-2
+    # (a depth order flip against the torch oracle's own fp32 depths shows up as one outlier pixel in dense scenes)
+    assert (out - ref["image"]).abs().max().item() < (2e-2 if n < 30000 else 6e-2)
     if n_rect_diff == 0:
         assert torch.equal(rast.n_contrib.cpu(), ref["n_contrib"]) or \
             (rast.n_contrib.cpu() != ref["n_contrib"]).float().mean() < 1e-3
-    assert torch.allclose(rast.final_T.cpu(), ref["final_T"], atol=2e-3)
+    dT = (rast.final_T.cpu() - ref["final_T"]).abs()
+    if n < 30000:
+        assert float(dT.max()) <= 2e-3
+    else:
+        assert float((dT <= 2e-3).float().mean()) > 0.995 and float(dT.mean()) < 2e-4
 
 
 def test_empty_and_capacity():
