@@ -445,6 +445,27 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
   }
 }
 
+// Sums of 9 values over each group of 8 consecutive lanes, left in the group's last lane.  v_add_f32 with a DPP
+// source (row_shr 1, 2, 4; lanes shifted in from outside read as 0) -- one instruction per value and step; the
+// compiler's own lowering of the same pattern is a v_mov_dpp plus a packed add.  A VGPR written by a VALU
+// instruction needs two wait states before a DPP read: the s_nop covers the first row, the 8 instructions
+// between two uses of the same register cover the rest.
+__device__ __forceinline__ void reduce9_groups_of_8(float (&v)[9]) {
+#define OMFS_DPP_ROW(SH)                                                                      \
+  "v_add_f32_dpp %0, %0, %0 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+  "v_add_f32_dpp %1, %1, %1 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+  "v_add_f32_dpp %2, %2, %2 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+  "v_add_f32_dpp %3, %3, %3 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+  "v_add_f32_dpp %4, %4, %4 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+  "v_add_f32_dpp %5, %5, %5 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+  "v_add_f32_dpp %6, %6, %6 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+  "v_add_f32_dpp %7, %7, %7 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
+  "v_add_f32_dpp %8, %8, %8 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+  asm volatile("s_nop 1\n\t" OMFS_DPP_ROW(1) OMFS_DPP_ROW(2) OMFS_DPP_ROW(4)
+               : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
+#undef OMFS_DPP_ROW
+}
+
 // Backward.  One wave per (OMFS_SEG-entry list segment, quadrant), no workgroup barrier: the serial depth
 // of a silhouette quadrant is bounded by the segment length.  A pixel whose last contributor lies behind this
 // segment enters it with the (T, C) the forward pass checkpointed at the next segment's start: T directly,
@@ -593,49 +614,39 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
       const float2 cb = cbn;
       jbn = m ? 63 - __builtin_clzll(m) : 0;   // prefetch the next splat's record
       an = s0[jbn]; cn = s1[jbn]; cbn = s2[jbn];
-      bool hit = false;
-      if (contributor <= last) {
-        const float dx = a.x - fx, dy = a.y - fy;
-        const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
-        const float e = p2 + c.y;
-        if (p2 <= 0.f && e >= LOG2_INV255) {
-          hit = true;
-          const float G = __builtin_amdgcn_exp2f(p2);
-          const float oG = cb.y * G;                              // opacity * G
-          const float alpha = fminf(0.99f, oG);
-          const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
-          T = T * r1a;
-          const float w = alpha * T;
-          v[6] = w * dL0; v[7] = w * dL1; v[8] = w * dL2;  // dL/dcolour
-          acc0 = fma_(la, lc0, (1.f - la) * acc0);
-          acc1 = fma_(la, lc1, (1.f - la) * acc1);
-          acc2 = fma_(la, lc2, (1.f - la) * acc2);
-          lc0 = c.z; lc1 = c.w; lc2 = cb.x; la = alpha;
-          float dLa = (c.z - acc0) * dL0 + (c.w - acc1) * dL1 + (cb.x - acc2) * dL2;
-          dLa = fma_(dLa, T, -(T_final * r1a) * bgdot);
-          // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream
-          // rasteriser does (DESIGN.md "Frozen conventions").  With A2 = -0.5 log2e A etc.:
-          //   dG/ddx = -G (A dx + B dy) = G (2 A2 dx + B2 dy) / log2e
-          const float gL = oG * dLa;                     // dL/dG * G  (opacity folded in)
-          const float gs = gL * (1.f / LOG2E);
-          v[0] = gs * fma_(2.f * a.z, dx, a.w * dy);      // d mean2d.x (dx = mean - pixel)
-          v[1] = gs * fma_(2.f * c.x, dy, a.w * dx);      // d mean2d.y
-          const float hx = -0.5f * gL * dx;
-          v[2] = hx * dx;                                 // d conic.a
-          v[3] = 2.f * hx * dy;                           // d conic.b (B multiplies dx*dy once)
-          v[4] = -0.5f * gL * dy * dy;                    // d conic.c
-          v[5] = G * dLa;                                 // d opacity
-        }
-      }
+      const float dx = a.x - fx, dy = a.y - fy;
+      const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
+      const float e = p2 + c.y;
+      const bool hit = contributor <= last && p2 <= 0.f && e >= LOG2_INV255;
       if (__ballot(hit) == 0ull) continue;  // nobody in this quadrant was touched: nothing to reduce
-#pragma unroll
-      for (int q = 0; q < 9; ++q) {
-        float x = v[q];
-        x += dpp_mov<0x111>(x);  // row_shr:1
-        x += dpp_mov<0x112>(x);  // row_shr:2
-        x += dpp_mov<0x114>(x);  // row_shr:4  -> lanes 7, 15, ..., 63 hold the sums of their 8-lane groups
-        v[q] = x;
+      if (hit) {
+        const float G = __builtin_amdgcn_exp2f(p2);
+        const float oG = cb.y * G;                              // opacity * G
+        const float alpha = fminf(0.99f, oG);
+        const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
+        T = T * r1a;
+        const float w = alpha * T;
+        v[6] = w * dL0; v[7] = w * dL1; v[8] = w * dL2;  // dL/dcolour
+        acc0 = fma_(la, lc0, (1.f - la) * acc0);
+        acc1 = fma_(la, lc1, (1.f - la) * acc1);
+        acc2 = fma_(la, lc2, (1.f - la) * acc2);
+        lc0 = c.z; lc1 = c.w; lc2 = cb.x; la = alpha;
+        float dLa = (c.z - acc0) * dL0 + (c.w - acc1) * dL1 + (cb.x - acc2) * dL2;
+        dLa = fma_(dLa, T, -(T_final * r1a) * bgdot);
+        // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream
+        // rasteriser does (DESIGN.md "Frozen conventions").  With A2 = -0.5 log2e A etc.:
+        //   dG/ddx = -G (A dx + B dy) = G (2 A2 dx + B2 dy) / log2e
+        const float gL = oG * dLa;                     // dL/dG * G  (opacity folded in)
+        const float gs = gL * (1.f / LOG2E);
+        v[0] = gs * fma_(2.f * a.z, dx, a.w * dy);      // d mean2d.x (dx = mean - pixel)
+        v[1] = gs * fma_(2.f * c.x, dy, a.w * dx);      // d mean2d.y
+        const float hx = -0.5f * gL * dx;
+        v[2] = hx * dx;                                 // d conic.a
+        v[3] = 2.f * hx * dy;                           // d conic.b (B multiplies dx*dy once)
+        v[4] = -0.5f * gL * dy * dy;                    // d conic.c
+        v[5] = G * dLa;                                 // d opacity
       }
+      reduce9_groups_of_8(v);   // lanes 7, 15, ..., 63 hold the sums of their 8-lane groups
       if ((lane & 7) == 7) {
         float* dst = &red[n_pending][lane >> 3][0];
 #pragma unroll
