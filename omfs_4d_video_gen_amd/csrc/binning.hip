@@ -14,77 +14,95 @@
 namespace omfs {
 
 // ------------------------------------------------------------------ scan + launch order
+// One workgroup.  Thread t owns the SCAN_PER consecutive tiles starting at t * per; their counts are loaded once
+// (independent loads, one round trip) and stay in registers for all phases:
+//   1. exclusive scan of the counts -> tile_start, tile_cursor = 0, overflow flag;
+//   2. launch order: tiles sorted by descending log2 bucket of their count (heavy tiles first).  One 64-bit LDS
+//      atomic per tile hands out the position inside the bucket (low word) together with the number of
+//      OMFS_SEG-entry list segments of the tiles in front of it (high word), so
+//   3. order_seg0[p] = segments owned by the tiles before position p of the launch order (order_seg0[n_tiles] =
+//      total) needs no further pass.  The backward pass launches one wave per (segment, quadrant) and finds its
+//      tile by bisection in this array.
+constexpr int SCAN_PER = 8;   // tiles per thread held in registers (n_tiles <= 8192; larger images loop)
+
 __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* __restrict__ tile_count,
                                                          uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ tile_cursor,
                                                          uint32_t* __restrict__ tile_order, uint32_t dup_capacity,
                                                          uint32_t* __restrict__ status, uint32_t* __restrict__ order_seg0) {
   __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t bucket_cnt[33];
-  __shared__ uint32_t bucket_off[33];
+  __shared__ unsigned long long bucket_acc[33];   // low: tiles in the bucket, high: their segments; then running bases
+  __shared__ uint32_t carry;                      // tiles / pairs of the chunks before (images with > 8192 tiles)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int per = (n_tiles + 1023) / 1024;
-  const int beg = min(n_tiles, tid * per), end = min(n_tiles, beg + per);
-  if (tid < 33) bucket_cnt[tid] = 0;
-  uint32_t sum = 0;
-  for (int t = beg; t < end; ++t) sum += tile_count[t];
-  uint32_t incl = wave_incl_scan_u32(sum, lane);
-  if (lane == 63) wave_tot[wave] = incl;
+  if (tid < 33) bucket_acc[tid] = 0ull;
+  if (tid == 0) carry = 0;
   __syncthreads();
-  uint32_t base = 0, total = 0;
-  for (int w = 0; w < 16; ++w) {
-    uint32_t v = wave_tot[w];
-    if (w < wave) base += v;
-    total += v;
+  // ---- pass A over chunks of 8192 tiles: scan + bucket totals
+  uint32_t total = 0;
+  uint32_t cnt[SCAN_PER];
+  const bool single = n_tiles <= 1024 * SCAN_PER;   // then cnt[] still holds this thread's counts in pass B
+  for (int c0 = 0; c0 < n_tiles; c0 += 1024 * SCAN_PER) {
+    const int beg = c0 + tid * SCAN_PER;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) { cnt[k] = beg + k < n_tiles ? tile_count[beg + k] : 0u; }
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) sum += cnt[k];
+    const uint32_t incl = wave_incl_scan_u32(sum, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = carry, chunk_total = 0;
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t v = wave_tot[w];
+      if (w < wave) base += v;
+      chunk_total += v;
+    }
+    uint32_t run = base + incl - sum;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+      if (beg + k < n_tiles) {
+        tile_start[beg + k] = run;       // rewritten as 0 below if the capacity overflows
+        tile_cursor[beg + k] = 0;
+        const uint32_t c = cnt[k];
+        const int bucket = c ? (32 - __clz(c)) : 0;  // 0..32, larger = more work
+        atomicAdd(&bucket_acc[32 - bucket], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
+        run += c;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) carry += chunk_total;
+    __syncthreads();
   }
+  total = carry;
   const bool overflow = total > dup_capacity;
-  uint32_t run = base + incl - sum;
-  for (int t = beg; t < end; ++t) {
-    uint32_t c = tile_count[t];
-    if (overflow) { c = 0; tile_count[t] = 0; }
-    tile_start[t] = overflow ? 0u : run;
-    tile_cursor[t] = 0;
-    run += c;
-    int bucket = c ? (32 - __clz(c)) : 0;  // 0..32, larger = more work
-    atomicAdd(&bucket_cnt[32 - bucket], 1u);
-  }
   if (tid == 0) {
     tile_start[n_tiles] = overflow ? 0u : total;
     if (overflow) atomicOr(status, OMFS_STATUS_DUP_OVERFLOW);
+    unsigned long long r = 0ull;   // exclusive scan over the buckets, both words at once
+    for (int b = 0; b < 33; ++b) {
+      const unsigned long long v = overflow ? 0ull : bucket_acc[b];   // on overflow every list is emptied: one bucket
+      bucket_acc[b] = r;
+      r += v;
+    }
+    order_seg0[n_tiles] = overflow ? 0u : (uint32_t)(r >> 32);
   }
   __syncthreads();
-  if (tid == 0) {
-    uint32_t r = 0;
-    for (int b = 0; b < 33; ++b) { bucket_off[b] = r; r += bucket_cnt[b]; }
+  // ---- pass B: positions in the launch order (+ segment prefix); counts are re-read only for images with > 8192 tiles
+  for (int c0 = 0; c0 < n_tiles; c0 += 1024 * SCAN_PER) {
+    const int beg = c0 + tid * SCAN_PER;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+      if (beg + k < n_tiles) {
+        uint32_t c = single ? cnt[k] : tile_count[beg + k];
+        if (overflow) { c = 0; tile_count[beg + k] = 0; tile_start[beg + k] = 0; }
+        const int bucket = c ? (32 - __clz(c)) : 0;
+        const unsigned long long old = atomicAdd(&bucket_acc[32 - bucket], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
+        const uint32_t pos = (uint32_t)old;
+        tile_order[pos] = (uint32_t)(beg + k);
+        order_seg0[pos] = (uint32_t)(old >> 32);
+      }
+    }
   }
-  __syncthreads();
-  for (int t = beg; t < end; ++t) {
-    uint32_t c = tile_count[t];
-    int bucket = c ? (32 - __clz(c)) : 0;
-    uint32_t pos = atomicAdd(&bucket_off[32 - bucket], 1u);
-    tile_order[pos] = (uint32_t)t;
-  }
-  // ---- backward segments: order_seg0[p] = number of OMFS_SEG-entry list segments owned by the tiles before
-  // position p of the launch order (heavy tiles first); order_seg0[n_tiles] = total.  The backward pass
-  // launches one wave per (segment, quadrant) and finds its tile by bisection in this array.
-  __syncthreads();
-  uint32_t ssum = 0;
-  for (int p = beg; p < end; ++p) ssum += (tile_count[tile_order[p]] + OMFS_SEG - 1) / OMFS_SEG;
-  const uint32_t sincl = wave_incl_scan_u32(ssum, lane);
-  if (lane == 63) wave_tot[wave] = sincl;
-  __syncthreads();
-  uint32_t sbase = 0, stotal = 0;
-  for (int w = 0; w < 16; ++w) {
-    const uint32_t v = wave_tot[w];
-    if (w < wave) sbase += v;
-    stotal += v;
-  }
-  uint32_t srun = sbase + sincl - ssum;
-  for (int p = beg; p < end; ++p) {
-    order_seg0[p] = srun;
-    srun += (tile_count[tile_order[p]] + OMFS_SEG - 1) / OMFS_SEG;
-  }
-  if (tid == 0) order_seg0[n_tiles] = stotal;
 }
 
 // ------------------------------------------------------------------ count + key scatter
