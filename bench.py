@@ -73,7 +73,7 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline_train(n_s=100000, w_s=800, h_s=450):
+def cpu_baseline_train(n_s=200000, w_s=1120, h_s=630):
     """PyTorch-CPU oracle: one full training iteration (render, L1+D-SSIM, autograd backward, Adam)
     on a bounded sample; returns (seconds, D_sample)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -273,7 +273,7 @@ def main():
 
     # ---- CPU baseline (rank 0, single GPU run only): the PyTorch-CPU oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_s, w_s, h_s = 100000, 800, 450     # ~10 s of CPU work on 16 cores, ~7 GB
+        n_s, w_s, h_s = 200000, 1120, 630    # ~15 s of CPU work on 16 cores
         sec, D_s = cpu_baseline_train(n_s, w_s, h_s)
         log(f"cpu baseline done: {sec:.2f}s")
         scale = D_s / max(D, 1)
