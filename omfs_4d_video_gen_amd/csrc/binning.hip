@@ -323,6 +323,83 @@ __device__ __forceinline__ uint2* radix_sort_pairs(uint2* a, uint2* b, int n, vo
   return src;
 }
 
+// Distribution sort for lists that fit in LDS.  Depths inside one tile spread almost uniformly between the tile's
+// nearest and farthest splat, so ONE monotone bucket pass -- bucket = floor((key - min) * NB / (max - min + 1)),
+// NB = 4 NT buckets (about one key per bucket) -- followed by ranking inside each bucket, by (depth
+// bits, id), replaces the 3-4 counting passes of the radix sort: the result is the same total order.  Returns
+// nullptr (input untouched in a) when some bucket holds more than BUCKET_MAX keys (many equal or clustered depths);
+// the caller then falls back to the radix sort.  hist: NB words, misc: 8 words.
+constexpr int BUCKET_MAX = 48;
+
+template <int NT>
+__device__ __forceinline__ uint2* bucket_sort_pairs(uint2* a, uint2* b, int n, volatile uint32_t* hist,
+                                                    volatile uint32_t* misc) {
+  constexpr int NB = (NT / 64) * 256;
+  constexpr int NW = NT / 64;
+  constexpr int PER = NB / NT;   // 4 consecutive buckets per thread in the scan
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- key range
+  uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+  for (int k = tid; k < n; k += NT) { const uint32_t x = a[k].x; kmin = min(kmin, x); kmax = max(kmax, x); }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
+    kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, d, 64));
+  }
+  for (int k = tid; k < NB; k += NT) hist[k] = 0;
+  if (tid == 0) { misc[0] = 0xFFFFFFFFu; misc[1] = 0u; misc[2] = 0u; }
+  __syncthreads();
+  if (lane == 0) { atomicMin((uint32_t*)&misc[0], kmin); atomicMax((uint32_t*)&misc[1], kmax); }
+  __syncthreads();
+  kmin = misc[0];
+  const float scale = (float)NB / ((float)(misc[1] - kmin) + 1.f);
+  auto bucket_of = [&](uint32_t x) { return min(NB - 1, (int)((float)(x - kmin) * scale)); };   // monotone in x
+  // ---- histogram
+  for (int k = tid; k < n; k += NT) atomicAdd((uint32_t*)&hist[bucket_of(a[k].x)], 1u);
+  __syncthreads();
+  // ---- exclusive scan over the buckets (thread t owns buckets PER t .. PER t + PER - 1)
+  uint32_t c[PER], sum = 0, big = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { c[j] = hist[tid * PER + j]; sum += c[j]; big = max(big, c[j]); }
+  const uint32_t incl = wave_incl_scan_u32(sum, lane);
+  if (big > (uint32_t)BUCKET_MAX) misc[2] = 1u;
+  __syncthreads();                               // every count is in registers: hist can be reused
+  if (lane == 63) hist[wave] = incl;             // wave totals
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += hist[w];
+  const bool fallback = misc[2] != 0u;
+  __syncthreads();                               // totals consumed before the cursors overwrite them
+  if (fallback) return nullptr;
+  uint32_t run = base + incl - sum;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { hist[tid * PER + j] = run; run += c[j]; }   // cursor = first slot of the bucket
+  __syncthreads();
+  // ---- placement (order inside a bucket is arbitrary)
+  for (int k = tid; k < n; k += NT) {
+    const uint2 item = a[k];
+    const uint32_t pos = atomicAdd((uint32_t*)&hist[bucket_of(item.x)], 1u);
+    b[pos] = item;
+  }
+  __syncthreads();
+  // ---- inside the buckets: every key counts the keys of its bucket that precede it in (depth bits, id) order and
+  // moves to that rank (all keys in parallel, independent LDS reads); cursor[bkt] is now the END of bucket bkt
+  uint2* out = a;                               // the input buffer is free
+  for (int k = tid; k < n; k += NT) {
+    const uint2 it = b[k];
+    const int bkt = bucket_of(it.x);
+    const int e = (int)hist[bkt], s0 = bkt ? (int)hist[bkt - 1] : 0;
+    int rank = 0;
+    for (int j = s0; j < e; ++j) {
+      const uint2 o = b[j];
+      rank += (o.x < it.x || (o.x == it.x && o.y < it.y)) ? 1 : 0;
+    }
+    out[s0 + rank] = it;
+  }
+  __syncthreads();
+  return out;
+}
+
 // Equal depth bits -> ascending Gaussian id (runs are almost always of length 1).
 template <int NT>
 __device__ __forceinline__ void fix_ties(uint2* s, int n) {
@@ -363,9 +440,15 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
   if (n <= lds_cap) {
     for (int k = tid; k < n; k += NT) bufA[k] = keys[s + k];
     __syncthreads();
-    uint2* res = n > 1 ? radix_sort_pairs<NT>(bufA, bufB, n, hist, misc) : bufA;
-    fix_ties<NT>(res, n);
-    __syncthreads();
+    uint2* res = bufA;
+    if (n > 1) {
+      res = bucket_sort_pairs<NT>(bufA, bufB, n, hist, misc);
+      if (res == nullptr) {                     // clustered depths: counting passes instead (uniform over the workgroup)
+        res = radix_sort_pairs<NT>(bufA, bufB, n, hist, misc);
+        fix_ties<NT>(res, n);
+        __syncthreads();
+      }
+    }
     for (int k = tid; k < n; k += NT) sorted_ids[s + k] = res[k].y;
   } else {
     uint2* res = radix_sort_pairs<NT>(keys + s, keys_tmp + s, n, hist, misc);
@@ -376,7 +459,13 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
   }
 }
 
-constexpr int SORT_SMALL_NT = 256, SORT_SMALL_CAP = 2048;
+#ifndef OMFS_SORT_SMALL_NT
+#define OMFS_SORT_SMALL_NT 512
+#endif
+#ifndef OMFS_SORT_SMALL_CAP
+#define OMFS_SORT_SMALL_CAP 2048
+#endif
+constexpr int SORT_SMALL_NT = OMFS_SORT_SMALL_NT, SORT_SMALL_CAP = OMFS_SORT_SMALL_CAP;
 constexpr int SORT_LARGE_NT = 1024, SORT_LARGE_CAP_DEFAULT = 8960;
 constexpr size_t sort_lds_bytes(int cap, int nt) { return (size_t)cap * 16 + ((nt / 64) * 256 + 8) * 4; }
 
@@ -453,7 +542,7 @@ extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam,
 extern "C" int omfs_tile_sort(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
   if (int rc = check_bin_args(cam, rb)) return rc;
   const int n_tiles = cdiv(cam->width, OMFS_TILE) * cdiv(cam->height, OMFS_TILE);
-  // short lists: 256 threads, 2048 pairs in LDS (36 KB -> 4 workgroups per CU);
+  // short lists: 512 threads, 2048 pairs in LDS (40 KB -> 4 workgroups per CU);
   // long lists : 1024 threads, sort_lds_pairs pairs in LDS (default 8960 = 160 KB, one workgroup per CU)
   const int cap_large = rb->sort_lds_pairs ? (int)rb->sort_lds_pairs : SORT_LARGE_CAP_DEFAULT;
   OMFS_REQUIRE(cap_large >= 256 && sort_lds_bytes(cap_large, SORT_LARGE_NT) <= 160 * 1024, "sort_lds_pairs");
