@@ -270,6 +270,31 @@ def main():
         log("render aux done")
         out["aux"] = {"render_surgery_fps": round(args.render_frames / dtr, 2),
                       "render_note": f"{args.render_frames} frames {W}x{H}, {N} Gaussians, GPU-resident rgb8 output, PNG encode excluded"}
+        if world == 1:
+            # the same loop with the PNG egress render.py uses (device->host copy + zlib level 1 on a thread pool), bounded sample
+            from concurrent.futures import ThreadPoolExecutor
+            from omfs_4d_video_gen_amd.engine.io_formats import encode_png
+            n_png = min(64, len(frames))
+            with ThreadPoolExecutor(max_workers=host_cores()) as pool:
+                t2 = time.perf_counter()
+                futs = [pool.submit(encode_png, rr.render(v, rgb8=True).cpu().numpy()) for v in frames[:n_png]]
+                png_bytes = sum(len(f.result()) for f in futs)
+                dtp = time.perf_counter() - t2
+            out["aux"]["render_surgery_fps_with_png"] = round(n_png / dtp, 2)
+            out["aux"]["png_note"] = f"{n_png} frames incl. D2H copy and PNG encode on {host_cores()} host threads ({png_bytes / n_png / 1e6:.2f} MB/frame)"
+            # practical HBM ceiling: device-to-device copy of 1 GiB (read + write counted)
+            src = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(10):
+                dst.copy_(src)
+            torch.cuda.synchronize()
+            out["aux"]["hbm_copy_gbs"] = round(10 * 2 * src.numel() * 4 / (time.perf_counter() - t3) / 1e9, 1)
+            del src, dst
+            log("png / copy aux done")
 
     # ---- CPU baseline (rank 0, single GPU run only): the PyTorch-CPU oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
