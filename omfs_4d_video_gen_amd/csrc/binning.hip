@@ -335,7 +335,6 @@ template <int NT>
 __device__ __forceinline__ uint2* bucket_sort_pairs(uint2* a, uint2* b, int n, volatile uint32_t* hist,
                                                     volatile uint32_t* misc) {
   constexpr int NB = (NT / 64) * 256;
-  constexpr int NW = NT / 64;
   constexpr int PER = NB / NT;   // 4 consecutive buckets per thread in the scan
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- key range
