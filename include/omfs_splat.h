@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMFS_ABI_VERSION 2
+#define OMFS_ABI_VERSION 3
 #define OMFS_TILE 16
 #define OMFS_SEG 128     /* list entries per backward segment                                          */
 #define OMFS_NPLANES 59
@@ -179,9 +179,23 @@ typedef struct omfs_grad_buffers {
   const float* dimage;    /* [3][H][W] dL/dimage                                                   */
   float* densify_stats;   /* optional [2][n_pad]: += |d mean2d| in NDC-scaled units (x W/2, y H/2) and += 1
                              for every Gaussian visible in this view (adaptive density control); may be NULL */
+  float* dface;           /* optional [F][16]: += dL/d(triangle frame record) -- R row-major (9), centre (3), scale (1) --
+                             of each Gaussian's parent triangle (FLAME fine-tuning); caller zeroes; may be NULL */
 } omfs_grad_buffers;
 
 int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, const omfs_grad_buffers* gb, void* stream);
+
+/* FLAME fine-tuning (upstream GaussianAvatars optimises the per-timestep FLAME parameters together with the
+ * Gaussians; SURVEY.md section 8b names flame_lbs_bwd in the inner contract).  One frame at a time:
+ *   omfs_face_frames_bwd : dface [F][16] (from omfs_project_bwd) -> dverts [v_pad][4] += (atomics; caller zeroes)
+ *   omfs_flame_skin_bwd  : dverts -> dv_shaped [V][3] (gradient of the blend-shaped vertices, overwritten) and
+ *                          sums[64] += { d joint_xf [5][12], d translation [3], pad } (caller zeroes)
+ * v_shaped [V][3] = v_static + basis . coef and joint_xf [60] of the frame are supplied by the host (it needs them
+ * anyway to chain the gradient through the 5-joint kinematic tree and the axis-angle map). */
+int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t* faces, int n_faces, const float* dface,
+                         float* dverts, void* stream);
+int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, const float* dverts,
+                        float* dv_shaped, float* sums, void* stream);
 
 typedef struct omfs_reg_params {
   float lambda_xyz, thr_xyz, lambda_scale, thr_scale;

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see module d
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 NPLANES = 59
 TILE = 16
 SEG = 128
@@ -60,7 +60,8 @@ class RasterBuffersC(C.Structure):
 
 
 class GradBuffersC(C.Structure):
-    _fields_ = [("dsplat", c_void_p), ("grads", c_void_p), ("dimage", c_void_p), ("densify_stats", c_void_p)]
+    _fields_ = [("dsplat", c_void_p), ("grads", c_void_p), ("dimage", c_void_p), ("densify_stats", c_void_p),
+                ("dface", c_void_p)]
 
 
 class RegParamsC(C.Structure):
@@ -80,6 +81,8 @@ SIGNATURES = {
     "omfs_flame_joints": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p]),
     "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p]),
     "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
+    "omfs_face_frames_bwd": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "omfs_flame_skin_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_simpleflame_fwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 5 + [C.c_int, c_void_p, c_void_p, c_void_p]),
     "omfs_simpleflame_bwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 3 + [C.c_int] + [c_void_p] * 7),
     "omfs_project_fwd": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),

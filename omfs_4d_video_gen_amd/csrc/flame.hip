@@ -177,6 +177,104 @@ __global__ void face_frames_kernel(const float* __restrict__ verts, int v_pad, c
   o[3] = make_float4(scale, 0.f, 0.f, 0.f);
 }
 
+// ---- backward (FLAME fine-tuning), one frame.  One thread per face: gradient of the frame record
+// (R columns a0, n, a2; centre; scale) w.r.t. the three vertices, added into dverts with float atomics
+// (a vertex belongs to ~6 faces).  The clamps of safe_normalize3 are not differentiated.
+__global__ void face_frames_bwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int n_faces,
+                                       const float* __restrict__ dface, float* __restrict__ dverts) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= n_faces) return;
+  const float4* vb = reinterpret_cast<const float4*>(verts);
+  const int i0 = faces[f * 3 + 0], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
+  const float4 v0 = vb[i0], v1 = vb[i1], v2 = vb[i2];
+  const float* g = dface + (size_t)f * 16;
+  float da0[3] = {g[0], g[3], g[6]}, dn[3] = {g[1], g[4], g[7]}, da2[3] = {g[2], g[5], g[8]};
+  const float dc[3] = {g[9], g[10], g[11]};
+  const float ds = g[12];
+  auto cross = [](const float* a, const float* b, float* o) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+  };
+  auto dot = [](const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; };
+  const float e1[3] = {v1.x - v0.x, v1.y - v0.y, v1.z - v0.z}, e2[3] = {v2.x - v0.x, v2.y - v0.y, v2.z - v0.z};
+  const float L1 = sqrtf(fmaxf(dot(e1, e1), 1e-20f));
+  const float a0[3] = {e1[0] / L1, e1[1] / L1, e1[2] / L1};
+  float m[3]; cross(a0, e2, m);
+  const float Ln = sqrtf(fmaxf(dot(m, m), 1e-20f));
+  const float n[3] = {m[0] / Ln, m[1] / Ln, m[2] / Ln};
+  float p[3]; cross(n, a0, p);
+  const float Lp = sqrtf(fmaxf(dot(p, p), 1e-20f));
+  const float a2[3] = {-p[0] / Lp, -p[1] / Lp, -p[2] / Lp};
+  const float h = dot(a2, e2);
+  // scale = (L1 + |h|) / 2
+  const float dL1 = 0.5f * ds, dh = 0.5f * ds * (h > 0.f ? 1.f : (h < 0.f ? -1.f : 0.f));
+  float de2[3];
+  for (int k = 0; k < 3; ++k) { da2[k] += dh * e2[k]; de2[k] = dh * a2[k]; }
+  // a2 = -p / |p|
+  const float t2 = dot(a2, da2);
+  float dp[3];
+  for (int k = 0; k < 3; ++k) dp[k] = -(da2[k] - a2[k] * t2) / Lp;
+  // p = n x a0
+  float tmp[3];
+  cross(a0, dp, tmp); for (int k = 0; k < 3; ++k) dn[k] += tmp[k];
+  cross(dp, n, tmp);  for (int k = 0; k < 3; ++k) da0[k] += tmp[k];
+  // n = m / |m|
+  const float tn = dot(n, dn);
+  float dm[3];
+  for (int k = 0; k < 3; ++k) dm[k] = (dn[k] - n[k] * tn) / Ln;
+  // m = a0 x e2
+  cross(e2, dm, tmp); for (int k = 0; k < 3; ++k) da0[k] += tmp[k];
+  cross(dm, a0, tmp); for (int k = 0; k < 3; ++k) de2[k] += tmp[k];
+  // a0 = e1 / |e1|, L1 = |e1|
+  const float t0 = dot(a0, da0);
+  float de1[3];
+  for (int k = 0; k < 3; ++k) de1[k] = (da0[k] - a0[k] * t0) / L1 + dL1 * a0[k];
+  const float third = 1.0f / 3.0f;
+  for (int k = 0; k < 3; ++k) {
+    const float c3 = dc[k] * third;
+    atomicAdd(&dverts[(size_t)i0 * 4 + k], c3 - de1[k] - de2[k]);
+    atomicAdd(&dverts[(size_t)i1 * 4 + k], c3 + de1[k]);
+    atomicAdd(&dverts[(size_t)i2 * 4 + k], c3 + de2[k]);
+  }
+}
+
+// One thread per vertex: v_posed = M_v [v_shaped; 1] + ..., M_v = sum_j w_vj X_j.  Writes dv_shaped = M_v(3x3)^T dv
+// and accumulates d X_j = w_vj dv (x) [v_shaped; 1] and d translation = dv (63 sums: LDS atomics per block, then one
+// global atomic per value and block).
+__global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __restrict__ lbs_weights, const float* __restrict__ v_shaped,
+                                                             const float* __restrict__ joint_xf, const float* __restrict__ dverts,
+                                                             int n_verts, float* __restrict__ dv_shaped, float* __restrict__ sums) {
+  __shared__ float acc[64];
+  __shared__ float X[60];
+  if (threadIdx.x < 64) acc[threadIdx.x] = 0.f;
+  if (threadIdx.x < 60) X[threadIdx.x] = joint_xf[threadIdx.x];
+  __syncthreads();
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < n_verts) {
+    const float* w = lbs_weights + (size_t)v * 8;
+    const float dv[3] = {dverts[(size_t)v * 4 + 0], dverts[(size_t)v * 4 + 1], dverts[(size_t)v * 4 + 2]};
+    const float vs[4] = {v_shaped[(size_t)v * 3 + 0], v_shaped[(size_t)v * 3 + 1], v_shaped[(size_t)v * 3 + 2], 1.f};
+    float out[3] = {0.f, 0.f, 0.f};
+    for (int j = 0; j < 5; ++j) {
+      const float wj = w[j];
+      if (wj == 0.f) continue;
+      for (int r = 0; r < 3; ++r) {
+        const float g = wj * dv[r];
+        for (int c = 0; c < 3; ++c) {
+          out[c] = fma_(X[j * 12 + r * 3 + c], g, out[c]);
+          atomicAdd(&acc[j * 12 + r * 3 + c], g * vs[c]);
+        }
+        atomicAdd(&acc[j * 12 + 9 + r], g);
+      }
+    }
+    for (int c = 0; c < 3; ++c) {
+      dv_shaped[(size_t)v * 3 + c] = out[c];
+      atomicAdd(&acc[60 + c], dv[c]);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 63) atomicAdd(&sums[threadIdx.x], acc[threadIdx.x]);
+}
+
 }  // namespace omfs
 
 using namespace omfs;
@@ -211,6 +309,26 @@ extern "C" int omfs_face_frames(const float* verts, int v_pad, const int32_t* fa
   OMFS_REQUIRE(n_faces > 0 && n_frames > 0 && v_pad > 0, "shape");
   hipLaunchKernelGGL(face_frames_kernel, dim3(cdiv(n_faces, 256), n_frames), dim3(256), 0, (hipStream_t)stream, verts,
                      v_pad, faces, n_faces, n_frames, face_xf);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t* faces, int n_faces, const float* dface,
+                                    float* dverts, void* stream) {
+  OMFS_REQUIRE(verts && faces && dface && dverts, "null pointer");
+  OMFS_REQUIRE(n_faces > 0 && v_pad > 0, "shape");
+  hipLaunchKernelGGL(face_frames_bwd_kernel, dim3(cdiv(n_faces, 256)), dim3(256), 0, (hipStream_t)stream, verts, faces,
+                     n_faces, dface, dverts);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf,
+                                   const float* dverts, float* dv_shaped, float* sums, void* stream) {
+  OMFS_REQUIRE(rig && v_shaped && joint_xf && dverts && dv_shaped && sums, "null pointer");
+  OMFS_REQUIRE(rig->n_verts > 0 && rig->lbs_weights, "rig");
+  hipLaunchKernelGGL(flame_skin_bwd_kernel, dim3(cdiv(rig->n_verts, 256)), dim3(256), 0, (hipStream_t)stream,
+                     rig->lbs_weights, v_shaped, joint_xf, dverts, rig->n_verts, dv_shaped, sums);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -5,9 +5,9 @@
 // regularisers are folded in here, so no extra pass over the
 // parameters exists.  Algorithmic bytes per Gaussian: 64 + 240 + 236 (+ face record, L2).
 //
-// Spec: SURVEY.md Appendix A item 7 (projection / deformation backward).  Gradients flow to the
-// Gaussian parameters only; the triangle frames (FLAME fine-tuning) are treated as constants
-// (DESIGN.md "Out of scope this round").
+// Spec: SURVEY.md Appendix A item 7 (projection / deformation backward).  With gb->dface the gradient
+// w.r.t. the parent triangle's frame record is accumulated as well (FLAME fine-tuning: flame.hip,
+// omfs_face_frames_bwd / omfs_flame_skin_bwd).
 #include "common.hpp"
 
 namespace omfs {
@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
                                                           const float4* __restrict__ dsplat, RegK reg,
                                                           const uint32_t* __restrict__ n_visible,
                                                           float* __restrict__ grads, float* __restrict__ densify_stats,
-                                                          float half_w, float half_h) {
+                                                          float half_w, float half_h, float* __restrict__ dface) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   auto P = [&](int plane) { return params[(size_t)plane * n_pad + i]; };
@@ -201,7 +201,26 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
     }
   }
   // scale: dL/ds_k = sum_r dM[r][k] Rw[r][k];  s = exp(ls) sf
-  for (int k = 0; k < 3; ++k) dls[k] = (dM[k] * Rw[k] + dM[3 + k] * Rw[3 + k] + dM[6 + k] * Rw[6 + k]) * s[k];
+  float dsk[3];   // dL/ds_k, s_k = exp(ls_k) sf
+  for (int k = 0; k < 3; ++k) {
+    dsk[k] = dM[k] * Rw[k] + dM[3 + k] * Rw[3 + k] + dM[6 + k] * Rw[6 + k];
+    dls[k] = dsk[k] * s[k];
+  }
+  if (dface) {
+    // triangle frame record (FLAME fine-tuning): mu = sf Rf l + cf, M = Rf (Q diag(s)), s = exp(ls) sf
+    float* df = dface + (size_t)binding[i] * 16;
+    float dsf = dsk[0] * es[0] + dsk[1] * es[1] + dsk[2] * es[2];
+    for (int r = 0; r < 3; ++r) {
+      dsf = fma_(dmu[r], dot3_(Rf[r * 3], Rf[r * 3 + 1], Rf[r * 3 + 2], l[0], l[1], l[2]), dsf);
+      for (int cc = 0; cc < 3; ++cc) {
+        float gR = sf * dmu[r] * l[cc];
+        for (int k = 0; k < 3; ++k) gR = fma_(dM[r * 3 + k], Q[cc * 3 + k] * s[k], gR);
+        atomicAdd(&df[r * 3 + cc], gR);
+      }
+      atomicAdd(&df[9 + r], dmu[r]);
+    }
+    atomicAdd(&df[12], dsf);
+  }
   if (reg.lambda_scale != 0.f) {
     const float u0 = fmaxf(es[0] - reg.thr_scale, 0.f), u1 = fmaxf(es[1] - reg.thr_scale, 0.f), u2 = fmaxf(es[2] - reg.thr_scale, 0.f);
     const float un = sqrtf(u0 * u0 + u1 * u1 + u2 * u2);
@@ -245,7 +264,7 @@ extern "C" int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, c
   RegK rk{reg->lambda_xyz, reg->thr_xyz, reg->lambda_scale, reg->thr_scale};
   hipLaunchKernelGGL(project_bwd_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, (hipStream_t)stream, g->n, g->n_pad,
                      g->params, g->binding, face_xf, pc, (const float4*)rb->g2, (const float4*)gb->dsplat, rk,
-                     reg->n_visible, gb->grads, gb->densify_stats, 0.5f * (float)cam->width, 0.5f * (float)cam->height);
+                     reg->n_visible, gb->grads, gb->densify_stats, 0.5f * (float)cam->width, 0.5f * (float)cam->height, gb->dface);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -139,8 +139,9 @@ class Rasterizer:
         return self.loss
 
     def backward(self, model: GaussianModel, face_xf: torch.Tensor, cam: L.CameraC, grads: torch.Tensor,
-                 dimage: torch.Tensor | None = None, reg=(0.01, 1.0, 1.0, 0.6)):
-        """dL/dimage (default: self.dimage from loss_l1_ssim) -> grads [59][n_pad] (overwritten)."""
+                 dimage: torch.Tensor | None = None, reg=(0.01, 1.0, 1.0, 0.6), dface: torch.Tensor | None = None):
+        """dL/dimage (default: self.dimage from loss_l1_ssim) -> grads [59][n_pad] (overwritten);
+        dface [F][16] (optional, zeroed by the caller) += dL/d(triangle frame records)."""
         self._ensure_bwd()
         lib = L.load()
         s = L.stream_ptr()
@@ -150,7 +151,7 @@ class Rasterizer:
         if grads.shape != (NPLANES, model.n_pad) or grads.dtype != torch.float32 or not grads.is_contiguous():
             raise ValueError("grads must be a contiguous float32 [59][n_pad] tensor")
         self.dsplat.zero_()
-        gb = L.GradBuffersC(L.ptr(self.dsplat), L.ptr(grads), L.ptr(dimg), 0)
+        gb = L.GradBuffersC(L.ptr(self.dsplat), L.ptr(grads), L.ptr(dimg), 0, L.ptr(dface))
         L.check(lib.omfs_composite_bwd(cam, self.rb, gb, s), "omfs_composite_bwd")
         L.check(lib.omfs_count_visible(self.rb, self.n, L.ptr(self.n_visible), s), "omfs_count_visible")
         rp = L.RegParamsC(float(reg[0]), float(reg[1]), float(reg[2]), float(reg[3]), L.ptr(self.n_visible))

@@ -76,7 +76,7 @@ class Trainer:
                  reg=(0.01, 1.0, 1.0, 0.6), position_lr_init=5e-3, position_lr_final=5e-5,
                  sh_degree_max: int = 3, sh_increase_every: int = 1000, start_sh_degree: int = 0,
                  dup_capacity: int | None = None, rank: int = 0, world_size: int = 1, process_group=None,
-                 n_capacity: int | None = None):
+                 n_capacity: int | None = None, finetune_flame: bool = False, flame_lr: dict | None = None):
         self.device = torch.device(device)
         self.rank, self.world = rank, world_size
         self.pg = process_group
@@ -98,6 +98,10 @@ class Trainer:
         self.timer = StageTimer(False)
         self._cams = {}
         self.densify_stats = None      # [2][n_pad] when adaptive density control is on (engine/densify.py)
+        self.flame_ft = None           # FLAME-parameter fine-tuning (engine/flame_finetune.py)
+        if finetune_flame:
+            from .flame_finetune import FlameFineTuner
+            self.flame_ft = FlameFineTuner(self.dflame, flame_params, flame_lr)
 
     def _cam(self, view: View, sh_degree: int):
         key = (id(view), sh_degree)
@@ -120,7 +124,10 @@ class Trainer:
         cam = self._cam(view, self.sh_degree)
         r, tm = self.rast, self.timer
         tm.begin()
-        _, face_xf = self.dflame.face_frames(view.timestep, 1)
+        ft = self.flame_ft
+        if ft is not None:
+            ft.begin(view.timestep)    # current parameters of this timestep -> the rows the FLAME kernels read
+        verts, face_xf = self.dflame.face_frames(view.timestep, 1)
         tm.mark("flame")
         fxf = face_xf[0]
         r.project(self.model, fxf, cam); tm.mark("project")
@@ -136,19 +143,28 @@ class Trainer:
         r.loss.zero_()
         r.loss_l1_ssim(view.target, self.lambda_dssim); tm.mark("loss")
         r.dsplat.zero_()
-        gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats))
+        gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
+                            L.ptr(ft.dface) if ft is not None else 0)
         L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")
         L.check(lib.omfs_count_visible(r.rb, r.n, L.ptr(r.n_visible), s), "omfs_count_visible")
         rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
         L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
+        if ft is not None:
+            ft.backward(verts[0]); tm.mark("flame_bwd")
         if self.world > 1:
             from .distributed import allreduce_sum_
             allreduce_sum_(self.grads, self.pg)
+            if ft is not None:         # every rank touched a different timestep: dense (tiny) gradient tensors, summed
+                for gr in ft.grads():
+                    allreduce_sum_(gr, self.pg)
             tm.mark("allreduce")
         lr = expon_lr(it, self.pos_lr[0], self.pos_lr[1], self.iterations)
         self.lr_planes[0:3] = lr
         self.opt.set_lr(self.lr_planes)
-        self.opt.step(self.grads, 1.0 / self.world); tm.mark("adam")
+        self.opt.step(self.grads, 1.0 / self.world)
+        if ft is not None:
+            ft.step(1.0 / self.world)
+        tm.mark("adam")
         self.step_idx += 1
 
     def loss_value(self) -> float:
