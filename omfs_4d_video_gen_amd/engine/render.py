@@ -56,6 +56,29 @@ def find_iteration(model_path: str, wanted: int) -> int:
     return have[-1]
 
 
+TUNED_KEYS = ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation")
+
+
+def tuned_flame(pc_dir: Path, dataset_flame: dict) -> dict:
+    """FLAME sequence to render with.  A model trained with --finetune_flame_params stores the tuned sequence and the
+    sequence it started from; the dataset being rendered may carry edits (render_surgery rewrites translation / jaw):
+    render `tuned + (dataset - source)`.  Without tuned parameters, or when the sequences do not match, the dataset's."""
+    import numpy as np
+    src_p, tuned_p = pc_dir / "flame_param_source.npz", pc_dir / "flame_param.npz"
+    if not (src_p.exists() and tuned_p.exists()):
+        return dataset_flame
+    src, tuned = dict(np.load(src_p)), dict(np.load(tuned_p))
+    out = dict(dataset_flame)
+    for k in TUNED_KEYS:
+        if k not in dataset_flame or k not in src or k not in tuned:
+            continue
+        d, s0, t = (np.asarray(x, np.float32) for x in (dataset_flame[k], src[k], tuned[k]))
+        if s0.shape != t.shape or d.size != s0.size:
+            return dataset_flame
+        out[k] = (t + (d.reshape(s0.shape) - s0)).astype(np.float32)
+    return out
+
+
 def render_split(args, split_name: str, it: int, rank: int, world: int):
     import json
     from omfs_4d_video_gen_amd.engine import io_formats as IO
@@ -73,7 +96,8 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     out_dir = Path(args.model_path) / split_name / f"ours_{it}"
     (out_dir / "renders").mkdir(parents=True, exist_ok=True)
     (out_dir / "gt").mkdir(parents=True, exist_ok=True)
-    r = Renderer(load_rig(), split["flame"], g, w, h, bg=bg, sh_degree=args.sh_degree)
+    flame = tuned_flame(Path(args.model_path) / "point_cloud" / f"iteration_{it}", split["flame"])
+    r = Renderer(load_rig(), flame, g, w, h, bg=bg, sh_degree=args.sh_degree)
     pool = ThreadPoolExecutor(max_workers=max(1, args.png_workers))
     pending = []
     mine = range(rank, len(cams), world)

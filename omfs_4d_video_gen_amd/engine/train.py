@@ -9,7 +9,11 @@ Outputs (what `render_surgery.py:271-287` and `train_ghost.py:141-156` look for)
   M/point_cloud/iteration_<it>/point_cloud.ply (+ flame_param.npz), M/chkpnt<it>.pth, M/cfg_args.json.
 Progress lines contain "iteration <n>" for the UI regex (`app.py:1387-1398`).
 Multi-GPU: launch with torch.distributed.run; views shard across ranks, gradients are all-reduced.
-Not implemented this round: FLAME fine-tuning, resume from a checkpoint.
+`--finetune_flame_params` optimises the per-timestep FLAME expression / poses / translation with the Gaussians
+(upstream's default for --bind_to_mesh; opt-in here, `--not_finetune_flame_params` is accepted and ignored): the tuned
+sequence is saved as point_cloud/iteration_<it>/flame_param.npz next to flame_param_source.npz (as loaded), and
+render.py applies "tuned + (dataset - source)" so that render_surgery's edits still act on the tuned sequence.
+`--start_checkpoint M/chkpnt<it>.pth` resumes (parameters, Adam moments, SH degree, FLAME state, iteration).
 """
 from __future__ import annotations
 
@@ -50,6 +54,12 @@ def parse(argv=None):
     p.add_argument("--max_gaussians", type=int, default=0, help="capacity for densification (0 = 4x the initial count)")
     p.add_argument("--no_densify", action="store_true")
     p.add_argument("--log_every", type=int, default=100)
+    p.add_argument("--finetune_flame_params", action="store_true")
+    p.add_argument("--not_finetune_flame_params", action="store_true", help="accepted for upstream compatibility (the default here)")
+    p.add_argument("--flame_expr_lr", type=float, default=1e-3)
+    p.add_argument("--flame_pose_lr", type=float, default=1e-5)
+    p.add_argument("--flame_trans_lr", type=float, default=1e-6)
+    p.add_argument("--start_checkpoint", type=str, default=None)
     args, unknown = p.parse_known_args(argv)
     if unknown:
         print(f"[engine] ignoring unknown arguments: {unknown}")
@@ -132,11 +142,35 @@ def main(argv=None):
         views.append(View(cam, int(trow), target=rgb.cuda(), name=os.path.basename(fr["file_path"])))
     n = args.n_gaussians if args.n_gaussians > 0 else 10 * rig.n_faces
     g0 = initial_gaussians(n, rig.n_faces, args.seed)
+    ckpt = None
+    if args.start_checkpoint:
+        from omfs_4d_video_gen_amd.engine.gaussians import unpack_params
+        ckpt = torch.load(args.start_checkpoint, map_location="cpu", weights_only=False)
+        n = int(ckpt["binding"].shape[0])
+        g0 = unpack_params(ckpt["params"][:, :n].numpy())
+        g0["binding"] = ckpt["binding"].numpy()
     densify = not args.no_densify and args.iterations > args.densify_from_iter
     cap = (args.max_gaussians if args.max_gaussians > 0 else 4 * n) if densify else n
     trainer = Trainer(rig, split["flame"], g0, views, size[0], size[1], bg=bg, iterations=args.iterations,
                       sh_degree_max=args.sh_degree, start_sh_degree=0, rank=rank, world_size=world, process_group=pg,
-                      n_capacity=cap)
+                      n_capacity=cap, finetune_flame=args.finetune_flame_params,
+                      flame_lr={"expr": args.flame_expr_lr, "pose": args.flame_pose_lr, "translation": args.flame_trans_lr})
+    it0 = 0
+    if ckpt is not None:
+        it0 = int(ckpt["iteration"])
+        wcols = min(trainer.opt.m.shape[1], ckpt["adam_m"].shape[1])
+        trainer.opt.m[:, :wcols].copy_(ckpt["adam_m"][:, :wcols])
+        trainer.opt.v[:, :wcols].copy_(ckpt["adam_v"][:, :wcols])
+        trainer.opt.step_count = it0
+        trainer.sh_degree = int(ckpt["sh_degree"])
+        trainer.step_idx = it0
+        if trainer.flame_ft is not None and "flame" in ckpt:
+            ft = trainer.flame_ft
+            with torch.no_grad():
+                ft.expr.copy_(ckpt["flame"]["expr"]); ft.pose.copy_(ckpt["flame"]["pose"]); ft.translation.copy_(ckpt["flame"]["translation"])
+            ft.opt.load_state_dict(ckpt["flame"]["optimizer"])
+        if rank == 0:
+            print(f"[engine] resumed from {args.start_checkpoint} at iteration {it0} with {n} Gaussians", flush=True)
     controller = None
     if densify:
         from omfs_4d_video_gen_amd.engine.densify import DensityController, scene_extent
@@ -151,7 +185,7 @@ def main(argv=None):
             json.dump({**vars(args), "n_gaussians": n, "n_train_views": len(views), "world_size": world}, f, indent=2)
     save_at, ckpt_at = set(args.save_iterations) | {args.iterations}, set(args.checkpoint_iterations)
     t0 = time.time()
-    for it in range(1, args.iterations + 1):
+    for it in range(it0 + 1, args.iterations + 1):
         trainer.step()
         if controller is not None:
             n_before = trainer.model.n
@@ -161,18 +195,26 @@ def main(argv=None):
         if it % args.log_every == 0 or it == args.iterations:
             if rank == 0:
                 print(f"Training progress: iteration {it}/{args.iterations} loss={trainer.loss_value():.5f} "
-                      f"({it / (time.time() - t0):.1f} it/s)", flush=True)
+                      f"({(it - it0) / (time.time() - t0):.1f} it/s)", flush=True)
             if it % (10 * args.log_every) == 0:
                 trainer.rast.check_status()
         if rank == 0 and it in save_at:
             print(f"\n[ITER {it}] Saving Gaussians", flush=True)
             g = trainer.model.to_dict()
             IO.save_gaussian_ply(out / "point_cloud" / f"iteration_{it}" / "point_cloud.ply", g)
-            np.savez(out / "point_cloud" / f"iteration_{it}" / "flame_param.npz", **split["flame"])
+            pc_dir = out / "point_cloud" / f"iteration_{it}"
+            if trainer.flame_ft is not None:
+                np.savez(pc_dir / "flame_param.npz", **trainer.flame_ft.to_flame_params(split["flame"]))
+                np.savez(pc_dir / "flame_param_source.npz", **split["flame"])
+            else:
+                np.savez(pc_dir / "flame_param.npz", **split["flame"])
         if rank == 0 and it in ckpt_at:
             print(f"\n[ITER {it}] Saving Checkpoint", flush=True)
             torch.save({"iteration": it, "params": trainer.model.params.cpu(), "binding": trainer.model.binding.cpu(),
-                        "adam_m": trainer.opt.m.cpu(), "adam_v": trainer.opt.v.cpu(), "sh_degree": trainer.sh_degree},
+                        "adam_m": trainer.opt.m.cpu(), "adam_v": trainer.opt.v.cpu(), "sh_degree": trainer.sh_degree,
+                        **({"flame": {"expr": trainer.flame_ft.expr.detach().cpu(), "pose": trainer.flame_ft.pose.detach().cpu(),
+                                      "translation": trainer.flame_ft.translation.detach().cpu(),
+                                      "optimizer": trainer.flame_ft.opt.state_dict()}} if trainer.flame_ft is not None else {})},
                        out / f"chkpnt{it}.pth")
     torch.cuda.synchronize()
     trainer.rast.check_status()

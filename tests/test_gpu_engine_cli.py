@@ -116,3 +116,40 @@ def test_engine_failure_surfaces_as_runtime_error(dataset, tmp_path, monkeypatch
     (tmp_path / "empty_model").mkdir()
     with pytest.raises(RuntimeError, match="Rendering failed"):
         rs.render_with_gaussians(str(tmp_path / "empty_model"), str(dataset))
+
+
+def test_finetune_flame_checkpoint_resume_and_tuned_render(dataset, tmp_path, monkeypatch):
+    """engine/train.py --finetune_flame_params with a checkpoint, resumed run == uninterrupted run (up to the order
+    of float atomics); engine/render.py renders `tuned + (dataset - source)`."""
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    from omfs_4d_video_gen_amd.engine import render as R
+    env = {**os.environ, "OMFS_SYNTHETIC_RIG": "1", "PYTHONPATH": str(ROOT)}
+    train = str(ROOT / "omfs_4d_video_gen_amd" / "engine" / "train.py")
+    common = ["--source_path", str(dataset), "--bind_to_mesh", "--n_gaussians", "12000", "--log_every", "10", "--finetune_flame_params",
+              "--flame_trans_lr", "1e-4", "--flame_pose_lr", "1e-4", "--white_background"]
+    a, b = tmp_path / "a", tmp_path / "b"
+    r1 = subprocess.run([sys.executable, train, *common, "--model_path", str(a), "--iterations", "40", "--checkpoint_iterations", "25"],
+                        env=env, capture_output=True, text=True)
+    assert r1.returncode == 0, r1.stderr[-2000:]
+    assert (a / "chkpnt25.pth").exists()
+    r2 = subprocess.run([sys.executable, train, *common, "--model_path", str(b), "--iterations", "40",
+                         "--start_checkpoint", str(a / "chkpnt25.pth")], env=env, capture_output=True, text=True)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    assert "resumed from" in r2.stdout and "iteration 40/40" in r2.stdout
+    ga = IO.load_gaussian_ply(a / "point_cloud" / "iteration_40" / "point_cloud.ply")
+    gb = IO.load_gaussian_ply(b / "point_cloud" / "iteration_40" / "point_cloud.ply")
+    for k in ("xyz", "log_scale", "opacity", "sh"):    # Adam's sign-like first steps amplify the float-atomic noise
+        d = np.abs(ga[k] - gb[k])
+        assert d.mean() <= 2e-4 * max(1.0, np.abs(ga[k]).max()) and d.max() <= 5e-2, (k, d.mean(), d.max())
+    fa = dict(np.load(a / "point_cloud" / "iteration_40" / "flame_param.npz"))
+    fb = dict(np.load(b / "point_cloud" / "iteration_40" / "flame_param.npz"))
+    src = dict(np.load(a / "point_cloud" / "iteration_40" / "flame_param_source.npz"))
+    assert np.abs(fa["translation"] - src["translation"]).max() > 1e-5          # the parameters moved ...
+    assert np.abs(fa["translation"] - fb["translation"]).max() < 2e-4           # ... the same way in both runs
+    assert fa["expr"].shape == src["expr"].shape and set(fa) == set(src)
+    # render-time sequence: tuned + (dataset - source)
+    edited = {k: np.array(v) for k, v in src.items()}
+    edited["translation"] = edited["translation"] + np.array([0.0, 0.002, 0.0], np.float32)
+    out = R.tuned_flame(a / "point_cloud" / "iteration_40", edited)
+    assert np.allclose(out["translation"], fa["translation"] + np.array([0.0, 0.002, 0.0], np.float32), atol=1e-7)
+    assert np.allclose(out["expr"], fa["expr"])
