@@ -295,6 +295,19 @@ def main():
             out["aux"]["hbm_copy_gbs"] = round(10 * 2 * src.numel() * 4 / (time.perf_counter() - t3) / 1e9, 1)
             del src, dst
             log("png / copy aux done")
+            # the same training step with upstream's FLAME-parameter fine-tuning switched on (not the headline config)
+            del rr
+            tf = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3, finetune_flame=True)
+            for _ in range(20):
+                tf.step()
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            for _ in range(100):
+                tf.step()
+            torch.cuda.synchronize()
+            out["aux"]["train_iters_per_sec_with_flame_finetune"] = round(100 / (time.perf_counter() - t4), 2)
+            del tf
+            log("flame fine-tune aux done")
 
     # ---- CPU baseline (rank 0, single GPU run only): the PyTorch-CPU oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

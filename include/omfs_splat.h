@@ -74,10 +74,12 @@ int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, const float*
                       int n_frames, float* joint_xf, float* coef, void* stream);
 
 /* verts [n_frames][v_pad][4] = LBS(v_static + basis . coef) (+ dynamic_offset) + translation.
- * dynamic_offset may be NULL; layout [n_frames][V][3]. translation [n_frames][3]. */
+ * dynamic_offset may be NULL; layout [n_frames][V][3]. translation [n_frames][3].
+ * v_shaped_out (may be NULL): [n_frames][v_pad][4] the blend-shaped vertices in front of the skinning (kept for
+ * omfs_flame_skin_bwd). */
 int omfs_flame_lbs(const omfs_flame_rig* rig, const float* coef, const float* joint_xf,
                    const float* translation, const float* dynamic_offset, int n_frames,
-                   float* verts, void* stream);
+                   float* verts, float* v_shaped_out, void* stream);
 
 /* face_xf [n_frames][n_faces][16]: R row-major (columns a0,n,a2) 9, centre 3, scale 1, pad 3 */
 int omfs_face_frames(const float* verts, int v_pad, const int32_t* faces, int n_faces, int n_frames,
@@ -179,23 +181,36 @@ typedef struct omfs_grad_buffers {
   const float* dimage;    /* [3][H][W] dL/dimage                                                   */
   float* densify_stats;   /* optional [2][n_pad]: += |d mean2d| in NDC-scaled units (x W/2, y H/2) and += 1
                              for every Gaussian visible in this view (adaptive density control); may be NULL */
-  float* dface;           /* optional [F][16]: += dL/d(triangle frame record) -- R row-major (9), centre (3), scale (1) --
-                             of each Gaussian's parent triangle (FLAME fine-tuning); caller zeroes; may be NULL */
+  float* dface;           /* optional [n][16]: each Gaussian's contribution to dL/d(frame record of its parent triangle)
+                             -- R row-major (9), centre (3), scale (1) -- overwritten, no atomics (FLAME fine-tuning:
+                             omfs_face_frames_bwd sums them per triangle); may be NULL                            */
 } omfs_grad_buffers;
 
 int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, const omfs_grad_buffers* gb, void* stream);
 
 /* FLAME fine-tuning (upstream GaussianAvatars optimises the per-timestep FLAME parameters together with the
  * Gaussians; SURVEY.md section 8b names flame_lbs_bwd in the inner contract).  One frame at a time:
- *   omfs_face_frames_bwd : dface [F][16] (from omfs_project_bwd) -> dverts [v_pad][4] += (atomics; caller zeroes)
+ *   omfs_flame_rodrigues : axis-angle [n][3] -> rotation matrices [n][9] (the formula of flame_fitter.py:133-152)
+ *   omfs_face_frames_bwd : per-Gaussian records dface [n][16] (from omfs_project_bwd), summed per triangle through the
+ *                          CSR (face_start [F+1], face_gauss [n]: Gaussians sorted by parent triangle) -> dverts
+ *                          [v_pad][4] += (atomics; caller zeroes)
  *   omfs_flame_skin_bwd  : dverts -> dv_shaped [V][3] (gradient of the blend-shaped vertices, overwritten) and
- *                          sums[64] += { d joint_xf [5][12], d translation [3], pad } (caller zeroes)
- * v_shaped [V][3] = v_static + basis . coef and joint_xf [60] of the frame are supplied by the host (it needs them
- * anyway to chain the gradient through the 5-joint kinematic tree and the axis-angle map). */
+ *                          sums[64] += { d joint_xf [5][12], d translation [3], pad } (caller zeroes); v_shaped
+ *                          [v_pad][4] is the optional second output of omfs_flame_lbs, joint_xf [60] that of
+ *                          omfs_flame_joints for the frame
+ *   omfs_flame_param_bwd : dv_shaped, sums -> d expr [n_expr], d pose [5][3] (axis-angle: global, neck, jaw, eyes);
+ *                          dcoef [n_coef] is scratch.  d translation = sums[60..62].
+ *   omfs_adam_flat       : torch.optim.Adam step on a flat buffer (the FLAME parameter tensors) */
 int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t* faces, int n_faces, const float* dface,
-                         float* dverts, void* stream);
+                         const int32_t* face_start, const int32_t* face_gauss, float* dverts, void* stream);
 int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, const float* dverts,
                         float* dv_shaped, float* sums, void* stream);
+int omfs_flame_rodrigues(const float* axis_angle, int n, float* rotmats, void* stream);
+int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basis_dense, int n_coef, const float* dv_shaped,
+                         const float* expr, const float* pose, const float* sums, float* dcoef, float* dexpr, float* dpose,
+                         void* stream);
+int omfs_adam_flat(float* params, const float* grads, float* m, float* v, int n, float lr, float beta1, float beta2,
+                   float eps, int step, float grad_scale, void* stream);
 
 typedef struct omfs_reg_params {
   float lambda_xyz, thr_xyz, lambda_scale, thr_scale;

@@ -79,10 +79,16 @@ SIGNATURES = {
     "omfs_abi_version": (C.c_int, []),
     "omfs_last_error": (C.c_char_p, []),
     "omfs_flame_joints": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p]),
-    "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p]),
+    "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p,
+                                 c_void_p]),
     "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
-    "omfs_face_frames_bwd": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "omfs_face_frames_bwd": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_flame_skin_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "omfs_flame_rodrigues": (C.c_int, [c_void_p, C.c_int, c_void_p, c_void_p]),
+    "omfs_flame_param_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    "omfs_adam_flat": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                 C.c_int, C.c_float, c_void_p]),
     "omfs_simpleflame_fwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 5 + [C.c_int, c_void_p, c_void_p, c_void_p]),
     "omfs_simpleflame_bwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 3 + [C.c_int] + [c_void_p] * 7),
     "omfs_project_fwd": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),

@@ -83,7 +83,8 @@ __global__ __launch_bounds__(64) void flame_lbs_kernel(const float* __restrict__
                                                        const float* __restrict__ joint_xf,
                                                        const float* __restrict__ translation,
                                                        const float* __restrict__ dynamic_offset, int n_verts, int v_pad,
-                                                       int k_pad, int n_frames, int b_pad, float* __restrict__ verts) {
+                                                       int k_pad, int n_frames, int b_pad, float* __restrict__ verts,
+                                                       float* __restrict__ v_shaped_out) {
   const int strip = blockIdx.x, cb = blockIdx.y;
   const int lane = threadIdx.x;
   const int n_strips = v_pad / 16, n_kt = k_pad / 16;
@@ -126,6 +127,7 @@ __global__ __launch_bounds__(64) void flame_lbs_kernel(const float* __restrict__
       M[i] = m;
     }
     float x = acc[0][r], y = acc[1][r], z = acc[2][r];
+    if (v_shaped_out) *reinterpret_cast<float4*>(v_shaped_out + ((size_t)frame * v_pad + v) * 4) = make_float4(x, y, z, 1.f);
     float ox = dot3_(M[0], M[1], M[2], x, y, z) + M[9];
     float oy = dot3_(M[3], M[4], M[5], x, y, z) + M[10];
     float oz = dot3_(M[6], M[7], M[8], x, y, z) + M[11];
@@ -177,17 +179,28 @@ __global__ void face_frames_kernel(const float* __restrict__ verts, int v_pad, c
   o[3] = make_float4(scale, 0.f, 0.f, 0.f);
 }
 
-// ---- backward (FLAME fine-tuning), one frame.  One thread per face: gradient of the frame record
+// ---- backward (FLAME fine-tuning), one frame.  One thread per face: sums the per-Gaussian records project_bwd
+// wrote (no atomics there), then the gradient of the frame record
 // (R columns a0, n, a2; centre; scale) w.r.t. the three vertices, added into dverts with float atomics
 // (a vertex belongs to ~6 faces).  The clamps of safe_normalize3 are not differentiated.
 __global__ void face_frames_bwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int n_faces,
-                                       const float* __restrict__ dface, float* __restrict__ dverts) {
+                                       const float* __restrict__ dface, const int32_t* __restrict__ face_start,
+                                       const int32_t* __restrict__ face_gauss, float* __restrict__ dverts) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n_faces) return;
+  // sum of the frame-gradient records of the Gaussians bound to this triangle (CSR by triangle)
+  float g[16];
+  for (int k = 0; k < 16; ++k) g[k] = 0.f;
+  for (int e = face_start[f]; e < face_start[f + 1]; ++e) {
+    const float4* rec = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e] * 4;
+    const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+    g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
+    g[8] += c.x; g[9] += c.y; g[10] += c.z; g[11] += c.w; g[12] += d.x;
+  }
+  if (face_start[f] == face_start[f + 1]) return;
   const float4* vb = reinterpret_cast<const float4*>(verts);
   const int i0 = faces[f * 3 + 0], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
   const float4 v0 = vb[i0], v1 = vb[i1], v2 = vb[i2];
-  const float* g = dface + (size_t)f * 16;
   float da0[3] = {g[0], g[3], g[6]}, dn[3] = {g[1], g[4], g[7]}, da2[3] = {g[2], g[5], g[8]};
   const float dc[3] = {g[9], g[10], g[11]};
   const float ds = g[12];
@@ -237,42 +250,201 @@ __global__ void face_frames_bwd_kernel(const float* __restrict__ verts, const in
   }
 }
 
-// One thread per vertex: v_posed = M_v [v_shaped; 1] + ..., M_v = sum_j w_vj X_j.  Writes dv_shaped = M_v(3x3)^T dv
-// and accumulates d X_j = w_vj dv (x) [v_shaped; 1] and d translation = dv (63 sums: LDS atomics per block, then one
-// global atomic per value and block).
+// One thread per vertex: v_posed = M_v [v_shaped; 1] + ..., M_v = sum_j w_vj X_j; v_shaped [v_pad][4] was stored by
+// flame_lbs.  Writes dv_shaped = M_v(3x3)^T dv and accumulates d X_j = w_vj dv (x) [v_shaped; 1] and
+// d translation = dv: 63 sums, reduced per wave with DPP, one global atomic per value and wave.
 __global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __restrict__ lbs_weights, const float* __restrict__ v_shaped,
                                                              const float* __restrict__ joint_xf, const float* __restrict__ dverts,
                                                              int n_verts, float* __restrict__ dv_shaped, float* __restrict__ sums) {
-  __shared__ float acc[64];
   __shared__ float X[60];
-  if (threadIdx.x < 64) acc[threadIdx.x] = 0.f;
   if (threadIdx.x < 60) X[threadIdx.x] = joint_xf[threadIdx.x];
   __syncthreads();
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < n_verts) {
-    const float* w = lbs_weights + (size_t)v * 8;
-    const float dv[3] = {dverts[(size_t)v * 4 + 0], dverts[(size_t)v * 4 + 1], dverts[(size_t)v * 4 + 2]};
-    const float vs[4] = {v_shaped[(size_t)v * 3 + 0], v_shaped[(size_t)v * 3 + 1], v_shaped[(size_t)v * 3 + 2], 1.f};
+  const bool on = v < n_verts;
+  float w[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, dv[3] = {0.f, 0.f, 0.f}, vs[4] = {0.f, 0.f, 0.f, 1.f};
+  if (on) {
+    for (int j = 0; j < 5; ++j) w[j] = lbs_weights[(size_t)v * 8 + j];
+    const float4 d = reinterpret_cast<const float4*>(dverts)[v], a = reinterpret_cast<const float4*>(v_shaped)[v];
+    dv[0] = d.x; dv[1] = d.y; dv[2] = d.z;
+    vs[0] = a.x; vs[1] = a.y; vs[2] = a.z;
     float out[3] = {0.f, 0.f, 0.f};
-    for (int j = 0; j < 5; ++j) {
-      const float wj = w[j];
-      if (wj == 0.f) continue;
-      for (int r = 0; r < 3; ++r) {
-        const float g = wj * dv[r];
-        for (int c = 0; c < 3; ++c) {
-          out[c] = fma_(X[j * 12 + r * 3 + c], g, out[c]);
-          atomicAdd(&acc[j * 12 + r * 3 + c], g * vs[c]);
-        }
-        atomicAdd(&acc[j * 12 + 9 + r], g);
+    for (int j = 0; j < 5; ++j)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) out[c] = fma_(X[j * 12 + r * 3 + c], w[j] * dv[r], out[c]);
+    for (int c = 0; c < 3; ++c) dv_shaped[(size_t)v * 3 + c] = out[c];
+  }
+  const bool last = (threadIdx.x & 63) == 63;
+  for (int j = 0; j < 5; ++j)
+    for (int r = 0; r < 3; ++r) {
+      const float g = w[j] * dv[r];
+      for (int c = 0; c < 4; ++c) {
+        const float t = wave_sum_to_lane63(g * vs[c]);
+        if (last && t != 0.f) atomicAdd(&sums[j * 12 + (c < 3 ? r * 3 + c : 9 + r)], t);
       }
     }
+  for (int c = 0; c < 3; ++c) {
+    const float t = wave_sum_to_lane63(dv[c]);
+    if (last && t != 0.f) atomicAdd(&sums[60 + c], t);
+  }
+}
+
+// dcoef[k] = sum_i basis_dense[k][i] dv_shaped[i]   (one block per coefficient)
+__global__ __launch_bounds__(256) void basis_t_gemv_kernel(const float* __restrict__ basis_dense, const float* __restrict__ dv_shaped,
+                                                           int row, float* __restrict__ dcoef) {
+  __shared__ float ws[4];
+  const float* b = basis_dense + (size_t)blockIdx.x * row;
+  float a = 0.f;
+  for (int i = threadIdx.x; i < row; i += 256) a = fma_(b[i], dv_shaped[i], a);
+  a = wave_sum_all(a);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) dcoef[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+
+// axis-angle -> rotation matrix, the formula of flame_fitter.py:133-152: a = aa / (|aa| + 1e-8), R = I + sin K + (1 - cos) K^2
+__device__ __forceinline__ void rodrigues_fwd(const float* aa, float* R, float* K, float& th) {
+  th = sqrtf(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]);
+  const float inv = 1.f / (th + 1e-8f);
+  const float a0 = aa[0] * inv, a1 = aa[1] * inv, a2 = aa[2] * inv;
+  const float Kl[9] = {0.f, -a2, a1, a2, 0.f, -a0, -a1, a0, 0.f};
+  const float sn = sinf(th), cs = cosf(th);
+  for (int r = 0; r < 3; ++r)
     for (int c = 0; c < 3; ++c) {
-      dv_shaped[(size_t)v * 3 + c] = out[c];
-      atomicAdd(&acc[60 + c], dv[c]);
+      float k2 = 0.f;
+      for (int m = 0; m < 3; ++m) k2 = fma_(Kl[r * 3 + m], Kl[m * 3 + c], k2);
+      R[r * 3 + c] = (r == c ? 1.f : 0.f) + sn * Kl[r * 3 + c] + (1.f - cs) * k2;
+      K[r * 3 + c] = Kl[r * 3 + c];
     }
+}
+
+__global__ void rodrigues_kernel(const float* __restrict__ aa, int n, float* __restrict__ rotmats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float R[9], K[9], th;
+  rodrigues_fwd(aa + (size_t)i * 3, R, K, th);
+  for (int k = 0; k < 9; ++k) rotmats[(size_t)i * 9 + k] = R[k];
+}
+
+// Gradient of the small FLAME front: (d joint_xf [5][12], d coef [K], d translation) -> (d expr [E], d pose [5][3]).
+// One wave; lane 0 walks the 5-joint chain and the axis-angle maps backwards, all lanes finish d expr.
+__global__ __launch_bounds__(64) void flame_front_bwd_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
+                                                             const float* __restrict__ expr, const float* __restrict__ pose,
+                                                             int n_expr, const float* __restrict__ sums, const float* __restrict__ dcoef,
+                                                             float* __restrict__ dexpr, float* __restrict__ dpose) {
+  __shared__ float sJ[15], sdJ[15];
+  const int lane = threadIdx.x;
+  if (lane < 15) {
+    float a = j_static[lane];
+    const float* row = j_expr + (size_t)lane * n_expr;
+    for (int k = 0; k < n_expr; ++k) a = fma_(row[k], expr[k], a);
+    sJ[lane] = a;
   }
   __syncthreads();
-  if (threadIdx.x < 63) atomicAdd(&sums[threadIdx.x], acc[threadIdx.x]);
+  if (lane == 0) {
+    float R[5][9], K[5][9], th[5], J[5][3];
+    for (int j = 0; j < 5; ++j) {
+      rodrigues_fwd(pose + j * 3, R[j], K[j], th[j]);
+      for (int c = 0; c < 3; ++c) J[j][c] = sJ[j * 3 + c];
+    }
+    const int par[5] = {-1, 0, 1, 1, 1};
+    float Rw[5][9], dRw[5][9], dtw[5][3], dJ[5][3], dR[5][9];
+    for (int i = 0; i < 9; ++i) Rw[0][i] = R[0][i];
+    for (int j = 1; j < 5; ++j)
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          float a = 0.f;
+          for (int m = 0; m < 3; ++m) a = fma_(Rw[par[j]][r * 3 + m], R[j][m * 3 + c], a);
+          Rw[j][r * 3 + c] = a;
+        }
+    // X_j = [Rw_j | tw_j - Rw_j J_j]
+    for (int j = 0; j < 5; ++j) {
+      const float* dX = sums + j * 12;
+      for (int r = 0; r < 3; ++r) {
+        dtw[j][r] = dX[9 + r];
+        for (int c = 0; c < 3; ++c) dRw[j][r * 3 + c] = dX[r * 3 + c] - dX[9 + r] * J[j][c];
+      }
+      for (int c = 0; c < 3; ++c) {
+        float a = 0.f;
+        for (int r = 0; r < 3; ++r) a = fma_(Rw[j][r * 3 + c], dX[9 + r], a);
+        dJ[j][c] = -a;
+      }
+      for (int i = 0; i < 9; ++i) dR[j][i] = 0.f;
+    }
+    for (int j = 4; j >= 1; --j) {
+      const int p = par[j];
+      // tw_j = Rw_p (J_j - J_p) + tw_p
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) dRw[p][r * 3 + c] = fma_(dtw[j][r], J[j][c] - J[p][c], dRw[p][r * 3 + c]);
+        dtw[p][r] += dtw[j][r];
+      }
+      for (int c = 0; c < 3; ++c) {
+        float a = 0.f;
+        for (int r = 0; r < 3; ++r) a = fma_(Rw[p][r * 3 + c], dtw[j][r], a);
+        dJ[j][c] += a; dJ[p][c] -= a;
+      }
+      // Rw_j = Rw_p R_j
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          float a = 0.f, b = 0.f;
+          for (int m = 0; m < 3; ++m) {
+            a = fma_(dRw[j][r * 3 + m], R[j][c * 3 + m], a);       // dRw_j R_j^T
+            b = fma_(Rw[p][m * 3 + r], dRw[j][m * 3 + c], b);      // Rw_p^T dRw_j
+          }
+          dRw[p][r * 3 + c] += a;
+          dR[j][r * 3 + c] += b;
+        }
+    }
+    for (int i = 0; i < 9; ++i) dR[0][i] += dRw[0][i];
+    for (int c = 0; c < 3; ++c) dJ[0][c] += dtw[0][c];
+    // pose features (R_j - I), j = 1..4, are coefficients n_expr .. n_expr+35
+    for (int j = 1; j < 5; ++j)
+      for (int i = 0; i < 9; ++i) dR[j][i] += dcoef[n_expr + (j - 1) * 9 + i];
+    for (int j = 0; j < 5; ++j) {
+      const float* G = dR[j];
+      const float* Kj = K[j];
+      const float t = th[j], sn = sinf(t), cs = cosf(t);
+      float K2[9], dK[9];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          float a = 0.f;
+          for (int m = 0; m < 3; ++m) a = fma_(Kj[r * 3 + m], Kj[m * 3 + c], a);
+          K2[r * 3 + c] = a;
+        }
+      float dsn = 0.f, dom = 0.f;   // d/d sin, d/d (1 - cos)
+      for (int i = 0; i < 9; ++i) { dsn = fma_(G[i], Kj[i], dsn); dom = fma_(G[i], K2[i], dom); }
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) {
+          float a = 0.f;   // (G K^T + K^T G)[r][c]
+          for (int m = 0; m < 3; ++m) a = fma_(G[r * 3 + m], Kj[c * 3 + m], fma_(Kj[m * 3 + r], G[m * 3 + c], a));
+          dK[r * 3 + c] = fma_(1.f - cs, a, sn * G[r * 3 + c]);
+        }
+      float dth = cs * dsn + sn * dom;
+      const float da[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+      const float* aa = pose + j * 3;
+      const float inv = 1.f / (t + 1e-8f);
+      dth -= (da[0] * aa[0] + da[1] * aa[1] + da[2] * aa[2]) * inv * inv;
+      for (int c = 0; c < 3; ++c) dpose[j * 3 + c] = da[c] * inv + (t > 0.f ? dth * aa[c] / t : 0.f);
+    }
+    for (int i = 0; i < 15; ++i) sdJ[i] = dJ[i / 3][i % 3];
+  }
+  __syncthreads();
+  for (int e = lane; e < n_expr; e += 64) {
+    float a = dcoef[e];
+    for (int i = 0; i < 15; ++i) a = fma_(j_expr[(size_t)i * n_expr + e], sdJ[i], a);
+    dexpr[e] = a;
+  }
+}
+
+// torch.optim.Adam semantics on a flat buffer (the FLAME parameter tensors)
+__global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int n,
+                                 float lr_step, float b1, float b2, float eps, float inv_sqrt_bc2, float grad_scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float ge = g[i] * grad_scale;
+  const float me = fma_(b1, m[i], (1.f - b1) * ge);
+  const float ve = fma_(b2, v[i], (1.f - b2) * ge * ge);
+  m[i] = me; v[i] = ve;
+  p[i] = p[i] - lr_step * (me / fma_(sqrtf(ve), inv_sqrt_bc2, eps));
 }
 
 }  // namespace omfs
@@ -292,13 +464,13 @@ extern "C" int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, c
 
 extern "C" int omfs_flame_lbs(const omfs_flame_rig* rig, const float* coef, const float* joint_xf,
                               const float* translation, const float* dynamic_offset, int n_frames, float* verts,
-                              void* stream) {
+                              float* v_shaped_out, void* stream) {
   OMFS_REQUIRE(rig && coef && joint_xf && translation && verts, "null pointer");
   OMFS_REQUIRE(n_frames > 0 && rig->v_pad % 16 == 0 && rig->v_pad >= rig->n_verts && rig->k_pad % 16 == 0, "shape");
   int b_pad = cdiv(n_frames, 16) * 16;
   hipLaunchKernelGGL(flame_lbs_kernel, dim3(rig->v_pad / 16, b_pad / 16), dim3(64), 0, (hipStream_t)stream,
                      rig->basis_tiled, rig->v_static, rig->lbs_weights, coef, joint_xf, translation, dynamic_offset,
-                     rig->n_verts, rig->v_pad, rig->k_pad, n_frames, b_pad, verts);
+                     rig->n_verts, rig->v_pad, rig->k_pad, n_frames, b_pad, verts, v_shaped_out);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
@@ -314,21 +486,52 @@ extern "C" int omfs_face_frames(const float* verts, int v_pad, const int32_t* fa
 }
 
 extern "C" int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t* faces, int n_faces, const float* dface,
-                                    float* dverts, void* stream) {
-  OMFS_REQUIRE(verts && faces && dface && dverts, "null pointer");
+                                    const int32_t* face_start, const int32_t* face_gauss, float* dverts, void* stream) {
+  OMFS_REQUIRE(verts && faces && dface && face_start && face_gauss && dverts, "null pointer");
   OMFS_REQUIRE(n_faces > 0 && v_pad > 0, "shape");
   hipLaunchKernelGGL(face_frames_bwd_kernel, dim3(cdiv(n_faces, 256)), dim3(256), 0, (hipStream_t)stream, verts, faces,
-                     n_faces, dface, dverts);
+                     n_faces, dface, face_start, face_gauss, dverts);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
 
-extern "C" int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf,
-                                   const float* dverts, float* dv_shaped, float* sums, void* stream) {
+extern "C" int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, const float* dverts,
+                                   float* dv_shaped, float* sums, void* stream) {
   OMFS_REQUIRE(rig && v_shaped && joint_xf && dverts && dv_shaped && sums, "null pointer");
   OMFS_REQUIRE(rig->n_verts > 0 && rig->lbs_weights, "rig");
   hipLaunchKernelGGL(flame_skin_bwd_kernel, dim3(cdiv(rig->n_verts, 256)), dim3(256), 0, (hipStream_t)stream,
                      rig->lbs_weights, v_shaped, joint_xf, dverts, rig->n_verts, dv_shaped, sums);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_flame_rodrigues(const float* axis_angle, int n, float* rotmats, void* stream) {
+  OMFS_REQUIRE(axis_angle && rotmats && n > 0, "args");
+  hipLaunchKernelGGL(rodrigues_kernel, dim3(cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, axis_angle, n, rotmats);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basis_dense, int n_coef, const float* dv_shaped,
+                                    const float* expr, const float* pose, const float* sums, float* dcoef, float* dexpr,
+                                    float* dpose, void* stream) {
+  OMFS_REQUIRE(rig && basis_dense && dv_shaped && expr && pose && sums && dcoef && dexpr && dpose, "null pointer");
+  OMFS_REQUIRE(n_coef == rig->n_expr + 36 && rig->j_static && rig->j_expr, "shape");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(basis_t_gemv_kernel, dim3(n_coef), dim3(256), 0, s, basis_dense, dv_shaped, 3 * rig->n_verts, dcoef);
+  OMFS_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(flame_front_bwd_kernel, dim3(1), dim3(64), 0, s, rig->j_static, rig->j_expr, expr, pose, rig->n_expr, sums,
+                     dcoef, dexpr, dpose);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_adam_flat(float* params, const float* grads, float* m, float* v, int n, float lr, float beta1, float beta2,
+                              float eps, int step, float grad_scale, void* stream) {
+  OMFS_REQUIRE(params && grads && m && v && n > 0 && step >= 1, "args");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, n,
+                     (float)(lr / bc1), beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -40,6 +40,10 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
   const bool visible = (rbits & 0xFFFFFu) != 0u;
   if (!visible) {
     for (int p = 0; p < OMFS_NPLANES; ++p) G(p, 0.f);
+    if (dface) {
+      float4* o = reinterpret_cast<float4*>(dface) + (size_t)i * 4;
+      for (int q = 0; q < 4; ++q) o[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     return;
   }
   const uint32_t clampbits = rbits >> 28;
@@ -207,19 +211,22 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
     dls[k] = dsk[k] * s[k];
   }
   if (dface) {
-    // triangle frame record (FLAME fine-tuning): mu = sf Rf l + cf, M = Rf (Q diag(s)), s = exp(ls) sf
-    float* df = dface + (size_t)binding[i] * 16;
+    // gradient w.r.t. the parent triangle's frame record (FLAME fine-tuning): mu = sf Rf l + cf, M = Rf (Q diag(s)),
+    // s = exp(ls) sf.  One 64-byte record per GAUSSIAN (no atomics); omfs_face_frames_bwd sums them per triangle.
+    float rec[16];
     float dsf = dsk[0] * es[0] + dsk[1] * es[1] + dsk[2] * es[2];
     for (int r = 0; r < 3; ++r) {
       dsf = fma_(dmu[r], dot3_(Rf[r * 3], Rf[r * 3 + 1], Rf[r * 3 + 2], l[0], l[1], l[2]), dsf);
       for (int cc = 0; cc < 3; ++cc) {
         float gR = sf * dmu[r] * l[cc];
         for (int k = 0; k < 3; ++k) gR = fma_(dM[r * 3 + k], Q[cc * 3 + k] * s[k], gR);
-        atomicAdd(&df[r * 3 + cc], gR);
+        rec[r * 3 + cc] = gR;
       }
-      atomicAdd(&df[9 + r], dmu[r]);
+      rec[9 + r] = dmu[r];
     }
-    atomicAdd(&df[12], dsf);
+    rec[12] = dsf; rec[13] = rec[14] = rec[15] = 0.f;
+    float4* o = reinterpret_cast<float4*>(dface) + (size_t)i * 4;
+    for (int q = 0; q < 4; ++q) o[q] = make_float4(rec[q * 4], rec[q * 4 + 1], rec[q * 4 + 2], rec[q * 4 + 3]);
   }
   if (reg.lambda_scale != 0.f) {
     const float u0 = fmaxf(es[0] - reg.thr_scale, 0.f), u1 = fmaxf(es[1] - reg.thr_scale, 0.f), u2 = fmaxf(es[2] - reg.thr_scale, 0.f);

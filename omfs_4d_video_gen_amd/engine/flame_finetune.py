@@ -2,11 +2,12 @@
 with the Gaussians, as upstream GaussianAvatars does by default for `--bind_to_mesh` (the
 reference only launches that trainer: `02_Visual_Engine/train_ghost.py:227-240`).
 
-Gradient path: composite_bwd -> project_bwd (dL/d triangle-frame record, `omfs_grad_buffers.dface`) ->
-`omfs_face_frames_bwd` (dL/d posed vertices) -> `omfs_flame_skin_bwd` (dL/d blend-shaped vertices, dL/d joint
-transforms, dL/d translation).  What remains is tiny (a 5-joint kinematic chain, the axis-angle map `rodrigues` of
-`flame_fitter.py:122-152`, one [K]x[3V] basis product): it is evaluated here with torch ops on the device and
-differentiated by autograd, which chains the three kernel outputs into the parameter gradients.
+Gradient path, all HIP (include/omfs_splat.h): composite_bwd -> project_bwd (dL/d triangle-frame record,
+`omfs_grad_buffers.dface`) -> `omfs_face_frames_bwd` (dL/d posed vertices) -> `omfs_flame_skin_bwd` (dL/d blend-shaped
+vertices, dL/d joint transforms, dL/d translation) -> `omfs_flame_param_bwd` (basis^T product, 5-joint kinematic chain,
+axis-angle map of `flame_fitter.py:122-152`) -> `omfs_adam_flat`.  The parameters ARE the device arrays the FLAME
+forward kernels read (`DeviceFlame.expr / .translation`, rotation matrices refreshed from the axis-angle poses by
+`omfs_flame_rodrigues`), so nothing is copied per step; seven small launches, no host math.
 """
 from __future__ import annotations
 
@@ -14,99 +15,126 @@ import numpy as np
 import torch
 
 from .. import _lib as L
-from .flame_rig import DeviceFlame, rodrigues
+from .flame_rig import DeviceFlame
 
 # upstream's learning rates for the FLAME parameter groups
 FLAME_LR = {"expr": 1e-3, "pose": 1e-5, "translation": 1e-6}
 
 
 class FlameFineTuner:
-    def __init__(self, dflame: DeviceFlame, flame_params: dict, lr: dict | None = None):
+    def __init__(self, dflame: DeviceFlame, flame_params: dict, lr: dict | None = None,
+                 beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-15):
         self.df = dflame
         dev = dflame.device
         T = dflame.n_frames
 
         def as2d(key, w):
             a = flame_params.get(key)
-            a = np.zeros((T, w), np.float32) if a is None else np.asarray(a, np.float32).reshape(-1, w)
-            return a
+            return np.zeros((T, w), np.float32) if a is None else np.asarray(a, np.float32).reshape(-1, w)
         eyes = as2d("eyes_pose", 6)
         pose = np.stack([as2d("rotation", 3), as2d("neck_pose", 3), as2d("jaw_pose", 3), eyes[:, :3], eyes[:, 3:]], 1)
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
-        self.pose = up(pose).requires_grad_(True)                       # [T][5][3] axis-angle
-        self.expr = up(dflame.h_expr).requires_grad_(True)              # [T][E]
-        self.translation = up(dflame.h_translation).requires_grad_(True)
-        self.source = {"pose": pose.copy(), "expr": dflame.h_expr.copy(), "translation": dflame.h_translation.copy()}
-        lr = {**FLAME_LR, **(lr or {})}
-        self.opt = torch.optim.Adam([{"params": [self.expr], "lr": lr["expr"]}, {"params": [self.pose], "lr": lr["pose"]},
-                                     {"params": [self.translation], "lr": lr["translation"]}], eps=1e-15)
+        self.pose = up(pose.reshape(T, 15))                 # [T][5*3] axis-angle: global, neck, jaw, eye-L, eye-R
+        self.expr = dflame.expr                             # [T][E]   the arrays the forward kernels read
+        self.translation = dflame.translation               # [T][3]
+        self.params = {"expr": self.expr, "pose": self.pose, "translation": self.translation}
+        self.grad = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.m = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        self.lr = {**FLAME_LR, **(lr or {})}
+        self.betas, self.eps = (beta1, beta2), eps
+        self.step_count = 0
         V = dflame.rig.n_verts
-        self.n_verts = V
-        # dense basis [K][3V] (column v*3+c) for the blend-shape product and its transpose product
-        self.basis = up(dflame.h_basis.transpose(0, 2, 1).reshape(dflame.h_basis.shape[0], 3 * V))
-        self.v_static = up(dflame.h_v_static[:, :V].T.reshape(-1))
-        self.j_static = up(dflame.h_j_static)                            # (5,3)
-        self.j_expr = up(dflame.h_j_expr)                                # (15,E)
-        self.eye = torch.eye(3, device=dev)
-        F = dflame.rig.n_faces
-        self.dface = torch.zeros(F, 16, device=dev)
+        self.n_coef = dflame.h_basis.shape[0]
+        # dense basis [K][3V] (column 3v+c): blend-shape recompute per vertex and the transpose product
+        self.basis = up(dflame.h_basis.transpose(0, 2, 1).reshape(self.n_coef, 3 * V))
+        dflame.keep_v_shaped = True
+        dflame._scratch.clear()
+        self.dface = None                                    # [n_capacity][16] per-Gaussian frame-gradient records
+        self._csr_key, self.face_start, self.face_gauss = None, None, None
         self.dverts = torch.zeros(dflame.v_pad, 4, device=dev)
         self.dv_shaped = torch.empty(V, 3, device=dev)
         self.sums = torch.zeros(64, device=dev)
-        self._live = None
+        self.dcoef = torch.empty(self.n_coef, device=dev)
+        self._t = None
+        self._last_t = None
+        self.refresh_rotmats()
 
-    # ---- forward: the small differentiable front; refreshes the rows the FLAME kernels read
-    def begin(self, t: int):
-        R = rodrigues(self.pose[t])                                      # (5,3,3)
-        psi = self.expr[t]
-        J = self.j_static + (self.j_expr @ psi).view(5, 3)
-        Rw, tw = [R[0]], [J[0]]
-        for j in range(1, 5):
-            p = 0 if j == 1 else 1
-            Rw.append(Rw[p] @ R[j])
-            tw.append(Rw[p] @ (J[j] - J[p]) + tw[p])
-        X = torch.cat([torch.cat([Rw[j].reshape(9), tw[j] - Rw[j] @ J[j]]) for j in range(5)])   # [60]
-        coef = torch.cat([psi, (R[1:] - self.eye).reshape(36)])
-        v_shaped = torch.addmv(self.v_static, self.basis.t(), coef)     # [3V], v*3+c
-        with torch.no_grad():
-            self.df.rotmats[t].copy_(R.reshape(45))
-            self.df.expr[t].copy_(psi)
-            self.df.translation[t].copy_(self.translation[t])
-        self._live = (t, X, v_shaped)
-        self.dface.zero_()
+    def refresh_rotmats(self):
+        """All timesteps: axis-angle poses -> the rotation matrices the forward kernels read."""
+        T = self.pose.shape[0]
+        L.check(L.load().omfs_flame_rodrigues(L.ptr(self.pose), T * 5, L.ptr(self.df.rotmats), L.stream_ptr()), "omfs_flame_rodrigues")
 
-    # ---- backward: kernels for the vertex-sized work, autograd for the chain
+    def bind(self, binding: torch.Tensor):
+        """(Re)build the triangle -> Gaussians CSR and the record buffer when the cloud's topology changed."""
+        key = (binding.data_ptr(), int(binding.shape[0]))
+        if key == self._csr_key:
+            return
+        b = binding.to(torch.int64)
+        order = torch.argsort(b, stable=True)
+        counts = torch.bincount(b, minlength=self.df.rig.n_faces)
+        self.face_start = torch.cat([torch.zeros(1, dtype=torch.int64, device=b.device), torch.cumsum(counts, 0)]).to(torch.int32)
+        self.face_gauss = order.to(torch.int32).contiguous()
+        if self.dface is None or self.dface.shape[0] < key[1]:
+            self.dface = torch.empty(key[1], 16, device=binding.device)
+        self._csr_key = key
+
+    def begin(self, t: int, binding: torch.Tensor):
+        """Before the FLAME forward of timestep t: its rotation matrices from the current poses."""
+        self.bind(binding)
+        L.check(L.load().omfs_flame_rodrigues(L.ptr(self.pose[t]), 5, L.ptr(self.df.rotmats[t]), L.stream_ptr()), "omfs_flame_rodrigues")
+        self._t = t
+
     def backward(self, verts: torch.Tensor):
-        """verts: [v_pad][4] posed vertices of the frame (DeviceFlame.face_frames); self.dface filled by project_bwd."""
-        t, X, v_shaped = self._live
+        """verts: [v_pad][4] posed vertices of the frame (DeviceFlame.face_frames); self.dface filled by project_bwd.
+        Leaves the gradient of timestep t in row t of the dense gradient tensors (all other rows zero)."""
+        t = self._t
+        df = self.df
         lib, s = L.load(), L.stream_ptr()
+        joint_xf, _, _, _, v_shaped = df._buffers(1)        # written by the FLAME forward kernels for this frame
         self.dverts.zero_()
         self.sums.zero_()
-        L.check(lib.omfs_face_frames_bwd(L.ptr(verts), self.df.v_pad, L.ptr(self.df.faces), self.df.rig.n_faces,
-                                         L.ptr(self.dface), L.ptr(self.dverts), s), "omfs_face_frames_bwd")
-        Xd, vsd = X.detach().contiguous(), v_shaped.detach().contiguous()
-        L.check(lib.omfs_flame_skin_bwd(self.df.c_rig, L.ptr(vsd), L.ptr(Xd), L.ptr(self.dverts), L.ptr(self.dv_shaped),
+        if self._last_t is not None and self._last_t != t:
+            for g in self.grad.values():
+                g[self._last_t].zero_()
+        L.check(lib.omfs_face_frames_bwd(L.ptr(verts), df.v_pad, L.ptr(df.faces), df.rig.n_faces, L.ptr(self.dface),
+                                         L.ptr(self.face_start), L.ptr(self.face_gauss), L.ptr(self.dverts), s), "omfs_face_frames_bwd")
+        L.check(lib.omfs_flame_skin_bwd(df.c_rig, L.ptr(v_shaped), L.ptr(joint_xf), L.ptr(self.dverts), L.ptr(self.dv_shaped),
                                         L.ptr(self.sums), s), "omfs_flame_skin_bwd")
-        surrogate = (v_shaped * self.dv_shaped.reshape(-1)).sum() + (X * self.sums[:60]).sum() + \
-            (self.translation[t] * self.sums[60:63]).sum()
-        surrogate.backward()
-        self._live = None
+        L.check(lib.omfs_flame_param_bwd(df.c_rig, L.ptr(self.basis), self.n_coef, L.ptr(self.dv_shaped), L.ptr(self.expr[t]),
+                                         L.ptr(self.pose[t]), L.ptr(self.sums), L.ptr(self.dcoef), L.ptr(self.grad["expr"][t]),
+                                         L.ptr(self.grad["pose"][t]), s), "omfs_flame_param_bwd")
+        self.grad["translation"][t].copy_(self.sums[60:63])
+        self._last_t = t
+        self._t = None
 
     def grads(self):
-        return [p.grad for p in (self.expr, self.pose, self.translation)]
+        return [self.grad["expr"], self.grad["pose"], self.grad["translation"]]
 
     def step(self, grad_scale: float = 1.0):
-        if grad_scale != 1.0:
-            for p in (self.expr, self.pose, self.translation):
-                if p.grad is not None:
-                    p.grad.mul_(grad_scale)
-        self.opt.step()
-        self.opt.zero_grad(set_to_none=False)
+        """Dense Adam over all timesteps (torch.optim.Adam semantics, as upstream)."""
+        self.step_count += 1
+        lib, s = L.load(), L.stream_ptr()
+        for k, p in self.params.items():
+            L.check(lib.omfs_adam_flat(L.ptr(p), L.ptr(self.grad[k]), L.ptr(self.m[k]), L.ptr(self.v[k]), p.numel(),
+                                       float(self.lr[k]), self.betas[0], self.betas[1], self.eps, self.step_count,
+                                       float(grad_scale), s), "omfs_adam_flat")
 
-    # ---- egress: the dataset schema of flame_fitter.py:431-441
+    # ---- checkpoint / egress
+    def state_dict(self) -> dict:
+        cpu = lambda d: {k: v.detach().cpu() for k, v in d.items()}
+        return {"params": cpu(self.params), "m": cpu(self.m), "v": cpu(self.v), "step": self.step_count}
+
+    def load_state_dict(self, st: dict):
+        for k in self.params:
+            self.params[k].copy_(st["params"][k]); self.m[k].copy_(st["m"][k]); self.v[k].copy_(st["v"][k])
+        self.step_count = int(st["step"])
+        self.refresh_rotmats()
+
     def to_flame_params(self, base: dict) -> dict:
+        """The tuned sequence in the dataset schema of flame_fitter.py:431-441."""
         out = {k: np.array(v) for k, v in base.items()}
-        pose = self.pose.detach().cpu().numpy()
+        pose = self.pose.detach().cpu().numpy().reshape(-1, 5, 3)
         T = pose.shape[0]
         out["rotation"] = pose[:, 0].astype(np.float32)
         out["neck_pose"] = pose[:, 1].astype(np.float32)

@@ -170,6 +170,7 @@ class DeviceFlame:
         self.c_rig = L.FlameRigC(V, self.v_pad, self.n_expr, self.k_pad, L.ptr(self.basis_tiled), L.ptr(self.v_static),
                                  L.ptr(self.lbs_weights), L.ptr(self.j_static), L.ptr(self.j_expr))
         self._scratch = {}
+        self.keep_v_shaped = False     # FLAME fine-tuning: flame_lbs also stores the blend-shaped vertices
 
     def _buffers(self, nb: int):
         if nb not in self._scratch:
@@ -177,7 +178,8 @@ class DeviceFlame:
             dev = self.device
             self._scratch[nb] = (
                 torch.empty(nb, 60, device=dev), torch.empty(self.k_pad, b_pad, device=dev),
-                torch.empty(nb, self.v_pad, 4, device=dev), torch.empty(nb, self.rig.n_faces, 16, device=dev))
+                torch.empty(nb, self.v_pad, 4, device=dev), torch.empty(nb, self.rig.n_faces, 16, device=dev),
+                torch.empty(nb, self.v_pad, 4, device=dev) if self.keep_v_shaped else None)
         return self._scratch[nb]
 
     def face_frames(self, t0: int, nb: int = 1, out=None):
@@ -187,14 +189,14 @@ class DeviceFlame:
             raise IndexError(f"frames [{t0},{t0 + nb}) outside sequence of {self.n_frames}")
         lib = L.load()
         s = L.stream_ptr()
-        joint_xf, coef, verts, face_xf = self._buffers(nb)
+        joint_xf, coef, verts, face_xf, v_shaped = self._buffers(nb)
         if out is not None:
             face_xf = out
         L.check(lib.omfs_flame_joints(self.c_rig, L.ptr(self.expr[t0]), L.ptr(self.rotmats[t0]), nb, L.ptr(joint_xf),
                                       L.ptr(coef), s), "omfs_flame_joints")
         dyn = L.ptr(self.dynamic[t0]) if self.dynamic is not None else 0
         L.check(lib.omfs_flame_lbs(self.c_rig, L.ptr(coef), L.ptr(joint_xf), L.ptr(self.translation[t0]), dyn, nb,
-                                   L.ptr(verts), s), "omfs_flame_lbs")
+                                   L.ptr(verts), L.ptr(v_shaped), s), "omfs_flame_lbs")
         L.check(lib.omfs_face_frames(L.ptr(verts), self.v_pad, L.ptr(self.faces), self.rig.n_faces, nb, L.ptr(face_xf), s),
                 "omfs_face_frames")
         return verts, face_xf

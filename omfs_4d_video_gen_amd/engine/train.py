@@ -165,10 +165,7 @@ def main(argv=None):
         trainer.sh_degree = int(ckpt["sh_degree"])
         trainer.step_idx = it0
         if trainer.flame_ft is not None and "flame" in ckpt:
-            ft = trainer.flame_ft
-            with torch.no_grad():
-                ft.expr.copy_(ckpt["flame"]["expr"]); ft.pose.copy_(ckpt["flame"]["pose"]); ft.translation.copy_(ckpt["flame"]["translation"])
-            ft.opt.load_state_dict(ckpt["flame"]["optimizer"])
+            trainer.flame_ft.load_state_dict(ckpt["flame"])
         if rank == 0:
             print(f"[engine] resumed from {args.start_checkpoint} at iteration {it0} with {n} Gaussians", flush=True)
     controller = None
@@ -212,9 +209,7 @@ def main(argv=None):
             print(f"\n[ITER {it}] Saving Checkpoint", flush=True)
             torch.save({"iteration": it, "params": trainer.model.params.cpu(), "binding": trainer.model.binding.cpu(),
                         "adam_m": trainer.opt.m.cpu(), "adam_v": trainer.opt.v.cpu(), "sh_degree": trainer.sh_degree,
-                        **({"flame": {"expr": trainer.flame_ft.expr.detach().cpu(), "pose": trainer.flame_ft.pose.detach().cpu(),
-                                      "translation": trainer.flame_ft.translation.detach().cpu(),
-                                      "optimizer": trainer.flame_ft.opt.state_dict()}} if trainer.flame_ft is not None else {})},
+                        **({"flame": trainer.flame_ft.state_dict()} if trainer.flame_ft is not None else {})},
                        out / f"chkpnt{it}.pth")
     torch.cuda.synchronize()
     trainer.rast.check_status()

@@ -126,7 +126,7 @@ class Trainer:
         tm.begin()
         ft = self.flame_ft
         if ft is not None:
-            ft.begin(view.timestep)    # current parameters of this timestep -> the rows the FLAME kernels read
+            ft.begin(view.timestep, self.model.binding)    # this timestep's rotation matrices from the current poses
         verts, face_xf = self.dflame.face_frames(view.timestep, 1)
         tm.mark("flame")
         fxf = face_xf[0]

@@ -1,6 +1,6 @@
 """GPU: gradients of the FLAME parameters (expression, joint poses, translation) through
-project_bwd -> omfs_face_frames_bwd -> omfs_flame_skin_bwd -> the autograd chain of engine/flame_finetune.py,
-against PyTorch-CPU autograd through the oracle's full FLAME + splat forward."""
+project_bwd -> omfs_face_frames_bwd -> omfs_flame_skin_bwd -> omfs_flame_param_bwd (engine/flame_finetune.py),
+against PyTorch-CPU autograd through the oracle's full FLAME + splat forward; device rodrigues vs the pinned host one."""
 import numpy as np
 import pytest
 import torch
@@ -32,7 +32,7 @@ def test_flame_parameter_gradients_match_autograd(n, width, height):
     t = 2
     bg = (0.2, 0.1, 0.3)
     ccam = mk(cam, sh_degree=3, bg=bg)
-    ft.begin(t)
+    ft.begin(t, model.binding)
     verts, face_xf = dflame.face_frames(t, 1)
     rast.forward(model, face_xf[0], ccam)
     gen = torch.Generator().manual_seed(5)
@@ -41,10 +41,10 @@ def test_flame_parameter_gradients_match_autograd(n, width, height):
     rast.backward(model, face_xf[0], ccam, grads, dimage=dimage.cuda().contiguous(), reg=(0.0, 1.0, 0.0, 0.6), dface=ft.dface)
     ft.backward(verts[0])
     torch.cuda.synchronize()
-    got = {"expr": ft.expr.grad[t].cpu(), "pose": ft.pose.grad[t].cpu(), "translation": ft.translation.grad[t].cpu()}
+    got = {"expr": ft.grad["expr"][t].cpu(), "pose": ft.grad["pose"][t].cpu().reshape(5, 3), "translation": ft.grad["translation"][t].cpu()}
     # rows of the other timesteps stay untouched
     others = [i for i in range(ft.expr.shape[0]) if i != t]
-    assert float(ft.expr.grad[others].abs().max()) == 0.0 and float(ft.pose.grad[others].abs().max()) == 0.0
+    assert float(ft.grad["expr"][others].abs().max()) == 0.0 and float(ft.grad["pose"][others].abs().max()) == 0.0
 
     # oracle: the same parameters as leaves of the full differentiable forward
     expr = torch.from_numpy(seq["expr"][t]).clone().requires_grad_(True)
@@ -63,6 +63,17 @@ def test_flame_parameter_gradients_match_autograd(n, width, height):
         scale = float(r.abs().max())
         assert scale > 0
         assert d <= 5e-3 * scale + 1e-6, f"{name}: max diff {d} vs max ref {scale}"
+
+
+def test_device_rodrigues_matches_the_pinned_host_formula():
+    from omfs_4d_video_gen_amd import _lib as L
+    from omfs_4d_video_gen_amd.engine.flame_rig import rodrigues
+    gen = torch.Generator().manual_seed(1)
+    aa = torch.randn(257, 3, generator=gen) * torch.logspace(-6, 0.5, 257)[:, None]
+    aa[0] = 0.0
+    out = torch.empty(257, 9, device="cuda")
+    L.check(L.load().omfs_flame_rodrigues(L.ptr(aa.cuda().contiguous()), 257, L.ptr(out), L.stream_ptr()), "omfs_flame_rodrigues")
+    assert torch.allclose(out.cpu().reshape(-1, 3, 3), rodrigues(aa), atol=2e-6)
 
 
 def test_finetuning_moves_a_perturbed_pose_back():
@@ -94,6 +105,6 @@ def test_finetuning_moves_a_perturbed_pose_back():
         if it % 4 == 0:
             losses.append(tr.loss_value())
     t_err0 = 0.005
-    t_now = tr.flame_ft.translation.detach().cpu().numpy() - np.asarray(seq["translation"], np.float32).reshape(-1, 3)
+    t_now = tr.flame_ft.translation.cpu().numpy() - np.asarray(seq["translation"], np.float32).reshape(-1, 3)
     assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), (losses[:5], losses[-5:])
     assert float(np.linalg.norm(t_now, axis=1).mean()) < 0.7 * t_err0

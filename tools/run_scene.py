@@ -18,6 +18,7 @@ ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--train", action="store_true")
+ap.add_argument("--finetune", action="store_true", help="FLAME-parameter fine-tuning on")
 ap.add_argument("--pretrain", type=int, default=100, help="training steps before the measured ones")
 a = ap.parse_args()
 srig = synthetic.make_rig(0)
@@ -32,7 +33,7 @@ for i, c in enumerate(cams):
     v = View(c, i)
     v.target = tr.render(v).clone()
     views.append(v)
-t = Trainer(rig, seq, g0, views, a.width, a.height, start_sh_degree=3)
+t = Trainer(rig, seq, g0, views, a.width, a.height, start_sh_degree=3, finetune_flame=a.finetune)
 for _ in range(a.pretrain + (a.iters if a.train else 0)):
     t.step()
 torch.cuda.synchronize()
