@@ -240,7 +240,10 @@ def main():
         "config": {"workload": f"train_ghost {N} mesh-bound Gaussians, {W}x{H}, {args.views} synthetic views, "
                                f"SH degree 3, L1+D-SSIM, Adam, fixed N (no densification)",
                    "n_gaussians": N, "width": W, "height": H, "views": args.views, "tile_pairs_D": D,
-                   "parallelism": f"dp{world} (views sharded, RCCL all-reduce of {59 * trainer.model.n_pad * 4 / 1e6:.1f} MB grads)"
+                   "parallelism": (f"dp{world} (views sharded; RCCL all-reduce of 14 planes = {14 * trainer.model.n_pad * 4 / 1e6:.1f} MB "
+                                   f"+ all-gather of {3 * trainer.model.n_pad * 4 / 1e6:.1f} MB dL/dcolour per rank, 45 SH planes rebuilt locally)"
+                                   if trainer.compact_dp else
+                                   f"dp{world} (views sharded, RCCL all-reduce of {59 * trainer.model.n_pad * 4 / 1e6:.1f} MB grads)")
                    if world > 1 else "single GPU"},
         "roofline": roofline,
         "stages_ms": {k: round(v[0], 4) for k, v in stages.items()},

@@ -69,9 +69,11 @@ typedef struct omfs_flame_rig {
 /* Joint transforms + blendshape coefficients for `n_frames` frames.
  * expr [n_frames][n_expr], rotmats [n_frames][5][9] row-major, translation unused here.
  * Writes joint_xf [n_frames][5][12] (R row-major 9, t 3) and coef [k_pad][b_pad]
- * (b_pad = n_frames rounded up to 16; rows: expr, then 36 pose features, then zeros). */
+ * (b_pad = n_frames rounded up to 16; rows: expr, then 36 pose features, then zeros).
+ * frame_index (device, may be NULL): batch column b shows row frame_index[b] of expr / rotmats (and of translation /
+ * dynamic_offset in omfs_flame_lbs) instead of row b -- an arbitrary set of timesteps in one launch. */
 int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, const float* rotmats,
-                      int n_frames, float* joint_xf, float* coef, void* stream);
+                      int n_frames, float* joint_xf, float* coef, const int32_t* frame_index, void* stream);
 
 /* verts [n_frames][v_pad][4] = LBS(v_static + basis . coef) (+ dynamic_offset) + translation.
  * dynamic_offset may be NULL; layout [n_frames][V][3]. translation [n_frames][3].
@@ -79,7 +81,7 @@ int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, const float*
  * omfs_flame_skin_bwd). */
 int omfs_flame_lbs(const omfs_flame_rig* rig, const float* coef, const float* joint_xf,
                    const float* translation, const float* dynamic_offset, int n_frames,
-                   float* verts, float* v_shaped_out, void* stream);
+                   float* verts, float* v_shaped_out, const int32_t* frame_index, void* stream);
 
 /* face_xf [n_frames][n_faces][16]: R row-major (columns a0,n,a2) 9, centre 3, scale 1, pad 3 */
 int omfs_face_frames(const float* verts, int v_pad, const int32_t* faces, int n_faces, int n_frames,
@@ -184,6 +186,10 @@ typedef struct omfs_grad_buffers {
   float* dface;           /* optional [n][16]: each Gaussian's contribution to dL/d(frame record of its parent triangle)
                              -- R row-major (9), centre (3), scale (1) -- overwritten, no atomics (FLAME fine-tuning:
                              omfs_face_frames_bwd sums them per triangle); may be NULL                            */
+  float* drgb_out;        /* optional [3][n_pad]: when set, omfs_project_bwd writes dL/d(colour) of this view (zero for
+                             clamped channels and invisible Gaussians) here and leaves the 45 SH planes of degree >= 1
+                             (planes 14..58) untouched: data-parallel ranks exchange these 3 planes instead of 45 and
+                             rebuild the summed gradient with omfs_sh_rest_grads; may be NULL                     */
 } omfs_grad_buffers;
 
 int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, const omfs_grad_buffers* gb, void* stream);
@@ -221,6 +227,20 @@ typedef struct omfs_reg_params {
 int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, const omfs_camera* cam,
                      const omfs_raster_buffers* rb, const omfs_grad_buffers* gb,
                      const omfs_reg_params* reg, void* stream);
+
+/* Data-parallel exchange in compact form.  The gradient of the SH coefficients of degree >= 1 is a rank-1 product per
+ * Gaussian and view: d SH[k][c] = Y_k(dir) * dL/dcolour[c].  Every rank holds the same parameters, triangle frames and
+ * cameras, so it can rebuild the sum over all ranks' views from the gathered dL/dcolour alone:
+ *   grads[(14 + 3(k-1) + c) * n_pad + i] = sum_w Y_k(dir_w(i)) * drgb_all[w][c][i],   k = 1..15
+ * face_xf_all [n_views][n_faces][16] (the views' timesteps), cam_pos_table [*][3] indexed by views->view[w],
+ * drgb_all [n_views][3][n_pad].  Identical on every rank (same order of summation). */
+typedef struct omfs_view_set {
+  int n_views;            /* <= 16                                                                 */
+  int view[16];           /* row of cam_pos_table of each view                                      */
+} omfs_view_set;
+
+int omfs_sh_rest_grads(const omfs_gaussians* g, const float* face_xf_all, int n_faces, const float* cam_pos_table,
+                       const omfs_view_set* views, const float* drgb_all, int sh_degree, float* grads, void* stream);
 
 /* (1-lambda) L1 + lambda (1-SSIM), 11x11 gaussian window, zero padding.
  * Writes dimage [3][H][W] and adds the scalar loss into loss_out[0] (caller zeroes).

@@ -61,7 +61,11 @@ class RasterBuffersC(C.Structure):
 
 class GradBuffersC(C.Structure):
     _fields_ = [("dsplat", c_void_p), ("grads", c_void_p), ("dimage", c_void_p), ("densify_stats", c_void_p),
-                ("dface", c_void_p)]
+                ("dface", c_void_p), ("drgb_out", c_void_p)]
+
+
+class ViewSetC(C.Structure):
+    _fields_ = [("n_views", C.c_int), ("view", C.c_int * 16)]
 
 
 class RegParamsC(C.Structure):
@@ -78,9 +82,11 @@ class AdamParamsC(C.Structure):
 SIGNATURES = {
     "omfs_abi_version": (C.c_int, []),
     "omfs_last_error": (C.c_char_p, []),
-    "omfs_flame_joints": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p]),
+    "omfs_flame_joints": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p,
-                                 c_void_p]),
+                                 c_void_p, c_void_p]),
+    "omfs_sh_rest_grads": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.c_int, c_void_p, C.POINTER(ViewSetC), c_void_p, C.c_int,
+                                     c_void_p, c_void_p]),
     "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_face_frames_bwd": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_flame_skin_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -22,15 +22,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
                                                           const float* __restrict__ expr, const float* __restrict__ rotmats,
                                                           int n_frames, int n_expr, int k_pad, int b_pad,
-                                                          float* __restrict__ joint_xf, float* __restrict__ coef) {
+                                                          float* __restrict__ joint_xf, float* __restrict__ coef,
+                                                          const int32_t* __restrict__ frame_index) {
   __shared__ float sJ[15];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= n_frames) {  // padded frame columns: zero coefficients
     for (int k = lane; k < k_pad; k += 64) coef[(size_t)k * b_pad + b] = 0.f;
     return;
   }
-  const float* e = expr + (size_t)b * n_expr;
-  const float* R = rotmats + (size_t)b * 45;
+  const int src = frame_index ? frame_index[b] : b;     // row of the sequence arrays this batch column shows
+  const float* e = expr + (size_t)src * n_expr;
+  const float* R = rotmats + (size_t)src * 45;
   if (lane < 15) {  // J[j][c] = j_static + sum_k j_expr[j*3+c][k] * e[k]
     float acc = j_static[lane];
     const float* row = j_expr + (size_t)lane * n_expr;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64) void flame_lbs_kernel(const float* __restrict__
                                                        const float* __restrict__ translation,
                                                        const float* __restrict__ dynamic_offset, int n_verts, int v_pad,
                                                        int k_pad, int n_frames, int b_pad, float* __restrict__ verts,
-                                                       float* __restrict__ v_shaped_out) {
+                                                       float* __restrict__ v_shaped_out, const int32_t* __restrict__ frame_index) {
   const int strip = blockIdx.x, cb = blockIdx.y;
   const int lane = threadIdx.x;
   const int n_strips = v_pad / 16, n_kt = k_pad / 16;
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(64) void flame_lbs_kernel(const float* __restrict__
   }
   if (frame >= n_frames) return;
   const float* X = joint_xf + (size_t)frame * 60;
-  const float tx = translation[frame * 3 + 0], ty = translation[frame * 3 + 1], tz = translation[frame * 3 + 2];
+  const int src = frame_index ? frame_index[frame] : frame;
+  const float tx = translation[src * 3 + 0], ty = translation[src * 3 + 1], tz = translation[src * 3 + 2];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     int v = strip * 16 + grp * 4 + r;
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(64) void flame_lbs_kernel(const float* __restrict__
     float oy = dot3_(M[3], M[4], M[5], x, y, z) + M[10];
     float oz = dot3_(M[6], M[7], M[8], x, y, z) + M[11];
     if (dynamic_offset) {
-      const float* d = dynamic_offset + ((size_t)frame * n_verts + v) * 3;
+      const float* d = dynamic_offset + ((size_t)src * n_verts + v) * 3;
       ox += d[0]; oy += d[1]; oz += d[2];
     }
     ox += tx; oy += ty; oz += tz;
@@ -452,25 +455,25 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
 using namespace omfs;
 
 extern "C" int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, const float* rotmats, int n_frames,
-                                 float* joint_xf, float* coef, void* stream) {
+                                 float* joint_xf, float* coef, const int32_t* frame_index, void* stream) {
   OMFS_REQUIRE(rig && expr && rotmats && joint_xf && coef, "null pointer");
   OMFS_REQUIRE(n_frames > 0 && rig->n_expr > 0 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36, "shape");
   int b_pad = cdiv(n_frames, 16) * 16;
   hipLaunchKernelGGL(flame_joints_kernel, dim3(b_pad), dim3(64), 0, (hipStream_t)stream, rig->j_static,
-                     rig->j_expr, expr, rotmats, n_frames, rig->n_expr, rig->k_pad, b_pad, joint_xf, coef);
+                     rig->j_expr, expr, rotmats, n_frames, rig->n_expr, rig->k_pad, b_pad, joint_xf, coef, frame_index);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
 
 extern "C" int omfs_flame_lbs(const omfs_flame_rig* rig, const float* coef, const float* joint_xf,
                               const float* translation, const float* dynamic_offset, int n_frames, float* verts,
-                              float* v_shaped_out, void* stream) {
+                              float* v_shaped_out, const int32_t* frame_index, void* stream) {
   OMFS_REQUIRE(rig && coef && joint_xf && translation && verts, "null pointer");
   OMFS_REQUIRE(n_frames > 0 && rig->v_pad % 16 == 0 && rig->v_pad >= rig->n_verts && rig->k_pad % 16 == 0, "shape");
   int b_pad = cdiv(n_frames, 16) * 16;
   hipLaunchKernelGGL(flame_lbs_kernel, dim3(rig->v_pad / 16, b_pad / 16), dim3(64), 0, (hipStream_t)stream,
                      rig->basis_tiled, rig->v_static, rig->lbs_weights, coef, joint_xf, translation, dynamic_offset,
-                     rig->n_verts, rig->v_pad, rig->k_pad, n_frames, b_pad, verts, v_shaped_out);
+                     rig->n_verts, rig->v_pad, rig->k_pad, n_frames, b_pad, verts, v_shaped_out, frame_index);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
                                                           const float4* __restrict__ dsplat, RegK reg,
                                                           const uint32_t* __restrict__ n_visible,
                                                           float* __restrict__ grads, float* __restrict__ densify_stats,
-                                                          float half_w, float half_h, float* __restrict__ dface) {
+                                                          float half_w, float half_h, float* __restrict__ dface, float* __restrict__ drgb_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   auto P = [&](int plane) { return params[(size_t)plane * n_pad + i]; };
@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
   const uint32_t rbits = __float_as_uint(g2[i].z);
   const bool visible = (rbits & 0xFFFFFu) != 0u;
   if (!visible) {
-    for (int p = 0; p < OMFS_NPLANES; ++p) G(p, 0.f);
+    for (int p = 0; p < (drgb_out ? OMFS_P_SH + 3 : OMFS_NPLANES); ++p) G(p, 0.f);
+    if (drgb_out)
+      for (int ch = 0; ch < 3; ++ch) drgb_out[(size_t)ch * n_pad + i] = 0.f;
     if (dface) {
       float4* o = reinterpret_cast<float4*>(dface) + (size_t)i * 4;
       for (int q = 0; q < 4; ++q) o[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -146,6 +148,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
   const float x = vx / vl, y = vy / vl, z = vz / vl;
   for (int ch = 0; ch < 3; ++ch)
     if ((clampbits >> ch) & 1u) drgb[ch] = 0.f;
+  if (drgb_out)
+    for (int ch = 0; ch < 3; ++ch) drgb_out[(size_t)ch * n_pad + i] = drgb[ch];
   {
     constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
     constexpr float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
     float ddx = 0.f, ddy = 0.f, ddz = 0.f;
     for (int ch = 0; ch < 3; ++ch) {
       const float g = drgb[ch];
-      for (int k = 0; k < 16; ++k) G(OMFS_P_SH + 3 * k + ch, k < ncoef ? basis[k] * g : 0.f);
+      for (int k = 0; k < (drgb_out ? 1 : 16); ++k) G(OMFS_P_SH + 3 * k + ch, k < ncoef ? basis[k] * g : 0.f);
       if (cam.sh_degree > 0 && g != 0.f) {
         auto Sh = [&](int k) { return P(OMFS_P_SH + 3 * k + ch); };
         float gx = -C1 * Sh(3), gy = -C1 * Sh(1), gz = C1 * Sh(2);
@@ -255,9 +259,77 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
   G(OMFS_P_OPACITY, dop * o * (1.f - o));
 }
 
+struct ViewSetK {
+  int n_views;
+  int view[16];
+};
+
+// Sum over the views of Y_k(dir_w) * dL/dcolour_w for the SH coefficients of degree >= 1 (planes 14..58): one lane
+// per Gaussian, the mean is re-posed with each view's triangle frame (64-byte gather, L2) exactly as project_bwd does.
+__global__ __launch_bounds__(256) void sh_rest_grads_kernel(int n, int n_pad, const float* __restrict__ params,
+                                                            const int32_t* __restrict__ binding, const float* __restrict__ face_xf_all,
+                                                            int n_faces, const float* __restrict__ cam_pos_table, ViewSetK vs,
+                                                            const float* __restrict__ drgb_all, int sh_degree, float* __restrict__ grads) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float l[3] = {params[(size_t)(OMFS_P_XYZ + 0) * n_pad + i], params[(size_t)(OMFS_P_XYZ + 1) * n_pad + i],
+                      params[(size_t)(OMFS_P_XYZ + 2) * n_pad + i]};
+  const int face = binding[i];
+  float acc[15][3];
+  for (int k = 0; k < 15; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
+  constexpr float C1 = 0.4886025119029199f;
+  constexpr float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+  constexpr float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                           -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+  const int ncoef = (sh_degree + 1) * (sh_degree + 1);
+  for (int w = 0; w < vs.n_views; ++w) {
+    const float* dr = drgb_all + (size_t)w * 3 * n_pad;
+    const float g0 = dr[i], g1 = dr[(size_t)n_pad + i], g2 = dr[(size_t)2 * n_pad + i];
+    if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;
+    const float4* fr = reinterpret_cast<const float4*>(face_xf_all) + ((size_t)w * n_faces + face) * 4;
+    const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2], f3 = fr[3];
+    const float Rf[9] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x};
+    const float cf[3] = {f2.y, f2.z, f2.w};
+    const float sf = f3.x;
+    float mu[3];
+    for (int r = 0; r < 3; ++r) mu[r] = fma_(dot3_(Rf[r * 3], Rf[r * 3 + 1], Rf[r * 3 + 2], l[0], l[1], l[2]), sf, cf[r]);
+    const float* cp = cam_pos_table + (size_t)vs.view[w] * 3;
+    const float vx = mu[0] - cp[0], vy = mu[1] - cp[1], vz = mu[2] - cp[2];
+    const float vl = sqrtf(fmaxf(vx * vx + vy * vy + vz * vz, 1e-20f));
+    const float x = vx / vl, y = vy / vl, z = vz / vl;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yzp = y * z, xzp = x * z;
+    float basis[15];
+    basis[0] = -C1 * y; basis[1] = C1 * z; basis[2] = -C1 * x;
+    basis[3] = C2[0] * xy; basis[4] = C2[1] * yzp; basis[5] = C2[2] * (2.f * zz - xx - yy); basis[6] = C2[3] * xzp; basis[7] = C2[4] * (xx - yy);
+    basis[8] = C3[0] * y * (3.f * xx - yy); basis[9] = C3[1] * xy * z; basis[10] = C3[2] * y * (4.f * zz - xx - yy);
+    basis[11] = C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); basis[12] = C3[4] * x * (4.f * zz - xx - yy);
+    basis[13] = C3[5] * z * (xx - yy); basis[14] = C3[6] * x * (xx - 3.f * yy);
+    for (int k = 0; k < 15; ++k) {
+      const float b = (k + 1) < ncoef ? basis[k] : 0.f;
+      acc[k][0] = fma_(b, g0, acc[k][0]); acc[k][1] = fma_(b, g1, acc[k][1]); acc[k][2] = fma_(b, g2, acc[k][2]);
+    }
+  }
+  for (int k = 0; k < 15; ++k)
+    for (int c = 0; c < 3; ++c) grads[(size_t)(OMFS_P_SH + 3 * (k + 1) + c) * n_pad + i] = acc[k][c];
+}
+
 }  // namespace omfs
 
 using namespace omfs;
+
+extern "C" int omfs_sh_rest_grads(const omfs_gaussians* g, const float* face_xf_all, int n_faces, const float* cam_pos_table,
+                                  const omfs_view_set* views, const float* drgb_all, int sh_degree, float* grads, void* stream) {
+  OMFS_REQUIRE(g && face_xf_all && cam_pos_table && views && drgb_all && grads, "null pointer");
+  OMFS_REQUIRE(g->n > 0 && g->n_pad >= g->n && g->params && g->binding && n_faces > 0, "buffers");
+  OMFS_REQUIRE(views->n_views >= 1 && views->n_views <= 16 && sh_degree >= 0 && sh_degree <= 3, "views");
+  ViewSetK vs;
+  vs.n_views = views->n_views;
+  for (int w = 0; w < 16; ++w) vs.view[w] = w < views->n_views ? views->view[w] : 0;
+  hipLaunchKernelGGL(sh_rest_grads_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, (hipStream_t)stream, g->n, g->n_pad, g->params,
+                     g->binding, face_xf_all, n_faces, cam_pos_table, vs, drgb_all, sh_degree, grads);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
 
 extern "C" int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, const omfs_camera* cam,
                                 const omfs_raster_buffers* rb, const omfs_grad_buffers* gb,
@@ -271,7 +343,7 @@ extern "C" int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, c
   RegK rk{reg->lambda_xyz, reg->thr_xyz, reg->lambda_scale, reg->thr_scale};
   hipLaunchKernelGGL(project_bwd_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, (hipStream_t)stream, g->n, g->n_pad,
                      g->params, g->binding, face_xf, pc, (const float4*)rb->g2, (const float4*)gb->dsplat, rk,
-                     reg->n_visible, gb->grads, gb->densify_stats, 0.5f * (float)cam->width, 0.5f * (float)cam->height, gb->dface);
+                     reg->n_visible, gb->grads, gb->densify_stats, 0.5f * (float)cam->width, 0.5f * (float)cam->height, gb->dface, gb->drgb_out);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

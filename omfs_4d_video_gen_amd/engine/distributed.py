@@ -1,8 +1,11 @@
 """Data-parallel plumbing: how units shard across ranks and the one exchange step of the path.
 
 train_ghost: rank r of W takes view (step*W + r) mod n_views; after the local backward every rank
-holds a full [59][n_pad] gradient buffer; ONE all-reduce (sum) over that buffer, then every rank
-applies the same Adam step with grad_scale = 1/W, so replicas stay bit-identical.
+holds a full [59][n_pad] gradient buffer; the exchange is either ONE all-reduce (sum) over that buffer ("full") or,
+by default, the compact form (trainer.py): all-reduce of the 14 planes that are not rank-1 (geometry, opacity, SH
+degree 0) + all-gather of each rank's dL/dcolour (3 planes), from which every rank rebuilds the summed gradient of the
+45 higher SH planes itself (omfs_sh_rest_grads) -- 2.3x fewer bytes per rank on the xGMI links at 8 ranks.  Then every
+rank applies the same Adam step with grad_scale = 1/W, so replicas stay bit-identical.
 render_surgery: frame f belongs to rank f mod W; no collective.
 `torch.distributed` backend "nccl" is RCCL on ROCm; tests run the same code over gloo on CPU tensors.
 """
@@ -25,6 +28,19 @@ def allreduce_sum_(buf: torch.Tensor, group=None) -> torch.Tensor:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
+
+
+def allgather_into_(out: torch.Tensor, inp: torch.Tensor, group=None) -> torch.Tensor:
+    """out [W][...] <- every rank's inp [...] (rank order).  One collective; falls back to the list form where the
+    backend lacks the tensor form."""
+    world = dist.get_world_size(group)
+    if out.shape[0] != world or out[0].shape != inp.shape:
+        raise ValueError("out must be [world_size, *inp.shape]")
+    try:
+        dist.all_gather_into_tensor(out, inp, group=group)
+    except (RuntimeError, NotImplementedError):
+        dist.all_gather(list(out.unbind(0)), inp, group=group)
+    return out
 
 
 def replicas_in_sync(params: torch.Tensor, group=None) -> bool:

@@ -79,19 +79,25 @@ class FlameFineTuner:
             self.dface = torch.empty(key[1], 16, device=binding.device)
         self._csr_key = key
 
-    def begin(self, t: int, binding: torch.Tensor):
-        """Before the FLAME forward of timestep t: its rotation matrices from the current poses."""
+    def begin(self, t: int, binding: torch.Tensor, all_timesteps: bool = False):
+        """Before the FLAME forward of timestep t: its rotation matrices from the current poses (all timesteps when the
+        forward poses other ranks' views as well)."""
         self.bind(binding)
-        L.check(L.load().omfs_flame_rodrigues(L.ptr(self.pose[t]), 5, L.ptr(self.df.rotmats[t]), L.stream_ptr()), "omfs_flame_rodrigues")
+        if all_timesteps:
+            self.refresh_rotmats()
+        else:
+            L.check(L.load().omfs_flame_rodrigues(L.ptr(self.pose[t]), 5, L.ptr(self.df.rotmats[t]), L.stream_ptr()), "omfs_flame_rodrigues")
         self._t = t
 
-    def backward(self, verts: torch.Tensor):
-        """verts: [v_pad][4] posed vertices of the frame (DeviceFlame.face_frames); self.dface filled by project_bwd.
-        Leaves the gradient of timestep t in row t of the dense gradient tensors (all other rows zero)."""
+    def backward(self, verts: torch.Tensor, nb: int = 1, col: int = 0):
+        """verts: [v_pad][4] posed vertices of the frame (column `col` of the last FLAME forward with batch nb);
+        self.dface filled by project_bwd.  Leaves the gradient of timestep t in row t of the dense gradient tensors
+        (all other rows zero)."""
         t = self._t
         df = self.df
         lib, s = L.load(), L.stream_ptr()
-        joint_xf, _, _, _, v_shaped = df._buffers(1)        # written by the FLAME forward kernels for this frame
+        joint_all, _, _, _, vs_all = df._buffers(nb)        # written by the FLAME forward kernels
+        joint_xf, v_shaped = joint_all[col], vs_all[col]
         self.dverts.zero_()
         self.sums.zero_()
         if self._last_t is not None and self._last_t != t:

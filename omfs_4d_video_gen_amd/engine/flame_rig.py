@@ -187,16 +187,26 @@ class DeviceFlame:
         The returned tensors are reused by the next call with the same nb."""
         if not (0 <= t0 and t0 + nb <= self.n_frames):
             raise IndexError(f"frames [{t0},{t0 + nb}) outside sequence of {self.n_frames}")
+        return self._run(L.ptr(self.expr[t0]), L.ptr(self.rotmats[t0]), L.ptr(self.translation[t0]),
+                         L.ptr(self.dynamic[t0]) if self.dynamic is not None else 0, nb, 0, out)
+
+    def face_frames_indexed(self, frame_index: torch.Tensor):
+        """Arbitrary timesteps in one batch: frame_index is a device int32 tensor [nb] of sequence rows.
+        Returns (verts [nb][v_pad][4], face_xf [nb][F][16]); column b shows timestep frame_index[b]."""
+        if frame_index.dtype != torch.int32 or not frame_index.is_cuda or frame_index.dim() != 1:
+            raise ValueError("frame_index must be a 1-D int32 device tensor")
+        return self._run(L.ptr(self.expr), L.ptr(self.rotmats), L.ptr(self.translation),
+                         L.ptr(self.dynamic) if self.dynamic is not None else 0, int(frame_index.shape[0]), L.ptr(frame_index), None)
+
+    def _run(self, expr_p, rot_p, trans_p, dyn_p, nb, index_p, out):
         lib = L.load()
         s = L.stream_ptr()
         joint_xf, coef, verts, face_xf, v_shaped = self._buffers(nb)
         if out is not None:
             face_xf = out
-        L.check(lib.omfs_flame_joints(self.c_rig, L.ptr(self.expr[t0]), L.ptr(self.rotmats[t0]), nb, L.ptr(joint_xf),
-                                      L.ptr(coef), s), "omfs_flame_joints")
-        dyn = L.ptr(self.dynamic[t0]) if self.dynamic is not None else 0
-        L.check(lib.omfs_flame_lbs(self.c_rig, L.ptr(coef), L.ptr(joint_xf), L.ptr(self.translation[t0]), dyn, nb,
-                                   L.ptr(verts), L.ptr(v_shaped), s), "omfs_flame_lbs")
+        L.check(lib.omfs_flame_joints(self.c_rig, expr_p, rot_p, nb, L.ptr(joint_xf), L.ptr(coef), index_p, s), "omfs_flame_joints")
+        L.check(lib.omfs_flame_lbs(self.c_rig, L.ptr(coef), L.ptr(joint_xf), trans_p, dyn_p, nb, L.ptr(verts), L.ptr(v_shaped),
+                                   index_p, s), "omfs_flame_lbs")
         L.check(lib.omfs_face_frames(L.ptr(verts), self.v_pad, L.ptr(self.faces), self.rig.n_faces, nb, L.ptr(face_xf), s),
                 "omfs_face_frames")
         return verts, face_xf

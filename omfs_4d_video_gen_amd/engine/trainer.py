@@ -17,8 +17,9 @@ from dataclasses import dataclass, field
 import numpy as np
 import torch
 
+from .. import _lib as L
 from .flame_rig import DeviceFlame, FlameRig
-from .gaussians import GaussianModel, NPLANES
+from .gaussians import GaussianModel, NPLANES, P_SH
 from .rasterizer import Adam, Rasterizer, default_lr_planes, make_camera_struct
 
 STAGES = ("flame", "project", "bin_count", "bin_scan", "bin_scatter", "tile_sort", "composite_fwd", "loss", "composite_bwd",
@@ -98,6 +99,15 @@ class Trainer:
         self.timer = StageTimer(False)
         self._cams = {}
         self.densify_stats = None      # [2][n_pad] when adaptive density control is on (engine/densify.py)
+        # data-parallel exchange: "compact" (default) = all-reduce of the 14 non-rank-1 planes + all-gather of dL/dcolour,
+        # the 45 higher SH planes are rebuilt on every rank (engine/distributed.py); "full" = one all-reduce of all 59
+        import os as _os
+        self.compact_dp = self.world > 1 and self.world <= 16 and _os.environ.get("OMFS_DP_EXCHANGE", "compact") != "full"
+        self._dp_patterns = {}
+        self.drgb_local = self.drgb_all = self.cam_pos_table = None
+        if self.compact_dp:
+            cp = np.stack([np.asarray(make_camera_struct(v.camera).cam_pos, np.float32) for v in views])
+            self.cam_pos_table = torch.from_numpy(cp).to(self.device)
         self.flame_ft = None           # FLAME-parameter fine-tuning (engine/flame_finetune.py)
         if finetune_flame:
             from .flame_finetune import FlameFineTuner
@@ -110,6 +120,22 @@ class Trainer:
             c = make_camera_struct(view.camera, sh_degree=sh_degree, bg=self.bg)
             self._cams[key] = c
         return c
+
+    def _dp_pattern(self, step: int):
+        """(device int32 timesteps [W], omfs_view_set) of ALL ranks' views at this step; the schedule is periodic,
+        so the few distinct patterns are built once (no per-step host-to-device copy)."""
+        from .distributed import view_index
+        ids = tuple(view_index(step, r, self.world, len(self.views)) for r in range(self.world))
+        pat = self._dp_patterns.get(ids)
+        if pat is None:
+            ts = torch.tensor([self.views[i].timestep for i in ids], dtype=torch.int32, device=self.device)
+            vs = L.ViewSetC()
+            vs.n_views = self.world
+            for w, i in enumerate(ids):
+                vs.view[w] = i
+            pat = (ts, vs)
+            self._dp_patterns[ids] = pat
+        return pat
 
     def view_for_step(self, step: int) -> View:
         from .distributed import view_index
@@ -125,11 +151,17 @@ class Trainer:
         r, tm = self.rast, self.timer
         tm.begin()
         ft = self.flame_ft
-        if ft is not None:
-            ft.begin(view.timestep, self.model.binding)    # this timestep's rotation matrices from the current poses
-        verts, face_xf = self.dflame.face_frames(view.timestep, 1)
+        if ft is not None:             # rotation matrices from the current poses
+            ft.begin(view.timestep, self.model.binding, all_timesteps=self.compact_dp)
+        nb, col = 1, 0
+        if self.compact_dp:            # pose ALL ranks' views of this step in one batch (same cost as one frame)
+            pat = self._dp_pattern(it)
+            verts, face_xf = self.dflame.face_frames_indexed(pat[0])
+            nb, col = self.world, self.rank
+        else:
+            verts, face_xf = self.dflame.face_frames(view.timestep, 1)
         tm.mark("flame")
-        fxf = face_xf[0]
+        fxf = face_xf[col]
         r.project(self.model, fxf, cam); tm.mark("project")
         from .. import _lib as L
         lib = L.load()
@@ -143,17 +175,26 @@ class Trainer:
         r.loss.zero_()
         r.loss_l1_ssim(view.target, self.lambda_dssim); tm.mark("loss")
         r.dsplat.zero_()
+        if self.compact_dp and (self.drgb_local is None or self.drgb_local.shape[1] != self.model.n_pad):
+            self.drgb_local = torch.zeros(3, self.model.n_pad, device=self.device)
+            self.drgb_all = torch.zeros(self.world, 3, self.model.n_pad, device=self.device)
         gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
-                            L.ptr(ft.dface) if ft is not None else 0)
+                            L.ptr(ft.dface) if ft is not None else 0, L.ptr(self.drgb_local) if self.compact_dp else 0)
         L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")
         L.check(lib.omfs_count_visible(r.rb, r.n, L.ptr(r.n_visible), s), "omfs_count_visible")
         rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
         L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
         if ft is not None:
-            ft.backward(verts[0]); tm.mark("flame_bwd")
+            ft.backward(verts[col], nb, col); tm.mark("flame_bwd")
         if self.world > 1:
-            from .distributed import allreduce_sum_
-            allreduce_sum_(self.grads, self.pg)
+            from .distributed import allgather_into_, allreduce_sum_
+            if self.compact_dp:
+                allreduce_sum_(self.grads[:P_SH + 3], self.pg)            # 14 contiguous planes
+                allgather_into_(self.drgb_all, self.drgb_local, self.pg)
+                L.check(lib.omfs_sh_rest_grads(g, L.ptr(face_xf), self.dflame.rig.n_faces, L.ptr(self.cam_pos_table), pat[1],
+                                               L.ptr(self.drgb_all), self.sh_degree, L.ptr(self.grads), s), "omfs_sh_rest_grads")
+            else:
+                allreduce_sum_(self.grads, self.pg)
             if ft is not None:         # every rank touched a different timestep: dense (tiny) gradient tensors, summed
                 for gr in ft.grads():
                     allreduce_sum_(gr, self.pg)
