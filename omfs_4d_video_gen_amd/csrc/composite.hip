@@ -70,6 +70,12 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
   return m;
 }
 
+#ifdef OMFS_DEBUG_COUNTERS
+__device__ unsigned long long omfs_dbg[8];   // bwd: visits, visits with a hit, hit lanes; fwd: visits, visits with a hit, hit lanes
+#define OMFS_DBG_ADD(i, v) do { if (lane_id() == 0) atomicAdd(&omfs_dbg[i], (unsigned long long)(v)); } while (0)
+#else
+#define OMFS_DBG_ADD(i, v) do { } while (0)
+#endif
 constexpr int WB = 64;   // splats staged per wave and step
 #ifndef OMFS_FWD_SEQ_SEGS
 #define OMFS_FWD_SEQ_SEGS 4
@@ -170,6 +176,13 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
       m &= m - 1ull;
       jn = m ? __builtin_ctzll(m) : 0;
       an = s0[jn]; cn = s1[jn]; cbn = s2[jn];
+      {
+        const float dx_ = a.x - fx, dy_ = a.y - fy;
+        const float p2_ = fma_(a.z * dx_, dx_, fma_(c.x * dy_, dy_, a.w * dx_ * dy_));
+        const unsigned long long hb = __ballot(!done && p2_ <= 0.f && p2_ + c.y >= LOG2_INV255);
+        (void)hb;
+        OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb));
+      }
       if (!done) {
         const float dx = a.x - fx, dy = a.y - fy;
         const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
@@ -618,7 +631,9 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
       const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
       const float e = p2 + c.y;
       const bool hit = contributor <= last && p2 <= 0.f && e >= LOG2_INV255;
-      if (__ballot(hit) == 0ull) continue;  // nobody in this quadrant was touched: nothing to reduce
+      const unsigned long long hit_bal = __ballot(hit);
+      OMFS_DBG_ADD(0, 1); OMFS_DBG_ADD(1, hit_bal != 0ull); OMFS_DBG_ADD(2, __popcll(hit_bal));
+      if (hit_bal == 0ull) continue;  // nobody in this quadrant was touched: nothing to reduce
       if (hit) {
         const float G = __builtin_amdgcn_exp2f(p2);
         const float oG = cb.y * G;                              // opacity * G
@@ -716,6 +731,14 @@ extern "C" int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buff
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
+
+#ifdef OMFS_DEBUG_COUNTERS
+extern "C" int omfs_debug_counters(unsigned long long* out8, int reset) {
+  OMFS_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(omfs_dbg), 64));
+  if (reset) { unsigned long long z[8] = {0}; OMFS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(omfs_dbg), z, 64)); }
+  return OMFS_OK;
+}
+#endif
 
 extern "C" int omfs_image_to_rgb8(const float* image, int width, int height, uint8_t* rgb8, void* stream) {
   OMFS_REQUIRE(image && rgb8 && width > 0 && height > 0, "args");
