@@ -311,6 +311,36 @@ def main():
             out["aux"]["train_iters_per_sec_with_flame_finetune"] = round(100 / (time.perf_counter() - t4), 2)
             del tf
             log("flame fine-tune aux done")
+            # flame_fitter.fit_flame_to_landmarks (reference flame_fitter.py:294-444) on 300 frames of synthetic landmarks:
+            # HIP SimpleFLAME forward/backward vs the PyTorch-CPU port of the reference's loop (oracle/simple_flame.py)
+            import contextlib
+            import io
+            import tempfile
+            from omfs_4d_video_gen_amd import flame_fitter as ff
+            from oracle.simple_flame import SimpleFlameOracle, fit as cpu_fit
+            with tempfile.TemporaryDirectory() as td:
+                synthetic.write_flame_pickle(srig, os.path.join(td, "flame2023.pkl"), os.path.join(td, "lmk.npy"))
+                ff.FLAME_LMK_PATH = type(ff.FLAME_LMK_PATH)(os.path.join(td, "lmk.npy"))
+                rng = np.random.default_rng(0)
+                Tf = 300
+                lmk = [np.stack([960 + 220 * rng.standard_normal(68), 540 + 260 * rng.standard_normal(68)], 1).astype(np.float32) for _ in range(Tf)]
+                sink = io.StringIO()
+                with contextlib.redirect_stdout(sink):
+                    ff.fit_flame_to_landmarks(lmk, (1920, 1080), os.path.join(td, "flame2023.pkl"), n_iters=5, device="cuda")
+                    torch.cuda.synchronize()
+                    t5 = time.perf_counter()
+                    ff.fit_flame_to_landmarks(lmk, (1920, 1080), os.path.join(td, "flame2023.pkl"), n_iters=100, device="cuda")
+                    torch.cuda.synchronize()
+                    d_gpu = time.perf_counter() - t5
+                init_rot = np.array([ff.estimate_head_pose_from_landmarks(l, (1920, 1080)) for l in lmk], np.float32).reshape(Tf, 3)
+                torch.set_num_threads(host_cores())
+                t6 = time.perf_counter()
+                cpu_fit(SimpleFlameOracle(srig), np.stack(lmk), [True] * Tf, (1920, 1080), init_rot, n_iters=5)
+                d_cpu = time.perf_counter() - t6
+            out["aux"]["flame_fit"] = {"frames": Tf, "hip_iters_per_sec": round(100 / d_gpu, 1), "cpu_port_iters_per_sec": round(5 / d_cpu, 2),
+                                       "note": "fit_flame_to_landmarks end to end (setup included) on 300 frames x 68 landmarks; "
+                                               "HIP SimpleFLAME fwd/bwd vs the PyTorch-CPU port of the reference loop"}
+            log("flame fit aux done")
 
     # ---- CPU baseline (rank 0, single GPU run only): the PyTorch-CPU oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -165,3 +165,29 @@ def test_validation_reporting_metrics_and_report(tmp_path):
     assert rep["summary"]["count"] == 5 and rep["summary"]["by_bucket"]["front"]["count"] == 2
     assert rep["rows"][1]["psnr"] == 99.0 and rep["rows"][0]["psnr"] < 20
     assert (tmp_path / "rep" / "human_review_checklist.md").read_text().startswith("# Human Review Checklist")
+
+
+def test_render_uses_tuned_flame_plus_dataset_edits(tmp_path):
+    """engine/render.py: a model trained with --finetune_flame_params stores the tuned and the source sequence;
+    the rendered sequence is tuned + (dataset - source), so render_surgery's edits act on the tuned parameters."""
+    import numpy as np
+    from omfs_4d_video_gen_amd.engine.render import tuned_flame
+    T = 5
+    rng = np.random.default_rng(0)
+    src = {"expr": rng.standard_normal((T, 100)).astype(np.float32), "rotation": rng.standard_normal((T, 3)).astype(np.float32),
+           "neck_pose": np.zeros((T, 3), np.float32), "jaw_pose": rng.standard_normal((T, 3)).astype(np.float32),
+           "eyes_pose": np.zeros((T, 6), np.float32), "translation": rng.standard_normal((T, 3)).astype(np.float32),
+           "shape": np.zeros(300, np.float32)}
+    tuned = {k: (v + 0.01).astype(np.float32) if k != "shape" else v for k, v in src.items()}
+    assert tuned_flame(tmp_path, src) is src                                  # nothing stored: the dataset's own sequence
+    np.savez(tmp_path / "flame_param.npz", **tuned)
+    np.savez(tmp_path / "flame_param_source.npz", **src)
+    edited = {k: v.copy() for k, v in src.items()}
+    edited["translation"][:, 1] += 0.003                                      # a LeFort-like edit of the dataset
+    edited["jaw_pose"][:, 0] += 0.02
+    out = tuned_flame(tmp_path, edited)
+    assert np.allclose(out["translation"], tuned["translation"] + [0.0, 0.003, 0.0], atol=1e-7)
+    assert np.allclose(out["jaw_pose"], tuned["jaw_pose"] + [0.02, 0.0, 0.0], atol=1e-7)
+    assert np.allclose(out["expr"], tuned["expr"]) and np.array_equal(out["shape"], src["shape"])
+    other = {k: (v[:3] if k != "shape" else v) for k, v in src.items()}           # a different sequence: dataset wins
+    assert tuned_flame(tmp_path, other) is other

@@ -1,5 +1,6 @@
 """CPU, world_size 2 over gloo: the N>1 path of the engine -- views shard disjointly, the ONE
-all-reduce over the gradient SoA gives the cross-rank sum, replicas that apply the same update stay
+all-reduce over the gradient SoA gives the cross-rank sum (also on the 14-plane slice of the compact
+exchange, whose dL/dcolour planes are all-gathered in rank order), replicas that apply the same update stay
 bit-identical, and frames shard without overlap."""
 import os
 import socket
@@ -18,7 +19,7 @@ def _free_port():
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from omfs_4d_video_gen_amd.engine.distributed import allreduce_sum_, frames_of_rank, replicas_in_sync, view_index
+    from omfs_4d_video_gen_amd.engine.distributed import allgather_into_, allreduce_sum_, frames_of_rank, replicas_in_sync, view_index
     n_views, n_pad = 16, 512
     views = [view_index(step, rank, world, n_views) for step in range(8)]
     g = torch.Generator().manual_seed(100 + rank)
@@ -32,6 +33,17 @@ def _worker(rank, world, port, q):
         assert torch.equal(grads, gathered[0] + gathered[1])
         params -= 0.01 * grads / world              # same update on every rank
         assert replicas_in_sync(params)
+    # compact exchange: 14-plane slice all-reduced in place, dL/dcolour planes gathered in rank order
+    grads = torch.randn(59, n_pad, generator=g)
+    local = grads.clone()
+    allreduce_sum_(grads[:14])
+    both = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    assert torch.equal(grads[:14], (both[0] + both[1])[:14]) and torch.equal(grads[14:], local[14:])
+    drgb = torch.full((3, n_pad), float(rank + 1))
+    out = torch.zeros(world, 3, n_pad)
+    allgather_into_(out, drgb)
+    assert all(torch.equal(out[r], torch.full((3, n_pad), float(r + 1))) for r in range(world))
     bad = params + (rank * 1e-3)
     assert not replicas_in_sync(bad)
     q.put((rank, views, list(frames_of_rank(11, rank, world)), params.double().sum().item()))
