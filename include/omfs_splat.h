@@ -154,7 +154,10 @@ typedef struct omfs_raster_buffers {
   float* image;           /* [3][height][width]                                                  */
   float* final_T;         /* [height][width]                                                     */
   uint32_t* n_contrib;    /* [height][width]                                                     */
+  uint32_t flags;         /* OMFS_RB_FORWARD_ONLY: no backward pass will follow (render_surgery): the forward skips
+                             the segment checkpoints (only the hand-over slots between its two kernels are written) */
 } omfs_raster_buffers;
+#define OMFS_RB_FORWARD_ONLY 1u
 
 /* deform + project + colour for one view -> g0,g1,g2. face_xf [n_faces][16]. */
 int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_camera* cam,

@@ -15,6 +15,7 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see module d
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
 ABI_VERSION = 3
+RB_FORWARD_ONLY = 1
 NPLANES = 59
 TILE = 16
 SEG = 128
@@ -56,7 +57,7 @@ class RasterBuffersC(C.Structure):
                 ("tile_order", c_void_p), ("keys", c_void_p), ("keys_tmp", c_void_p), ("sorted_ids", c_void_p),
                 ("dup_capacity", C.c_uint32), ("sort_lds_pairs", C.c_uint32), ("status", c_void_p),
                 ("seg_ckpt", c_void_p), ("order_seg0", c_void_p), ("seg_capacity", C.c_uint32),
-                ("image", c_void_p), ("final_T", c_void_p), ("n_contrib", c_void_p)]
+                ("image", c_void_p), ("final_T", c_void_p), ("n_contrib", c_void_p), ("flags", C.c_uint32)]
 
 
 class GradBuffersC(C.Structure):

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
                                                            const float4* __restrict__ g0, const float4* __restrict__ g1,
                                                            const float4* __restrict__ g2, float* __restrict__ image,
                                                            float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                           float4* __restrict__ seg_ckpt) {
+                                                           float4* __restrict__ seg_ckpt, int keep_ckpt) {
   __shared__ float4 s0[WB];
   __shared__ float4 s1[WB];
   __shared__ float s2[WB];
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
   const uint32_t lim = deep ? beg + (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG) : end;
   for (uint32_t b = beg; b < lim && live != 0ull; b += WB) {
     // entering a new segment: checkpoint (T, C) so the backward pass can start there (see composite_bwd_kernel)
-    if (b != beg && ((b - beg) & (OMFS_SEG - 1)) == 0u)
+    if (keep_ckpt && b != beg && ((b - beg) & (OMFS_SEG - 1)) == 0u)
       seg_ckpt[((size_t)(beg / OMFS_SEG) + tile + (b - beg) / OMFS_SEG) * 256 + quad * 64 + lane] = make_float4(T, C0, C1, C2);
     // ---- stage this step's 64 entries
     const uint32_t k = b + lane;
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
     CompCam cam, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ sorted_ids, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ g2, float* __restrict__ image, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float4* __restrict__ seg_ckpt) {
+    uint32_t* __restrict__ n_contrib, float4* __restrict__ seg_ckpt, int keep_ckpt) {
   __shared__ float4 pg0[DEEP_WAVES][WB];
   __shared__ float4 pg1[DEEP_WAVES][WB];
   __shared__ float pg2[DEEP_WAVES][WB];
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
       __syncthreads();   // res is reused by the next round
     }
     // boundary checkpoints of this batch (the state in front of segment sbatch + wave)
-    if (wave < nb && have_boundary)
+    if (keep_ckpt && wave < nb && have_boundary)
       seg_ckpt[(slot0 + sbatch + wave) * 256 + quad * 64 + lane] = make_float4(bT, bC0, bC1, bC2);
     live = __ballot(!done);
     __syncthreads();     // comp is rewritten by the next batch
@@ -703,14 +703,15 @@ extern "C" int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buff
   CompCam cc = make_compcam(cam);
   const int n_tiles = cc.gx * cdiv(cam->height, OMFS_TILE);
   OMFS_REQUIRE(rb->seg_capacity >= (uint32_t)n_tiles + rb->dup_capacity / OMFS_SEG, "seg_capacity < n_tiles + dup_capacity/OMFS_SEG");
+  const int keep_ckpt = (rb->flags & OMFS_RB_FORWARD_ONLY) ? 0 : 1;
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_tiles * 4), dim3(64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
-                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt);
+                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt);
   OMFS_CHECK_HIP(hipGetLastError());
   // quadrants whose list is longer than FWD_SEQ_SEGS segments and still unsaturated (the rest exit at once)
   hipLaunchKernelGGL(composite_fwd_deep_kernel, dim3(n_tiles * 4), dim3(DEEP_WAVES * 64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
-                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt);
+                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

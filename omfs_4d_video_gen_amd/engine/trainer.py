@@ -223,6 +223,7 @@ class Renderer:
         self.dflame = DeviceFlame(rig, flame_params, device=device)
         self.model = GaussianModel(gaussians, device=device)
         self.rast = Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity)
+        self.rast.rb.flags = L.RB_FORWARD_ONLY     # no backward pass follows: the forward skips the segment checkpoints
         self.bg, self.sh_degree = tuple(bg), sh_degree
         self.timer = StageTimer(False)
         self._cams = {}
