@@ -171,16 +171,18 @@ class DeviceFlame:
                                  L.ptr(self.lbs_weights), L.ptr(self.j_static), L.ptr(self.j_expr))
         self._scratch = {}
         self.keep_v_shaped = False     # FLAME fine-tuning: flame_lbs also stores the blend-shaped vertices
+        self.slot = 0                  # output buffer set (the trainer poses the next step's frames on a side stream)
 
     def _buffers(self, nb: int):
-        if nb not in self._scratch:
+        key = (nb, self.slot)
+        if key not in self._scratch:
             b_pad = (nb + 15) // 16 * 16
             dev = self.device
-            self._scratch[nb] = (
+            self._scratch[key] = (
                 torch.empty(nb, 60, device=dev), torch.empty(self.k_pad, b_pad, device=dev),
                 torch.empty(nb, self.v_pad, 4, device=dev), torch.empty(nb, self.rig.n_faces, 16, device=dev),
                 torch.empty(nb, self.v_pad, 4, device=dev) if self.keep_v_shaped else None)
-        return self._scratch[nb]
+        return self._scratch[key]
 
     def face_frames(self, t0: int, nb: int = 1, out=None):
         """Frames t0..t0+nb-1 -> (verts [nb][v_pad][4], face_xf [nb][F][16]) device tensors.

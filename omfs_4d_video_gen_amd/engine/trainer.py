@@ -108,6 +108,9 @@ class Trainer:
         if self.compact_dp:
             cp = np.stack([np.asarray(make_camera_struct(v.camera).cam_pos, np.float32) for v in views])
             self.cam_pos_table = torch.from_numpy(cp).to(self.device)
+        self._side_stream = torch.cuda.Stream(device=self.device)
+        self._events = [(torch.cuda.Event(), torch.cuda.Event()), (torch.cuda.Event(), torch.cuda.Event())]
+        self._prefetch = None
         self.flame_ft = None           # FLAME-parameter fine-tuning (engine/flame_finetune.py)
         if finetune_flame:
             from .flame_finetune import FlameFineTuner
@@ -120,6 +123,21 @@ class Trainer:
             c = make_camera_struct(view.camera, sh_degree=sh_degree, bg=self.bg)
             self._cams[key] = c
         return c
+
+    def _frame_key(self, step: int):
+        from .distributed import view_index
+        if self.compact_dp:
+            return (step & 1,) + tuple(self.views[view_index(step, r, self.world, len(self.views))].timestep for r in range(self.world))
+        return (step & 1, self.view_for_step(step).timestep)
+
+    def _pose_frames(self, step: int):
+        """FLAME forward for the frames of `step` on the current stream: (verts, face_xf, batch, own column, dp pattern)."""
+        if self.compact_dp:            # pose ALL ranks' views of this step in one batch (same cost as one frame)
+            pat = self._dp_pattern(step)
+            verts, face_xf = self.dflame.face_frames_indexed(pat[0])
+            return verts, face_xf, self.world, self.rank, pat
+        verts, face_xf = self.dflame.face_frames(self.view_for_step(step).timestep, 1)
+        return verts, face_xf, 1, 0, None
 
     def _dp_pattern(self, step: int):
         """(device int32 timesteps [W], omfs_view_set) of ALL ranks' views at this step; the schedule is periodic,
@@ -153,13 +171,27 @@ class Trainer:
         ft = self.flame_ft
         if ft is not None:             # rotation matrices from the current poses
             ft.begin(view.timestep, self.model.binding, all_timesteps=self.compact_dp)
-        nb, col = 1, 0
-        if self.compact_dp:            # pose ALL ranks' views of this step in one batch (same cost as one frame)
-            pat = self._dp_pattern(it)
-            verts, face_xf = self.dflame.face_frames_indexed(pat[0])
-            nb, col = self.world, self.rank
+            verts, face_xf, nb, col, pat = self._pose_frames(it)
         else:
-            verts, face_xf = self.dflame.face_frames(view.timestep, 1)
+            # the sequence is fixed: this step's frames were posed on the side stream during the previous step,
+            # the next step's are posed now, concurrently with this step's kernels (double-buffered outputs)
+            slot = it & 1
+            want = self._frame_key(it)
+            if self._prefetch is not None and self._prefetch[0] == want:
+                torch.cuda.current_stream().wait_event(self._prefetch[1])
+                verts, face_xf, nb, col, pat = self._prefetch[2]
+            else:
+                self.dflame.slot = slot
+                verts, face_xf, nb, col, pat = self._pose_frames(it)
+            ev_main, ev_side = self._events[slot]
+            ev_main.record()
+            with torch.cuda.stream(self._side_stream):
+                self._side_stream.wait_event(ev_main)       # the other buffer set was last read by the previous step
+                self.dflame.slot = slot ^ 1
+                nxt = self._pose_frames(it + 1)
+                ev_side.record(self._side_stream)
+            self._prefetch = (self._frame_key(it + 1), ev_side, nxt)
+            self.dflame.slot = slot
         tm.mark("flame")
         fxf = face_xf[col]
         r.project(self.model, fxf, cam); tm.mark("project")
