@@ -142,8 +142,8 @@ typedef struct omfs_raster_buffers {
   uint32_t* keys_tmp;     /* [dup_capacity][2] scratch for tiles longer than the LDS capacity    */
   uint32_t* sorted_ids;   /* [dup_capacity] per-tile front-to-back Gaussian ids                  */
   uint32_t dup_capacity;
-  uint32_t sort_lds_pairs; /* longest tile list sorted inside LDS (0 = default 8960 pairs = 160 KB; 16 B of LDS
-                              each); longer lists are sorted through keys/keys_tmp in global memory */
+  uint32_t sort_lds_pairs; /* longest tile list whose bucket-ordered copy is kept in LDS (0 = default 7936 pairs = 78 KB,
+                              two workgroups per CU; 8 B of LDS each); longer lists keep it in keys_tmp        */
   uint32_t* status;       /* [1] OMFS_STATUS_* bits, OR-ed by kernels (caller zeroes)            */
   /* forward checkpoints for the depth-parallel backward pass: per pixel (T, C.rgb) on entering list segment k
    * (k >= 1) of tile t, stored at slot tile_start[t]/OMFS_SEG + t + k; seg_capacity >= n_tiles + dup_capacity/OMFS_SEG */

@@ -323,23 +323,25 @@ __device__ __forceinline__ uint2* radix_sort_pairs(uint2* a, uint2* b, int n, vo
   return src;
 }
 
-// Distribution sort for lists that fit in LDS.  Depths inside one tile spread almost uniformly between the tile's
-// nearest and farthest splat, so ONE monotone bucket pass -- bucket = floor((key - min) * NB / (max - min + 1)),
-// NB = 4 NT buckets (about one key per bucket) -- followed by ranking inside each bucket, by (depth
-// bits, id), replaces the 3-4 counting passes of the radix sort: the result is the same total order.  Returns
-// nullptr (input untouched in a) when some bucket holds more than BUCKET_MAX keys (many equal or clustered depths);
+// Distribution sort.  Depths inside one tile spread almost uniformly between the tile's nearest and farthest splat,
+// so ONE monotone bucket pass -- bucket = floor((key - min) * NB / (max - min + 1)), NB = 4 NT buckets (about one key
+// per bucket) -- followed by ranking inside each bucket, by (depth bits, id), replaces the 3-4 counting passes of a
+// radix sort: the result is the same total order.  The unsorted pairs are read straight from global memory (three
+// passes over 8 B per pair, L2 resident: the scatter has just written them); only the bucket-ordered copy b lives in LDS
+// (or in keys_tmp for lists beyond the LDS capacity), and the ranking pass writes the ids to their final place.
+// Returns false (nothing written) when some bucket holds more than BUCKET_MAX keys (many equal or clustered depths);
 // the caller then falls back to the radix sort.  hist: NB words, misc: 8 words.
 constexpr int BUCKET_MAX = 48;
 
 template <int NT>
-__device__ __forceinline__ uint2* bucket_sort_pairs(uint2* a, uint2* b, int n, volatile uint32_t* hist,
-                                                    volatile uint32_t* misc) {
+__device__ __forceinline__ bool bucket_sort_to_ids(const uint2* __restrict__ src, uint2* b, int n, volatile uint32_t* hist,
+                                                   volatile uint32_t* misc, uint32_t* __restrict__ out_ids) {
   constexpr int NB = (NT / 64) * 256;
   constexpr int PER = NB / NT;   // 4 consecutive buckets per thread in the scan
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // ---- key range
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-  for (int k = tid; k < n; k += NT) { const uint32_t x = a[k].x; kmin = min(kmin, x); kmax = max(kmax, x); }
+  for (int k = tid; k < n; k += NT) { const uint32_t x = src[k].x; kmin = min(kmin, x); kmax = max(kmax, x); }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
@@ -354,7 +356,7 @@ __device__ __forceinline__ uint2* bucket_sort_pairs(uint2* a, uint2* b, int n, v
   const float scale = (float)NB / ((float)(misc[1] - kmin) + 1.f);
   auto bucket_of = [&](uint32_t x) { return min(NB - 1, (int)((float)(x - kmin) * scale)); };   // monotone in x
   // ---- histogram
-  for (int k = tid; k < n; k += NT) atomicAdd((uint32_t*)&hist[bucket_of(a[k].x)], 1u);
+  for (int k = tid; k < n; k += NT) atomicAdd((uint32_t*)&hist[bucket_of(src[k].x)], 1u);
   __syncthreads();
   // ---- exclusive scan over the buckets (thread t owns buckets PER t .. PER t + PER - 1)
   uint32_t c[PER], sum = 0, big = 0;
@@ -369,21 +371,20 @@ __device__ __forceinline__ uint2* bucket_sort_pairs(uint2* a, uint2* b, int n, v
   for (int w = 0; w < wave; ++w) base += hist[w];
   const bool fallback = misc[2] != 0u;
   __syncthreads();                               // totals consumed before the cursors overwrite them
-  if (fallback) return nullptr;
+  if (fallback) return false;
   uint32_t run = base + incl - sum;
 #pragma unroll
   for (int j = 0; j < PER; ++j) { hist[tid * PER + j] = run; run += c[j]; }   // cursor = first slot of the bucket
   __syncthreads();
   // ---- placement (order inside a bucket is arbitrary)
   for (int k = tid; k < n; k += NT) {
-    const uint2 item = a[k];
+    const uint2 item = src[k];
     const uint32_t pos = atomicAdd((uint32_t*)&hist[bucket_of(item.x)], 1u);
     b[pos] = item;
   }
   __syncthreads();
-  // ---- inside the buckets: every key counts the keys of its bucket that precede it in (depth bits, id) order and
-  // moves to that rank (all keys in parallel, independent LDS reads); cursor[bkt] is now the END of bucket bkt
-  uint2* out = a;                               // the input buffer is free
+  // ---- inside the buckets: every key counts the keys of its bucket that precede it in (depth bits, id) order
+  // (all keys in parallel, independent reads) and its id goes to that rank; cursor[bkt] is now the END of bucket bkt
   for (int k = tid; k < n; k += NT) {
     const uint2 it = b[k];
     const int bkt = bucket_of(it.x);
@@ -393,10 +394,9 @@ __device__ __forceinline__ uint2* bucket_sort_pairs(uint2* a, uint2* b, int n, v
       const uint2 o = b[j];
       rank += (o.x < it.x || (o.x == it.x && o.y < it.y)) ? 1 : 0;
     }
-    out[s0 + rank] = it;
+    out_ids[s0 + rank] = it.y;
   }
-  __syncthreads();
-  return out;
+  return true;
 }
 
 // Equal depth bits -> ascending Gaussian id (runs are almost always of length 1).
@@ -417,9 +417,9 @@ __device__ __forceinline__ void fix_ties(uint2* s, int n) {
   }
 }
 
-// grid = n_tiles (blocks walk tile_order: heavy tiles first), block = NT.  A launch handles the
-// tiles with n_lo < n <= n_hi; lists longer than lds_cap are sorted through keys/keys_tmp (global).
-// dynamic LDS = lds_cap*16 (two pair buffers) + ((NT/64)*256 + 8)*4.
+// grid = n_tiles (blocks walk tile_order: heavy tiles first), block = NT.  A launch handles the tiles with
+// n_lo < n <= n_hi.  dynamic LDS = lds_cap*8 (the bucket-ordered pairs) + ((NT/64)*256 + 8)*4; lists longer than
+// lds_cap keep that copy in keys_tmp (global) instead.
 template <int NT>
 __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
                                                        const uint32_t* __restrict__ tile_start,
@@ -427,8 +427,7 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
                                                        uint32_t* __restrict__ sorted_ids, int lds_cap, int n_lo, int n_hi) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / 64;
-  uint2* bufA = reinterpret_cast<uint2*>(smem);
-  uint2* bufB = bufA + lds_cap;
+  uint2* bufB = reinterpret_cast<uint2*>(smem);
   volatile uint32_t* hist = reinterpret_cast<volatile uint32_t*>(bufB + lds_cap);
   volatile uint32_t* misc = hist + NW * 256;
   const uint32_t tile = tile_order[blockIdx.x];
@@ -436,26 +435,17 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
   const int n = (int)(tile_start[tile + 1] - s);
   if (n <= n_lo || n > n_hi) return;
   const int tid = threadIdx.x;
-  if (n <= lds_cap) {
-    for (int k = tid; k < n; k += NT) bufA[k] = keys[s + k];
-    __syncthreads();
-    uint2* res = bufA;
-    if (n > 1) {
-      res = bucket_sort_pairs<NT>(bufA, bufB, n, hist, misc);
-      if (res == nullptr) {                     // clustered depths: counting passes instead (uniform over the workgroup)
-        res = radix_sort_pairs<NT>(bufA, bufB, n, hist, misc);
-        fix_ties<NT>(res, n);
-        __syncthreads();
-      }
-    }
-    for (int k = tid; k < n; k += NT) sorted_ids[s + k] = res[k].y;
-  } else {
-    uint2* res = radix_sort_pairs<NT>(keys + s, keys_tmp + s, n, hist, misc);
-    __syncthreads();
-    fix_ties<NT>(res, n);
-    __syncthreads();
-    for (int k = tid; k < n; k += NT) sorted_ids[s + k] = res[k].y;
+  if (n == 1) {
+    if (tid == 0) sorted_ids[s] = keys[s].y;
+    return;
   }
+  if (bucket_sort_to_ids<NT>(keys + s, n <= lds_cap ? bufB : keys_tmp + s, n, hist, misc, sorted_ids + s)) return;
+  // clustered depths: counting passes through keys / keys_tmp (uniform over the workgroup)
+  uint2* res = radix_sort_pairs<NT>(keys + s, keys_tmp + s, n, hist, misc);
+  __syncthreads();
+  fix_ties<NT>(res, n);
+  __syncthreads();
+  for (int k = tid; k < n; k += NT) sorted_ids[s + k] = res[k].y;
 }
 
 #ifndef OMFS_SORT_SMALL_NT
@@ -465,8 +455,8 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
 #define OMFS_SORT_SMALL_CAP 2048
 #endif
 constexpr int SORT_SMALL_NT = OMFS_SORT_SMALL_NT, SORT_SMALL_CAP = OMFS_SORT_SMALL_CAP;
-constexpr int SORT_LARGE_NT = 1024, SORT_LARGE_CAP_DEFAULT = 8960;
-constexpr size_t sort_lds_bytes(int cap, int nt) { return (size_t)cap * 16 + ((nt / 64) * 256 + 8) * 4; }
+constexpr int SORT_LARGE_NT = 1024, SORT_LARGE_CAP_DEFAULT = 7936;   // 78 KB of LDS: two workgroups per CU
+constexpr size_t sort_lds_bytes(int cap, int nt) { return (size_t)cap * 8 + ((nt / 64) * 256 + 8) * 4; }
 
 }  // namespace omfs
 
@@ -541,8 +531,8 @@ extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam,
 extern "C" int omfs_tile_sort(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
   if (int rc = check_bin_args(cam, rb)) return rc;
   const int n_tiles = cdiv(cam->width, OMFS_TILE) * cdiv(cam->height, OMFS_TILE);
-  // short lists: 512 threads, 2048 pairs in LDS (40 KB -> 4 workgroups per CU);
-  // long lists : 1024 threads, sort_lds_pairs pairs in LDS (default 8960 = 160 KB, one workgroup per CU)
+  // short lists: 512 threads, 2048 pairs in LDS (24 KB);
+  // long lists : 1024 threads, sort_lds_pairs pairs in LDS (default 7936 = 78 KB, two workgroups per CU)
   const int cap_large = rb->sort_lds_pairs ? (int)rb->sort_lds_pairs : SORT_LARGE_CAP_DEFAULT;
   OMFS_REQUIRE(cap_large >= 256 && sort_lds_bytes(cap_large, SORT_LARGE_NT) <= 160 * 1024, "sort_lds_pairs");
   const int cap_small = cap_large < SORT_SMALL_CAP ? cap_large : SORT_SMALL_CAP;
