@@ -331,17 +331,40 @@ __device__ __forceinline__ uint2* radix_sort_pairs(uint2* a, uint2* b, int n, vo
 // (or in keys_tmp for lists beyond the LDS capacity), and the ranking pass writes the ids to their final place.
 // Returns false (nothing written) when some bucket holds more than BUCKET_MAX keys (many equal or clustered depths);
 // the caller then falls back to the radix sort.  hist: NB words, misc: 8 words.
-constexpr int BUCKET_MAX = 48;
+#ifndef OMFS_BUCKET_MAX
+#define OMFS_BUCKET_MAX 256
+#endif
+constexpr int BUCKET_MAX = OMFS_BUCKET_MAX;
 
 template <int NT>
-__device__ __forceinline__ bool bucket_sort_to_ids(const uint2* __restrict__ src, uint2* b, int n, volatile uint32_t* hist,
+__device__ __forceinline__ bool bucket_sort_to_ids(const uint2* __restrict__ src, uint2* b, int n, volatile uint32_t* vhist,
                                                    volatile uint32_t* misc, uint32_t* __restrict__ out_ids) {
   constexpr int NB = (NT / 64) * 256;
   constexpr int PER = NB / NT;   // 4 consecutive buckets per thread in the scan
+  constexpr int KPT = 8;         // keys a thread keeps in registers (lists up to 8 NT pairs are read from memory ONCE)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* hist = const_cast<uint32_t*>(vhist);   // every cross-thread hand-over below goes through a barrier
+  const bool in_regs = n <= KPT * NT;
+  uint2 reg[KPT];
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {                // independent loads: one memory round trip
+      const int k = tid + j * NT;
+      reg[j] = k < n ? src[k] : make_uint2(0u, 0u);
+    }
+  }
+  auto for_keys = [&](auto&& f) {
+    if (in_regs) {
+#pragma unroll
+      for (int j = 0; j < KPT; ++j)
+        if (tid + j * NT < n) f(reg[j]);
+    } else {
+      for (int k = tid; k < n; k += NT) f(src[k]);
+    }
+  };
   // ---- key range
   uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-  for (int k = tid; k < n; k += NT) { const uint32_t x = src[k].x; kmin = min(kmin, x); kmax = max(kmax, x); }
+  for_keys([&](const uint2& it) { kmin = min(kmin, it.x); kmax = max(kmax, it.x); });
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, d, 64));
@@ -356,7 +379,7 @@ __device__ __forceinline__ bool bucket_sort_to_ids(const uint2* __restrict__ src
   const float scale = (float)NB / ((float)(misc[1] - kmin) + 1.f);
   auto bucket_of = [&](uint32_t x) { return min(NB - 1, (int)((float)(x - kmin) * scale)); };   // monotone in x
   // ---- histogram
-  for (int k = tid; k < n; k += NT) atomicAdd((uint32_t*)&hist[bucket_of(src[k].x)], 1u);
+  for_keys([&](const uint2& it) { atomicAdd(&hist[bucket_of(it.x)], 1u); });
   __syncthreads();
   // ---- exclusive scan over the buckets (thread t owns buckets PER t .. PER t + PER - 1)
   uint32_t c[PER], sum = 0, big = 0;
@@ -368,7 +391,8 @@ __device__ __forceinline__ bool bucket_sort_to_ids(const uint2* __restrict__ src
   if (lane == 63) hist[wave] = incl;             // wave totals
   __syncthreads();
   uint32_t base = 0;
-  for (int w = 0; w < wave; ++w) base += hist[w];
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) base += w < wave ? hist[w] : 0u;
   const bool fallback = misc[2] != 0u;
   __syncthreads();                               // totals consumed before the cursors overwrite them
   if (fallback) return false;
@@ -377,23 +401,21 @@ __device__ __forceinline__ bool bucket_sort_to_ids(const uint2* __restrict__ src
   for (int j = 0; j < PER; ++j) { hist[tid * PER + j] = run; run += c[j]; }   // cursor = first slot of the bucket
   __syncthreads();
   // ---- placement (order inside a bucket is arbitrary)
-  for (int k = tid; k < n; k += NT) {
-    const uint2 item = src[k];
-    const uint32_t pos = atomicAdd((uint32_t*)&hist[bucket_of(item.x)], 1u);
-    b[pos] = item;
-  }
+  for_keys([&](const uint2& it) { b[atomicAdd(&hist[bucket_of(it.x)], 1u)] = it; });
   __syncthreads();
   // ---- inside the buckets: every key counts the keys of its bucket that precede it in (depth bits, id) order
-  // (all keys in parallel, independent reads) and its id goes to that rank; cursor[bkt] is now the END of bucket bkt
+  // (all keys in parallel, reads issued four at a time) and its id goes to that rank; cursor[bkt] is now the END of bucket bkt
   for (int k = tid; k < n; k += NT) {
     const uint2 it = b[k];
     const int bkt = bucket_of(it.x);
     const int e = (int)hist[bkt], s0 = bkt ? (int)hist[bkt - 1] : 0;
-    int rank = 0;
-    for (int j = s0; j < e; ++j) {
-      const uint2 o = b[j];
-      rank += (o.x < it.x || (o.x == it.x && o.y < it.y)) ? 1 : 0;
+    auto before = [&](const uint2& o) { return (o.x < it.x || (o.x == it.x && o.y < it.y)) ? 1 : 0; };
+    int rank = 0, j = s0;
+    for (; j + 4 <= e; j += 4) {
+      const uint2 o0 = b[j], o1 = b[j + 1], o2 = b[j + 2], o3 = b[j + 3];
+      rank += (before(o0) + before(o1)) + (before(o2) + before(o3));
     }
+    for (; j < e; ++j) rank += before(b[j]);
     out_ids[s0 + rank] = it.y;
   }
   return true;

@@ -21,8 +21,8 @@ def test_bitexact_vs_c_oracle(n, width, height, yaw, seed):
     # a few exact depth ties and coincident Gaussians: the order must fall back to the Gaussian id
     for k in ("xyz", "log_scale", "rot", "binding"):
         g[k][1:100:2] = g[k][0:100:2]
-        # ... and one stack of 150 coincident Gaussians: more equal depths than a sort bucket takes (radix fallback)
-        g[k][200:350] = g[k][200]
+        # ... and one stack of 400 coincident Gaussians: more equal depths than a sort bucket takes (radix fallback)
+        g[k][200:600] = g[k][200]
     seq = synthetic.make_flame_sequence(4, seed)
     cam = synthetic.make_camera(width, height, yaw=yaw)
     dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq)
