@@ -166,8 +166,10 @@ int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_c
  *  count   : tile_count[t] = #Gaussians whose 3-sigma rectangle contains tile t AND that can reach
  *            alpha >= 1/255 at one of its pixel centres (frozen test, DESIGN.md "Binning")
  *  scan    : tile_count -> tile_start (exclusive scan), tile_order, zeroed tile_cursor
- *  scatter : (depth bits, id) pairs into their tile's segment of keys
- *  sort    : per-tile radix sort by depth (ties by id) -> sorted_ids                              */
+ *  scatter : (depth bits, id) pairs into their tile's segment of keys; REPLAYS the tile-test outcomes that the
+ *            omfs_bin_count of the same view recorded in keys_tmp (one 64-bit ballot per walk step), so the four
+ *            steps must run in this order on the same g / cam / rb
+ *  sort    : per-tile sort by (depth bits, id) -> sorted_ids (keys_tmp is scratch again from here on)       */
 int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);

@@ -172,9 +172,19 @@ __device__ __forceinline__ uint32_t publish_rects(const PairSource& ps, int i, i
 }
 
 // f(tile, owner lane) for every rectangle tile of the wave's 64 Gaussians that passes the frozen tile test.
-template <typename F>
-__device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* wr, uint32_t total, int gx, F&& f) {
-  for (uint32_t p = lane_id(); p < total; p += 64) {
+// The test is evaluated once per frame: the count kernel records its outcome as one 64-bit ballot per walk step
+// (HITS_RECORD, `hits` points at this wave's HITS_PER_WAVE slots in keys_tmp, which nothing else uses before the
+// sort), the scatter kernel's two walks replay it (HITS_REPLAY) and skip the ~100-instruction test; waves with
+// more steps than slots recompute (HITS_NONE behaviour for the steps beyond).
+constexpr int HITS_PER_WAVE = 64;
+enum { HITS_NONE = 0, HITS_RECORD = 1, HITS_REPLAY = 2 };
+
+template <int MODE, typename F>
+__device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* wr, uint32_t total, int gx,
+                                                               unsigned long long* hits, F&& f) {
+  const int lane = lane_id();
+  uint32_t step = 0;
+  for (uint32_t p = lane; p < total; p += 64, ++step) {
     int j = 0;
 #pragma unroll
     for (int s = 32; s > 0; s >>= 1)
@@ -186,14 +196,25 @@ __device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* 
     // k / w for k < 2^15, w < 2^8: (k + 0.5) / w is at least 0.5/w away from an integer, far above the rounding error
     const int q = (int)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)w));
     const int tx = x0 + (k - q * w), ty = y0 + q;
-    const float4 r0 = wr->r0[j];
-    const float2 r1 = wr->r1[j];
-    if (tile_touched(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty)) f(ty * gx + tx, j);
+    bool hit;
+    if (MODE == HITS_REPLAY && hits && step < (uint32_t)HITS_PER_WAVE) {
+      hit = (hits[step] >> lane) & 1ull;
+    } else {
+      const float4 r0 = wr->r0[j];
+      const float2 r1 = wr->r1[j];
+      hit = tile_touched(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
+      if (MODE == HITS_RECORD && hits && step < (uint32_t)HITS_PER_WAVE) {
+        const unsigned long long bal = __ballot(hit);
+        if (lane == 0) hits[step] = bal;             // lane 0 runs every step of the walk (p = 64 step)
+      }
+    }
+    if (hit) f(ty * gx + tx, j);
   }
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSource ps, int gx, int n_tiles,
-                                                                uint32_t* __restrict__ tile_count) {
+                                                                uint32_t* __restrict__ tile_count,
+                                                                unsigned long long* __restrict__ hits_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);
@@ -201,7 +222,8 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSourc
   const int i = blockIdx.x * BIN_THREADS + threadIdx.x;
   const uint32_t total = publish_rects(ps, i, n, wr);
   __syncthreads();
-  for_each_touched_tile_balanced(wr, total, gx, [&](int t, int) { atomicAdd(&hist[t], 1u); });
+  unsigned long long* hits = hits_all ? hits_all + ((size_t)blockIdx.x * BIN_WAVES + (threadIdx.x >> 6)) * HITS_PER_WAVE : nullptr;
+  for_each_touched_tile_balanced<HITS_RECORD>(wr, total, gx, hits, [&](int t, int) { atomicAdd(&hist[t], 1u); });
   __syncthreads();
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) {
     const uint32_t c = hist[t];
@@ -212,16 +234,18 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSourc
 __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSource ps, int gx, int n_tiles,
                                                                   const uint32_t* __restrict__ tile_start,
                                                                   uint32_t* __restrict__ tile_cursor,
-                                                                  uint2* __restrict__ keys) {
+                                                                  uint2* __restrict__ keys,
+                                                                  unsigned long long* __restrict__ hits_all) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);  // count, then this block's next slot in the tile
+  unsigned long long* hits = hits_all ? hits_all + ((size_t)blockIdx.x * BIN_WAVES + (threadIdx.x >> 6)) * HITS_PER_WAVE : nullptr;
   if (tile_start[n_tiles] == 0u) return;                // nothing visible, or capacity overflow (flagged by the scan)
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
   const int i = blockIdx.x * BIN_THREADS + threadIdx.x;
   const uint32_t total = publish_rects(ps, i, n, wr);
   __syncthreads();
-  for_each_touched_tile_balanced(wr, total, gx, [&](int t, int) { atomicAdd(&hist[t], 1u); });
+  for_each_touched_tile_balanced<HITS_REPLAY>(wr, total, gx, hits, [&](int t, int) { atomicAdd(&hist[t], 1u); });
   __syncthreads();
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) {
     const uint32_t c = hist[t];
@@ -229,7 +253,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSou
   }
   __syncthreads();
   const uint32_t id0 = (uint32_t)(i - lane_id());
-  for_each_touched_tile_balanced(wr, total, gx, [&](int t, int j) {
+  for_each_touched_tile_balanced<HITS_REPLAY>(wr, total, gx, hits, [&](int t, int j) {
     const uint32_t pos = atomicAdd(&hist[t], 1u);
     keys[pos] = make_uint2(wr->depth[j], id0 + (uint32_t)j);
   });
@@ -494,6 +518,13 @@ static int check_bin_args(const omfs_camera* cam, const omfs_raster_buffers* rb)
 
 static constexpr size_t BIN_LDS_LIMIT = 150 * 1024;
 
+// The tile-test ballots recorded by omfs_bin_count for omfs_bin_scatter live in keys_tmp (8 B per pair of capacity,
+// idle until the sort): HITS_PER_WAVE words for each wave of 64 Gaussians; NULL (recompute) when it is too small.
+static unsigned long long* hits_buffer(int n, const omfs_raster_buffers* rb) {
+  const size_t need = (size_t)cdiv(n, BIN_THREADS) * BIN_WAVES * HITS_PER_WAVE;
+  return need <= (size_t)rb->dup_capacity ? reinterpret_cast<unsigned long long*>(rb->keys_tmp) : nullptr;
+}
+
 extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
   if (int rc = check_bin_args(cam, rb)) return rc;
   OMFS_REQUIRE(g && g->n > 0 && rb->g0 && rb->g1, "gaussians");
@@ -508,7 +539,8 @@ extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, c
       OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles, rb->tile_count);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles, rb->tile_count,
+                       hits_buffer(g->n, rb));
   } else {
     hipLaunchKernelGGL(bin_count_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, rb->tile_count);
   }
@@ -541,7 +573,7 @@ extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam,
       attr_set = true;
     }
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles,
-                       rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
+                       rb->tile_start, rb->tile_cursor, (uint2*)rb->keys, hits_buffer(g->n, rb));
   } else {
     hipLaunchKernelGGL(bin_scatter_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, n_tiles,
                        rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
