@@ -19,6 +19,12 @@ constexpr int SW = 64;                 // output columns per wave
 constexpr int SRH = OMFS_SSIM_ROWS;
 constexpr int SROWS = SRH + 2 * HALO;  // input rows streamed per wave
 static_assert(SROWS % 11 == 0, "the register ring is unrolled by the 11 window taps");
+#ifndef OMFS_SSIM_ROWS_BWD
+#define OMFS_SSIM_ROWS_BWD OMFS_SSIM_ROWS
+#endif
+constexpr int SRH_B = OMFS_SSIM_ROWS_BWD;   // the backward kernel's own strip height
+constexpr int SROWS_B = SRH_B + 2 * HALO;
+static_assert(SROWS_B % 11 == 0, "the register ring is unrolled by the 11 window taps");
 
 struct GaussW { float g[11]; };  // normalised 11-tap window, passed by value (scalar registers)
 
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ 
                                                       const float* __restrict__ map_xy, float* __restrict__ dimage) {
   __shared__ float s0[SW + 2 * HALO], s1[SW + 2 * HALO], s2[SW + 2 * HALO];
   const int l = threadIdx.x, ch = blockIdx.z;
-  const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH;
+  const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH_B;
   const size_t plane = (size_t)width * height;
   const size_t co = ch * plane;
   const int xa = ox - HALO + l, xb = ox + SW - HALO + l, xo = ox + l;
@@ -114,20 +120,20 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ 
     const int y = oy - HALO + iy;
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = 0.f;
-    if (iy < SROWS && y >= 0 && y < height) {
+    if (iy < SROWS_B && y >= 0 && y < height) {
       const size_t ro = co + (size_t)y * width;
       if (ina) { v[0] = map_mu1[ro + xa]; v[1] = map_xx[ro + xa]; v[2] = map_xy[ro + xa]; }
       if (inb) { v[3] = map_mu1[ro + xb]; v[4] = map_xx[ro + xb]; v[5] = map_xy[ro + xb]; }
     }
     // the pixel pair of the output row this input row completes two iterations later (row iy - 10)
     const int yo = oy + iy - 2 * HALO;
-    if (iy >= 2 * HALO && iy < SROWS && yo < height && ino) { v[6] = img[co + (size_t)yo * width + xo]; v[7] = gt[co + (size_t)yo * width + xo]; }
+    if (iy >= 2 * HALO && iy < SROWS_B && yo < height && ino) { v[6] = img[co + (size_t)yo * width + xo]; v[7] = gt[co + (size_t)yo * width + xo]; }
   };
   float ring[11][3];
   float cur[8], nxt[8], nn[8];
   load_row(0, cur);
   load_row(1, nxt);
-  for (int base = 0; base < SROWS; base += 11) {
+  for (int base = 0; base < SROWS_B; base += 11) {
 #pragma unroll
     for (int r = 0; r < 11; ++r) {
       const int iy = base + r;
@@ -233,7 +239,8 @@ extern "C" int omfs_loss_l1_ssim(const float* image, const float* target, int wi
   hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(64), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
   OMFS_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, dimage, (int)(grid.x * grid.y * grid.z), lambda_dssim, loss_out);
-  hipLaunchKernelGGL(ssim_bwd_kernel, grid, dim3(64), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
+  dim3 grid_b(cdiv(width, SW), cdiv(height, SRH_B), 3);
+  hipLaunchKernelGGL(ssim_bwd_kernel, grid_b, dim3(64), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
