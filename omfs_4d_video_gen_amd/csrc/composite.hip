@@ -504,6 +504,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
   __shared__ uint32_t sid[WB];
   __shared__ float red[PEND][8][9];       // [pending slot][8-lane group][value]
   __shared__ uint32_t pend_id[PEND];      // Gaussian id of each pending slot
+  __shared__ float pend_abc[PEND][3];     // its conic in the staged form (A2, B2, C2)
   const uint32_t seg = blockIdx.x >> 2;
   if (seg >= order_seg0[n_tiles]) return;
   // launch-order position p with order_seg0[p] <= seg < order_seg0[p+1] (bisection, ~13 L2-resident loads)
@@ -565,7 +566,15 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
         float sum = 0.f;
 #pragma unroll
         for (int p8 = 0; p8 < 8; ++p8) sum += src[p8 * 9];
-        if (sum != 0.f) atomicAdd(&dsplat[(size_t)pend_id[slot] * 16 + q], sum);
+        // moments -> gradients of the 2-D splat (lanes q = 0, 1 exchange S_x, S_y)
+        const float other = __shfl_xor(sum, 1, 64);
+        const float A2 = pend_abc[slot][0], B2 = pend_abc[slot][1], C2 = pend_abc[slot][2];
+        float out = sum;
+        if (q == 0) out = (1.f / LOG2E) * fma_(2.f * A2, sum, B2 * other);        // d mean2d.x
+        else if (q == 1) out = (1.f / LOG2E) * fma_(2.f * C2, sum, B2 * other);   // d mean2d.y
+        else if (q == 2 || q == 4) out = -0.5f * sum;                             // d conic.a, d conic.c
+        else if (q == 3) out = -sum;                                              // d conic.b (B multiplies dx*dy once)
+        if (out != 0.f) atomicAdd(&dsplat[(size_t)pend_id[slot] * 16 + q], out);
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -620,8 +629,6 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
       m &= ~(1ull << jb);
       const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
       float v[9];
-#pragma unroll
-      for (int q = 0; q < 9; ++q) v[q] = 0.f;
       const float4 a = an;
       const float4 c = cn;
       const float2 cb = cbn;
@@ -634,8 +641,10 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
       const unsigned long long hit_bal = __ballot(hit);
       OMFS_DBG_ADD(0, 1); OMFS_DBG_ADD(1, hit_bal != 0ull); OMFS_DBG_ADD(2, __popcll(hit_bal));
       if (hit_bal == 0ull) continue;  // nobody in this quadrant was touched: nothing to reduce
-      if (hit) {
-        const float G = __builtin_amdgcn_exp2f(p2);
+      {
+        // Branch-free: G is masked to 0 for lanes that are not hit, which makes alpha = 0, 1/(1-alpha) = 1 and every
+        // gradient term below exactly 0 for them; their colour recurrence takes a no-op step (a splat of alpha 0).
+        const float G = hit ? __builtin_amdgcn_exp2f(p2) : 0.f;
         const float oG = cb.y * G;                              // opacity * G
         const float alpha = fminf(0.99f, oG);
         const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
@@ -648,17 +657,17 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
         lc0 = c.z; lc1 = c.w; lc2 = cb.x; la = alpha;
         float dLa = (c.z - acc0) * dL0 + (c.w - acc1) * dL1 + (cb.x - acc2) * dL2;
         dLa = fma_(dLa, T, -(T_final * r1a) * bgdot);
-        // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream
-        // rasteriser does (DESIGN.md "Frozen conventions").  With A2 = -0.5 log2e A etc.:
-        //   dG/ddx = -G (A dx + B dy) = G (2 A2 dx + B2 dy) / log2e
-        const float gL = oG * dLa;                     // dL/dG * G  (opacity folded in)
-        const float gs = gL * (1.f / LOG2E);
-        v[0] = gs * fma_(2.f * a.z, dx, a.w * dy);      // d mean2d.x (dx = mean - pixel)
-        v[1] = gs * fma_(2.f * c.x, dy, a.w * dx);      // d mean2d.y
-        const float hx = -0.5f * gL * dx;
-        v[2] = hx * dx;                                 // d conic.a
-        v[3] = 2.f * hx * dy;                           // d conic.b (B multiplies dx*dy once)
-        v[4] = -0.5f * gL * dy * dy;                    // d conic.c
+        // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream rasteriser does
+        // (DESIGN.md "Frozen conventions").  Only the moments of gL = dL/dG * G over the pixels are reduced here:
+        //   S_x = sum gL dx, S_y, S_xx, S_xy, S_yy  (dx = mean - pixel);
+        // the flush turns them into d mean2d = (2 A2 S_x + B2 S_y, 2 C2 S_y + B2 S_x) / log2e and
+        // d conic = (-S_xx / 2, -S_xy, -S_yy / 2)  (A2 = -0.5 log2e A etc. as staged).
+        const float gL = oG * dLa;                     // opacity folded in
+        v[0] = gL * dx;
+        v[1] = gL * dy;
+        v[2] = v[0] * dx;
+        v[3] = v[0] * dy;
+        v[4] = v[1] * dy;
         v[5] = G * dLa;                                 // d opacity
       }
       reduce9_groups_of_8(v);   // lanes 7, 15, ..., 63 hold the sums of their 8-lane groups
@@ -667,7 +676,10 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
 #pragma unroll
         for (int q = 0; q < 9; ++q) dst[q] = v[q];
       }
-      if (lane == 0) pend_id[n_pending] = sid[jb];
+      if (lane == 0) {
+        pend_id[n_pending] = sid[jb];
+        pend_abc[n_pending][0] = a.z; pend_abc[n_pending][1] = a.w; pend_abc[n_pending][2] = c.x;   // A2, B2, C2
+      }
       if (++n_pending == PEND) { flush_pending(); n_pending = 0; }
     }
   }
