@@ -621,10 +621,12 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
       rid = sorted_ids[beg + cbase - WB + lane];
       r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
     }
+    // The record of the next splat is fetched from LDS while the current one is evaluated; two register sets
+    // alternate (the loop body is written once and instantiated twice), so no copies are needed.
     int jbn = m ? 63 - __builtin_clzll(m) : 0;
-    float4 an = s0[jbn], cn = s1[jbn];
-    float2 cbn = s2[jbn];
-    while (m) {
+    float4 recA0 = s0[jbn], recA1 = s1[jbn], recB0 = recA0, recB1 = recA1;
+    float2 recA2 = s2[jbn], recB2 = recA2;
+    auto visit = [&](const float4& an, const float4& cn, const float2& cbn, float4& nx0, float4& nx1, float2& nx2) {
       const int jb = jbn;
       m &= ~(1ull << jb);
       const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
@@ -633,14 +635,14 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
       const float4 c = cn;
       const float2 cb = cbn;
       jbn = m ? 63 - __builtin_clzll(m) : 0;   // prefetch the next splat's record
-      an = s0[jbn]; cn = s1[jbn]; cbn = s2[jbn];
+      nx0 = s0[jbn]; nx1 = s1[jbn]; nx2 = s2[jbn];
       const float dx = a.x - fx, dy = a.y - fy;
       const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
       const float e = p2 + c.y;
       const bool hit = contributor <= last && p2 <= 0.f && e >= LOG2_INV255;
       const unsigned long long hit_bal = __ballot(hit);
       OMFS_DBG_ADD(0, 1); OMFS_DBG_ADD(1, hit_bal != 0ull); OMFS_DBG_ADD(2, __popcll(hit_bal));
-      if (hit_bal == 0ull) continue;  // nobody in this quadrant was touched: nothing to reduce
+      if (hit_bal == 0ull) return;    // nobody in this quadrant was touched: nothing to reduce
       {
         // Branch-free: G is masked to 0 for lanes that are not hit, which makes alpha = 0, 1/(1-alpha) = 1 and every
         // gradient term below exactly 0 for them; their colour recurrence takes a no-op step (a splat of alpha 0).
@@ -681,6 +683,11 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
         pend_abc[n_pending][0] = a.z; pend_abc[n_pending][1] = a.w; pend_abc[n_pending][2] = c.x;   // A2, B2, C2
       }
       if (++n_pending == PEND) { flush_pending(); n_pending = 0; }
+    };
+    while (m) {
+      visit(recA0, recA1, recA2, recB0, recB1, recB2);
+      if (!m) break;
+      visit(recB0, recB1, recB2, recA0, recA1, recA2);
     }
   }
   if (n_pending) flush_pending();
