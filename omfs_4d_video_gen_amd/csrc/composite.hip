@@ -165,17 +165,16 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
     unsigned long long m = combine(live);
     if (m == 0ull) continue;
     const uint32_t base = b - beg;
+    // LDS reads of the next splat are issued before the current one is evaluated; two register sets alternate
+    // (the body is written once and instantiated twice), so the prefetch needs no copies
     int jn = __builtin_ctzll(m);
-    float4 an = s0[jn], cn = s1[jn];   // LDS reads of the next splat are issued before the current one is evaluated
-    float cbn = s2[jn];
-    while (m) {
+    float4 recA0 = s0[jn], recA1 = s1[jn], recB0 = recA0, recB1 = recA1;
+    float recA2 = s2[jn], recB2 = recA2;
+    auto visit = [&](const float4& a, const float4& c, const float& cb, float4& nx0, float4& nx1, float& nx2) {
       const int j = jn;
-      const float4 a = an;
-      const float4 c = cn;
-      const float cb = cbn;
       m &= m - 1ull;
       jn = m ? __builtin_ctzll(m) : 0;
-      an = s0[jn]; cn = s1[jn]; cbn = s2[jn];
+      nx0 = s0[jn]; nx1 = s1[jn]; nx2 = s2[jn];
       {
         const float dx_ = a.x - fx, dy_ = a.y - fy;
         const float p2_ = fma_(a.z * dx_, dx_, fma_(c.x * dy_, dy_, a.w * dx_ * dy_));
@@ -207,8 +206,13 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
         live = nl;
         m &= combine(live);
         jn = m ? __builtin_ctzll(m) : 0;   // the prefetched splat may have been dropped
-        an = s0[jn]; cn = s1[jn]; cbn = s2[jn];
+        nx0 = s0[jn]; nx1 = s1[jn]; nx2 = s2[jn];
       }
+    };
+    while (m) {
+      visit(recA0, recA1, recA2, recB0, recB1, recB2);
+      if (!m) break;
+      visit(recB0, recB1, recB2, recA0, recA1, recA2);
     }
   }
   if (deep) {
