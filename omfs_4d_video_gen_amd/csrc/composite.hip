@@ -334,28 +334,30 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
         __builtin_amdgcn_wave_barrier();
         const uint32_t base = b - tbeg;
         int jn = m ? __builtin_ctzll(m) : 0;
-        float4 an = pg0[wave][jn], cn = pg1[wave][jn];
-        float cbn = pg2[wave][jn];
-        while (m) {
+        float4 recA0 = pg0[wave][jn], recA1 = pg1[wave][jn], recB0 = recA0, recB1 = recA1;
+        float recA2 = pg2[wave][jn], recB2 = recA2;
+        // branch-free: alpha is masked to 0 for pixels that are done or not hit (P and A then stay as they are)
+        auto visit = [&](const float4& a, const float4& c, const float& cb, float4& nx0, float4& nx1, float& nx2) {
           const int j = jn;
-          const float4 a = an;
-          const float4 c = cn;
-          const float cb = cbn;
           m &= m - 1ull;
           jn = m ? __builtin_ctzll(m) : 0;
-          an = pg0[wave][jn]; cn = pg1[wave][jn]; cbn = pg2[wave][jn];
+          nx0 = pg0[wave][jn]; nx1 = pg1[wave][jn]; nx2 = pg2[wave][jn];
           const float dx = a.x - fx, dy = a.y - fy;
           const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
           const float e = p2 + c.y;
-          if (!done && p2 <= 0.f && e >= LOG2_INV255) {
-            const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
-            const float w = alpha * P;
-            A0 = fma_(c.z, w, A0);
-            A1 = fma_(c.w, w, A1);
-            A2 = fma_(cb, w, A2);
-            P = P * (1.f - alpha);
-            lw = base + (uint32_t)j + 1u;
-          }
+          const bool hit = !done && p2 <= 0.f && e >= LOG2_INV255;
+          const float alpha = hit ? fminf(0.99f, __builtin_amdgcn_exp2f(e)) : 0.f;
+          const float w = alpha * P;
+          A0 = fma_(c.z, w, A0);
+          A1 = fma_(c.w, w, A1);
+          A2 = fma_(cb, w, A2);
+          P = P * (1.f - alpha);
+          lw = hit ? base + (uint32_t)j + 1u : lw;
+        };
+        while (m) {
+          visit(recA0, recA1, recA2, recB0, recB1, recB2);
+          if (!m) break;
+          visit(recB0, recB1, recB2, recA0, recA1, recA2);
         }
       }
       comp[wave][lane] = make_float4(P, A0, A1, A2);
