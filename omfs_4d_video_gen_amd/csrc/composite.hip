@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
     int jn = __builtin_ctzll(m);
     float4 recA0 = s0[jn], recA1 = s1[jn], recB0 = recA0, recB1 = recA1;
     float recA2 = s2[jn], recB2 = recA2;
-    auto visit = [&](const float4& a, const float4& c, const float& cb, float4& nx0, float4& nx1, float& nx2) {
+    auto visit = [&](const float4& a, const float4& c, const float& cb, float4& nx0, float4& nx1, float& nx2, bool check) {
       const int j = jn;
       m &= m - 1ull;
       jn = m ? __builtin_ctzll(m) : 0;
@@ -201,6 +201,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
           }
         }
       }
+      if (!check) return;     // saturation is looked at after every fourth splat
       const unsigned long long nl = __ballot(!done);
       if (nl != live) {
         live = nl;
@@ -210,10 +211,15 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
       }
     };
     while (m) {
-      visit(recA0, recA1, recA2, recB0, recB1, recB2);
+      visit(recA0, recA1, recA2, recB0, recB1, recB2, false);
       if (!m) break;
-      visit(recB0, recB1, recB2, recA0, recA1, recA2);
+      visit(recB0, recB1, recB2, recA0, recA1, recA2, false);
+      if (!m) break;
+      visit(recA0, recA1, recA2, recB0, recB1, recB2, false);
+      if (!m) break;
+      visit(recB0, recB1, recB2, recA0, recA1, recA2, true);
     }
+    live = __ballot(!done);
   }
   if (deep) {
     // hand-over: the state at boundary FWD_SEQ_SEGS and, in the tile's unused boundary-0 slot, the live mask
