@@ -12,6 +12,7 @@ everything enqueued on the current HIP stream without a host sync.  Views shard 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -101,8 +102,7 @@ class Trainer:
         self.densify_stats = None      # [2][n_pad] when adaptive density control is on (engine/densify.py)
         # data-parallel exchange: "compact" (default) = all-reduce of the 14 non-rank-1 planes + all-gather of dL/dcolour,
         # the 45 higher SH planes are rebuilt on every rank (engine/distributed.py); "full" = one all-reduce of all 59
-        import os as _os
-        self.compact_dp = self.world > 1 and self.world <= 16 and _os.environ.get("OMFS_DP_EXCHANGE", "compact") != "full"
+        self.compact_dp = self.world > 1 and self.world <= 16 and os.environ.get("OMFS_DP_EXCHANGE", "compact") != "full"
         self._dp_patterns = {}
         self.drgb_local = self.drgb_all = self.cam_pos_table = None
         if self.compact_dp:
@@ -195,7 +195,6 @@ class Trainer:
         tm.mark("flame")
         fxf = face_xf[col]
         r.project(self.model, fxf, cam); tm.mark("project")
-        from .. import _lib as L
         lib = L.load()
         g = r._gauss(self.model)
         s = L.stream_ptr()
@@ -270,7 +269,6 @@ class Renderer:
         r, tm = self.rast, self.timer
         tm.begin()
         _, face_xf = self.dflame.face_frames(view.timestep, 1); tm.mark("flame")
-        from .. import _lib as L
         lib = L.load()
         g = r._gauss(self.model)
         s = L.stream_ptr()
