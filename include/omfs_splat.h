@@ -206,20 +206,22 @@ int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, co
  *                          CSR (face_start [F+1], face_gauss [n]: Gaussians sorted by parent triangle) -> dverts
  *                          [v_pad][4] += (atomics; caller zeroes)
  *   omfs_flame_skin_bwd  : dverts -> dv_shaped [V][3] (gradient of the blend-shaped vertices, overwritten) and
- *                          sums[64] += { d joint_xf [5][12], d translation [3], pad } (caller zeroes); v_shaped
+ *                          sums [omfs_flame_skin_rows(rig)][64]: one row of partial sums per wave,
+ *                          { d joint_xf [5][12], d translation [3], pad } (overwritten, no atomics); v_shaped
  *                          [v_pad][4] is the optional second output of omfs_flame_lbs, joint_xf [60] that of
  *                          omfs_flame_joints for the frame
- *   omfs_flame_param_bwd : dv_shaped, sums -> d expr [n_expr], d pose [5][3] (axis-angle: global, neck, jaw, eyes);
- *                          dcoef [n_coef] is scratch.  d translation = sums[60..62].
+ *   omfs_flame_param_bwd : dv_shaped, sums (the rows above) -> d expr [n_expr], d pose [5][3] (axis-angle: global,
+ *                          neck, jaw, eyes), d translation [3]; dcoef [n_coef] is scratch.
  *   omfs_adam_flat       : torch.optim.Adam step on a flat buffer (the FLAME parameter tensors) */
 int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t* faces, int n_faces, const float* dface,
                          const int32_t* face_start, const int32_t* face_gauss, float* dverts, void* stream);
 int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, const float* dverts,
                         float* dv_shaped, float* sums, void* stream);
 int omfs_flame_rodrigues(const float* axis_angle, int n, float* rotmats, void* stream);
+int omfs_flame_skin_rows(const omfs_flame_rig* rig);
 int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basis_dense, int n_coef, const float* dv_shaped,
                          const float* expr, const float* pose, const float* sums, float* dcoef, float* dexpr, float* dpose,
-                         void* stream);
+                         float* dtrans, void* stream);
 int omfs_adam_flat(float* params, const float* grads, float* m, float* v, int n, float lr, float beta1, float beta2,
                    float eps, int step, float grad_scale, void* stream);
 

@@ -93,7 +93,8 @@ SIGNATURES = {
     "omfs_flame_skin_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_flame_rodrigues": (C.c_int, [c_void_p, C.c_int, c_void_p, c_void_p]),
     "omfs_flame_param_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p, c_void_p]),
+    "omfs_flame_skin_rows": (C.c_int, [C.POINTER(FlameRigC)]),
     "omfs_adam_flat": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_int, C.c_float, c_void_p]),
     "omfs_simpleflame_fwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 5 + [C.c_int, c_void_p, c_void_p, c_void_p]),

@@ -194,13 +194,26 @@ __global__ void face_frames_bwd_kernel(const float* __restrict__ verts, const in
   // sum of the frame-gradient records of the Gaussians bound to this triangle (CSR by triangle)
   float g[16];
   for (int k = 0; k < 16; ++k) g[k] = 0.f;
-  for (int e = face_start[f]; e < face_start[f + 1]; ++e) {
-    const float4* rec = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e] * 4;
-    const float4 a = rec[0], b = rec[1], c = rec[2], d = rec[3];
+  const int lo = face_start[f], hi = face_start[f + 1];
+  auto add = [&](const float4& a, const float4& b, const float4& c, const float4& d) {
     g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
     g[8] += c.x; g[9] += c.y; g[10] += c.z; g[11] += c.w; g[12] += d.x;
+  };
+  int e = lo;
+  for (; e + 4 <= hi; e += 4) {            // four records per memory round trip
+    const float4* r0 = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e] * 4;
+    const float4* r1 = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e + 1] * 4;
+    const float4* r2 = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e + 2] * 4;
+    const float4* r3 = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e + 3] * 4;
+    const float4 a0 = r0[0], b0 = r0[1], c0 = r0[2], d0 = r0[3], a1 = r1[0], b1 = r1[1], c1 = r1[2], d1 = r1[3];
+    const float4 a2 = r2[0], b2 = r2[1], c2 = r2[2], d2 = r2[3], a3 = r3[0], b3 = r3[1], c3 = r3[2], d3 = r3[3];
+    add(a0, b0, c0, d0); add(a1, b1, c1, d1); add(a2, b2, c2, d2); add(a3, b3, c3, d3);
   }
-  if (face_start[f] == face_start[f + 1]) return;
+  for (; e < hi; ++e) {
+    const float4* rec = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e] * 4;
+    add(rec[0], rec[1], rec[2], rec[3]);
+  }
+  if (lo == hi) return;
   const float4* vb = reinterpret_cast<const float4*>(verts);
   const int i0 = faces[f * 3 + 0], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
   const float4 v0 = vb[i0], v1 = vb[i1], v2 = vb[i2];
@@ -254,8 +267,8 @@ __global__ void face_frames_bwd_kernel(const float* __restrict__ verts, const in
 }
 
 // One thread per vertex: v_posed = M_v [v_shaped; 1] + ..., M_v = sum_j w_vj X_j; v_shaped [v_pad][4] was stored by
-// flame_lbs.  Writes dv_shaped = M_v(3x3)^T dv and accumulates d X_j = w_vj dv (x) [v_shaped; 1] and
-// d translation = dv: 63 sums, reduced per wave with DPP, one global atomic per value and wave.
+// flame_lbs.  Writes dv_shaped = M_v(3x3)^T dv and the per-wave partial sums of d X_j = w_vj dv (x) [v_shaped; 1] and
+// d translation = dv (63 values, DPP wave reduction) into sums[wave][64].
 __global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __restrict__ lbs_weights, const float* __restrict__ v_shaped,
                                                              const float* __restrict__ joint_xf, const float* __restrict__ dverts,
                                                              int n_verts, float* __restrict__ dv_shaped, float* __restrict__ sums) {
@@ -276,19 +289,22 @@ __global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __rest
         for (int c = 0; c < 3; ++c) out[c] = fma_(X[j * 12 + r * 3 + c], w[j] * dv[r], out[c]);
     for (int c = 0; c < 3; ++c) dv_shaped[(size_t)v * 3 + c] = out[c];
   }
+  // one row of 64 partial sums per wave (no same-address atomics); flame_front_bwd adds the rows up
   const bool last = (threadIdx.x & 63) == 63;
+  float* row = sums + (size_t)(blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * 64;
   for (int j = 0; j < 5; ++j)
     for (int r = 0; r < 3; ++r) {
       const float g = w[j] * dv[r];
       for (int c = 0; c < 4; ++c) {
         const float t = wave_sum_to_lane63(g * vs[c]);
-        if (last && t != 0.f) atomicAdd(&sums[j * 12 + (c < 3 ? r * 3 + c : 9 + r)], t);
+        if (last) row[j * 12 + (c < 3 ? r * 3 + c : 9 + r)] = t;
       }
     }
   for (int c = 0; c < 3; ++c) {
     const float t = wave_sum_to_lane63(dv[c]);
-    if (last && t != 0.f) atomicAdd(&sums[60 + c], t);
+    if (last) row[60 + c] = t;
   }
+  if (last) row[63] = 0.f;
 }
 
 // dcoef[k] = sum_i basis_dense[k][i] dv_shaped[i]   (one block per coefficient)
@@ -296,9 +312,14 @@ __global__ __launch_bounds__(256) void basis_t_gemv_kernel(const float* __restri
                                                            int row, float* __restrict__ dcoef) {
   __shared__ float ws[4];
   const float* b = basis_dense + (size_t)blockIdx.x * row;
-  float a = 0.f;
-  for (int i = threadIdx.x; i < row; i += 256) a = fma_(b[i], dv_shaped[i], a);
-  a = wave_sum_all(a);
+  float a = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int i = threadIdx.x;
+  for (; i + 768 < row; i += 1024) {       // four independent loads per round trip
+    a = fma_(b[i], dv_shaped[i], a); a1 = fma_(b[i + 256], dv_shaped[i + 256], a1);
+    a2 = fma_(b[i + 512], dv_shaped[i + 512], a2); a3 = fma_(b[i + 768], dv_shaped[i + 768], a3);
+  }
+  for (; i < row; i += 256) a = fma_(b[i], dv_shaped[i], a);
+  a = wave_sum_all((a + a1) + (a2 + a3));
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = a;
   __syncthreads();
   if (threadIdx.x == 0) dcoef[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
@@ -332,10 +353,18 @@ __global__ void rodrigues_kernel(const float* __restrict__ aa, int n, float* __r
 // One wave; lane 0 walks the 5-joint chain and the axis-angle maps backwards, all lanes finish d expr.
 __global__ __launch_bounds__(64) void flame_front_bwd_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
                                                              const float* __restrict__ expr, const float* __restrict__ pose,
-                                                             int n_expr, const float* __restrict__ sums, const float* __restrict__ dcoef,
-                                                             float* __restrict__ dexpr, float* __restrict__ dpose) {
+                                                             int n_expr, const float* __restrict__ partial, int n_rows,
+                                                             const float* __restrict__ dcoef, float* __restrict__ dexpr,
+                                                             float* __restrict__ dpose, float* __restrict__ dtrans) {
   __shared__ float sJ[15], sdJ[15];
+  __shared__ float sums[64];
   const int lane = threadIdx.x;
+  {   // add up the per-wave rows of flame_skin_bwd: lane q owns value q
+    float t = 0.f;
+    for (int r = 0; r < n_rows; ++r) t += partial[(size_t)r * 64 + lane];
+    sums[lane] = t;
+    if (lane >= 60 && lane < 63) dtrans[lane - 60] = t;
+  }
   if (lane < 15) {
     float a = j_static[lane];
     const float* row = j_expr + (size_t)lane * n_expr;
@@ -498,6 +527,8 @@ extern "C" int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t
   return OMFS_OK;
 }
 
+extern "C" int omfs_flame_skin_rows(const omfs_flame_rig* rig) { return rig ? cdiv(rig->n_verts, 256) * 4 : 0; }
+
 extern "C" int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, const float* dverts,
                                    float* dv_shaped, float* sums, void* stream) {
   OMFS_REQUIRE(rig && v_shaped && joint_xf && dverts && dv_shaped && sums, "null pointer");
@@ -517,14 +548,14 @@ extern "C" int omfs_flame_rodrigues(const float* axis_angle, int n, float* rotma
 
 extern "C" int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basis_dense, int n_coef, const float* dv_shaped,
                                     const float* expr, const float* pose, const float* sums, float* dcoef, float* dexpr,
-                                    float* dpose, void* stream) {
-  OMFS_REQUIRE(rig && basis_dense && dv_shaped && expr && pose && sums && dcoef && dexpr && dpose, "null pointer");
+                                    float* dpose, float* dtrans, void* stream) {
+  OMFS_REQUIRE(rig && basis_dense && dv_shaped && expr && pose && sums && dcoef && dexpr && dpose && dtrans, "null pointer");
   OMFS_REQUIRE(n_coef == rig->n_expr + 36 && rig->j_static && rig->j_expr, "shape");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(basis_t_gemv_kernel, dim3(n_coef), dim3(256), 0, s, basis_dense, dv_shaped, 3 * rig->n_verts, dcoef);
   OMFS_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(flame_front_bwd_kernel, dim3(1), dim3(64), 0, s, rig->j_static, rig->j_expr, expr, pose, rig->n_expr, sums,
-                     dcoef, dexpr, dpose);
+                     cdiv(rig->n_verts, 256) * 4, dcoef, dexpr, dpose, dtrans);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

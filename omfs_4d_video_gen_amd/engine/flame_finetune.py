@@ -54,7 +54,7 @@ class FlameFineTuner:
         self._csr_key, self.face_start, self.face_gauss = None, None, None
         self.dverts = torch.zeros(dflame.v_pad, 4, device=dev)
         self.dv_shaped = torch.empty(V, 3, device=dev)
-        self.sums = torch.zeros(64, device=dev)
+        self.sums = torch.zeros(int(L.load().omfs_flame_skin_rows(dflame.c_rig)), 64, device=dev)   # one row per wave
         self.dcoef = torch.empty(self.n_coef, device=dev)
         self._t = None
         self._last_t = None
@@ -99,7 +99,6 @@ class FlameFineTuner:
         joint_all, _, _, _, vs_all = df._buffers(nb)        # written by the FLAME forward kernels
         joint_xf, v_shaped = joint_all[col], vs_all[col]
         self.dverts.zero_()
-        self.sums.zero_()
         if self._last_t is not None and self._last_t != t:
             for g in self.grad.values():
                 g[self._last_t].zero_()
@@ -109,8 +108,7 @@ class FlameFineTuner:
                                         L.ptr(self.sums), s), "omfs_flame_skin_bwd")
         L.check(lib.omfs_flame_param_bwd(df.c_rig, L.ptr(self.basis), self.n_coef, L.ptr(self.dv_shaped), L.ptr(self.expr[t]),
                                          L.ptr(self.pose[t]), L.ptr(self.sums), L.ptr(self.dcoef), L.ptr(self.grad["expr"][t]),
-                                         L.ptr(self.grad["pose"][t]), s), "omfs_flame_param_bwd")
-        self.grad["translation"][t].copy_(self.sums[60:63])
+                                         L.ptr(self.grad["pose"][t]), L.ptr(self.grad["translation"][t]), s), "omfs_flame_param_bwd")
         self._last_t = t
         self._t = None
 
