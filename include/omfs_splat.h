@@ -246,6 +246,9 @@ typedef struct omfs_view_set {
   int view[16];           /* row of cam_pos_table of each view                                      */
 } omfs_view_set;
 
+/* the same three planes omfs_project_bwd writes to drgb_out, available right after omfs_composite_bwd (so that the
+ * all-gather can overlap omfs_project_bwd) */
+int omfs_extract_drgb(const omfs_raster_buffers* rb, const float* dsplat, int n, int n_pad, float* drgb_out, void* stream);
 int omfs_sh_rest_grads(const omfs_gaussians* g, const float* face_xf_all, int n_faces, const float* cam_pos_table,
                        const omfs_view_set* views, const float* drgb_all, int sh_degree, float* grads, void* stream);
 

@@ -259,6 +259,24 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
   G(OMFS_P_OPACITY, dop * o * (1.f - o));
 }
 
+// dL/dcolour of this view per Gaussian, straight from the 2-D splat gradient records (zero for clamped channels and
+// invisible Gaussians): lets the data-parallel all-gather start before project_bwd runs.
+__global__ __launch_bounds__(256) void extract_drgb_kernel(int n, int n_pad, const float4* __restrict__ g2,
+                                                           const float4* __restrict__ dsplat, float* __restrict__ drgb_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t rbits = __float_as_uint(g2[i].z);
+  float d[3] = {0.f, 0.f, 0.f};
+  if ((rbits & 0xFFFFFu) != 0u) {
+    const float4 d1 = dsplat[(size_t)i * 4 + 1], d2 = dsplat[(size_t)i * 4 + 2];
+    const uint32_t clampbits = rbits >> 28;
+    d[0] = (clampbits & 1u) ? 0.f : d1.z;
+    d[1] = (clampbits & 2u) ? 0.f : d1.w;
+    d[2] = (clampbits & 4u) ? 0.f : d2.x;
+  }
+  for (int ch = 0; ch < 3; ++ch) drgb_out[(size_t)ch * n_pad + i] = d[ch];
+}
+
 struct ViewSetK {
   int n_views;
   int view[16];
@@ -316,6 +334,14 @@ __global__ __launch_bounds__(256) void sh_rest_grads_kernel(int n, int n_pad, co
 }  // namespace omfs
 
 using namespace omfs;
+
+extern "C" int omfs_extract_drgb(const omfs_raster_buffers* rb, const float* dsplat, int n, int n_pad, float* drgb_out, void* stream) {
+  OMFS_REQUIRE(rb && rb->g2 && dsplat && drgb_out && n > 0 && n_pad >= n, "args");
+  hipLaunchKernelGGL(extract_drgb_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, n_pad, (const float4*)rb->g2,
+                     (const float4*)dsplat, drgb_out);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
 
 extern "C" int omfs_sh_rest_grads(const omfs_gaussians* g, const float* face_xf_all, int n_faces, const float* cam_pos_table,
                                   const omfs_view_set* views, const float* drgb_all, int sh_degree, float* grads, void* stream) {

@@ -30,17 +30,17 @@ def allreduce_sum_(buf: torch.Tensor, group=None) -> torch.Tensor:
     return buf
 
 
-def allgather_into_(out: torch.Tensor, inp: torch.Tensor, group=None) -> torch.Tensor:
+def allgather_into_(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: bool = False):
     """out [W][...] <- every rank's inp [...] (rank order).  One collective; falls back to the list form where the
-    backend lacks the tensor form."""
+    backend lacks the tensor form.  With async_op the work handle is returned (call .wait() before reading out)."""
     world = dist.get_world_size(group)
     if out.shape[0] != world or out[0].shape != inp.shape:
         raise ValueError("out must be [world_size, *inp.shape]")
     try:
-        dist.all_gather_into_tensor(out, inp, group=group)
+        work = dist.all_gather_into_tensor(out, inp, group=group, async_op=async_op)
     except (RuntimeError, NotImplementedError):
-        dist.all_gather(list(out.unbind(0)), inp, group=group)
-    return out
+        work = dist.all_gather(list(out.unbind(0)), inp, group=group, async_op=async_op)
+    return work if async_op else out
 
 
 def replicas_in_sync(params: torch.Tensor, group=None) -> bool:

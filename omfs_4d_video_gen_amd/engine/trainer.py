@@ -104,7 +104,7 @@ class Trainer:
         # the 45 higher SH planes are rebuilt on every rank (engine/distributed.py); "full" = one all-reduce of all 59
         self.compact_dp = self.world > 1 and self.world <= 16 and os.environ.get("OMFS_DP_EXCHANGE", "compact") != "full"
         self._dp_patterns = {}
-        self.drgb_local = self.drgb_all = self.cam_pos_table = None
+        self.drgb_local = self.drgb_scratch = self.drgb_all = self.cam_pos_table = None
         if self.compact_dp:
             cp = np.stack([np.asarray(make_camera_struct(v.camera).cam_pos, np.float32) for v in views])
             self.cam_pos_table = torch.from_numpy(cp).to(self.device)
@@ -208,10 +208,16 @@ class Trainer:
         r.dsplat.zero_()
         if self.compact_dp and (self.drgb_local is None or self.drgb_local.shape[1] != self.model.n_pad):
             self.drgb_local = torch.zeros(3, self.model.n_pad, device=self.device)
+            self.drgb_scratch = torch.zeros(3, self.model.n_pad, device=self.device)
             self.drgb_all = torch.zeros(self.world, 3, self.model.n_pad, device=self.device)
         gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
-                            L.ptr(ft.dface) if ft is not None else 0, L.ptr(self.drgb_local) if self.compact_dp else 0)
+                            L.ptr(ft.dface) if ft is not None else 0, L.ptr(self.drgb_scratch) if self.compact_dp else 0)
         L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")
+        gather = None
+        if self.compact_dp:            # dL/dcolour is final here: its all-gather runs under project_bwd
+            from .distributed import allgather_into_
+            L.check(lib.omfs_extract_drgb(r.rb, L.ptr(r.dsplat), self.model.n, self.model.n_pad, L.ptr(self.drgb_local), s), "omfs_extract_drgb")
+            gather = allgather_into_(self.drgb_all, self.drgb_local, self.pg, async_op=True)
         L.check(lib.omfs_count_visible(r.rb, r.n, L.ptr(r.n_visible), s), "omfs_count_visible")
         rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
         L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
@@ -221,7 +227,7 @@ class Trainer:
             from .distributed import allgather_into_, allreduce_sum_
             if self.compact_dp:
                 allreduce_sum_(self.grads[:P_SH + 3], self.pg)            # 14 contiguous planes
-                allgather_into_(self.drgb_all, self.drgb_local, self.pg)
+                gather.wait()
                 L.check(lib.omfs_sh_rest_grads(g, L.ptr(face_xf), self.dflame.rig.n_faces, L.ptr(self.cam_pos_table), pat[1],
                                                L.ptr(self.drgb_all), self.sh_degree, L.ptr(self.grads), s), "omfs_sh_rest_grads")
             else:
