@@ -145,7 +145,7 @@ def main(argv=None):
     ckpt = None
     if args.start_checkpoint:
         from omfs_4d_video_gen_amd.engine.gaussians import unpack_params
-        ckpt = torch.load(args.start_checkpoint, map_location="cpu", weights_only=False)
+        ckpt = torch.load(args.start_checkpoint, map_location="cpu", weights_only=True)
         n = int(ckpt["binding"].shape[0])
         g0 = unpack_params(ckpt["params"][:, :n].numpy())
         g0["binding"] = ckpt["binding"].numpy()
