@@ -165,7 +165,8 @@ int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_c
 /* the four binning steps, separately launchable (omfs_bin_sort = all four in order):
  *  count   : tile_count[t] = #Gaussians whose 3-sigma rectangle contains tile t AND that can reach
  *            alpha >= 1/255 at one of its pixel centres (frozen test, DESIGN.md "Binning")
- *  scan    : tile_count -> tile_start (exclusive scan), tile_order, zeroed tile_cursor
+ *  scan    : tile_count -> tile_start (exclusive scan), tile_order, zeroed tile_cursor; tile_count is consumed (left
+ *            zeroed for the next view: it must be zero before the first omfs_bin_count)
  *  scatter : (depth bits, id) pairs into their tile's segment of keys; REPLAYS the tile-test outcomes that the
  *            omfs_bin_count of the same view recorded in keys_tmp (one 64-bit ballot per walk step), so the four
  *            steps must run in this order on the same g / cam / rb
@@ -182,8 +183,9 @@ int omfs_image_to_rgb8(const float* image, int width, int height, uint8_t* rgb8,
 
 /* ------------------------------------------------------------------ backward + optimiser */
 typedef struct omfs_grad_buffers {
-  float* dsplat;          /* [n][16] per-Gaussian 2D-splat gradient record (atomically accumulated):
-                             dmean2d.xy, dconic.abc, dopacity, drgb, |dmean2d| ... ; caller zeroes */
+  float* dsplat;          /* [n][16] per-Gaussian 2D-splat gradient record (atomically accumulated by omfs_composite_bwd):
+                             dmean2d.xy, dconic.abc, dopacity, drgb; zero before the first use -- omfs_project_bwd
+                             clears every record it consumes, so a composite_bwd / project_bwd pair leaves it zeroed */
   float* grads;           /* [59][n_pad] parameter gradients (overwritten)                         */
   const float* dimage;    /* [3][H][W] dL/dimage                                                   */
   float* densify_stats;   /* optional [2][n_pad]: += |d mean2d| in NDC-scaled units (x W/2, y H/2) and += 1
@@ -253,7 +255,7 @@ int omfs_sh_rest_grads(const omfs_gaussians* g, const float* face_xf_all, int n_
                        const omfs_view_set* views, const float* drgb_all, int sh_degree, float* grads, void* stream);
 
 /* (1-lambda) L1 + lambda (1-SSIM), 11x11 gaussian window, zero padding.
- * Writes dimage [3][H][W] and adds the scalar loss into loss_out[0] (caller zeroes).
+ * Writes dimage [3][H][W] and the scalar loss into loss_out[0].
  * scratch: 3 * 3*H*W floats. */
 int omfs_loss_l1_ssim(const float* image, const float* target, int width, int height, float lambda_dssim,
                       float* dimage, float* loss_out, float* scratch, void* stream);

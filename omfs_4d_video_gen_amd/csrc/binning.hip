@@ -94,7 +94,8 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
     for (int k = 0; k < SCAN_PER; ++k) {
       if (beg + k < n_tiles) {
         uint32_t c = single ? cnt[k] : tile_count[beg + k];
-        if (overflow) { c = 0; tile_count[beg + k] = 0; tile_start[beg + k] = 0; }
+        tile_count[beg + k] = 0;                       // consumed: the next frame's omfs_bin_count accumulates from zero
+        if (overflow) { c = 0; tile_start[beg + k] = 0; }
         const int bucket = c ? (32 - __clz(c)) : 0;
         const unsigned long long old = atomicAdd(&bucket_acc[32 - bucket], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
         const uint32_t pos = (uint32_t)old;
@@ -530,7 +531,6 @@ extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, c
   OMFS_REQUIRE(g && g->n > 0 && rb->g0 && rb->g1, "gaussians");
   const int gx = cdiv(cam->width, OMFS_TILE), n_tiles = gx * cdiv(cam->height, OMFS_TILE);
   hipStream_t s = (hipStream_t)stream;
-  OMFS_CHECK_HIP(hipMemsetAsync(rb->tile_count, 0, sizeof(uint32_t) * n_tiles, s));
   PairSource ps{(const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2};
   const size_t lds = (size_t)n_tiles * 4 + BIN_SCRATCH_BYTES;
   if (lds <= BIN_LDS_LIMIT) {

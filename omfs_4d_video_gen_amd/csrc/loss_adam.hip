@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ 
   }
 }
 
-// one block: loss_out += constant + sum(partials)   (fixed order: bitwise reproducible)
+// one block: loss_out = constant + sum(partials)   (fixed order: bitwise reproducible)
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ partials, int n, float constant,
                                                           float* __restrict__ loss_out) {
   __shared__ float ws[16];
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int w = 0; w < 16; ++w) t += ws[w];
-    loss_out[0] += constant + t;
+    loss_out[0] = constant + t;
   }
 }
 

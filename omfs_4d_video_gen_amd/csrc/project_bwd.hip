@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
                                                           const int32_t* __restrict__ binding,
                                                           const float* __restrict__ face_xf, ProjCamB cam,
                                                           const float4* __restrict__ g2,
-                                                          const float4* __restrict__ dsplat, RegK reg,
+                                                          float4* __restrict__ dsplat, RegK reg,
                                                           const uint32_t* __restrict__ n_visible,
                                                           float* __restrict__ grads, float* __restrict__ densify_stats,
                                                           float half_w, float half_h, float* __restrict__ dface, float* __restrict__ drgb_out) {
@@ -50,6 +50,10 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
   }
   const uint32_t clampbits = rbits >> 28;
   const float4 d0 = dsplat[(size_t)i * 4 + 0], d1 = dsplat[(size_t)i * 4 + 1], d2 = dsplat[(size_t)i * 4 + 2];
+  {   // consumed: leave the record zeroed for the next iteration's composite_bwd (no separate clear pass)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    dsplat[(size_t)i * 4 + 0] = z; dsplat[(size_t)i * 4 + 1] = z; dsplat[(size_t)i * 4 + 2] = z;
+  }
   const float dpx = d0.x, dpy = d0.y, dA = d0.z, dB = d0.w, dC = d1.x, dop = d1.y;
   if (densify_stats) {   // adaptive density control statistics
     const float gx = dpx * half_w, gy = dpy * half_h;
@@ -368,7 +372,7 @@ extern "C" int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, c
   pc.fx = cam->fx; pc.fy = cam->fy; pc.limx = cam->limx; pc.limy = cam->limy; pc.sh_degree = cam->sh_degree;
   RegK rk{reg->lambda_xyz, reg->thr_xyz, reg->lambda_scale, reg->thr_scale};
   hipLaunchKernelGGL(project_bwd_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, (hipStream_t)stream, g->n, g->n_pad,
-                     g->params, g->binding, face_xf, pc, (const float4*)rb->g2, (const float4*)gb->dsplat, rk,
+                     g->params, g->binding, face_xf, pc, (const float4*)rb->g2, (float4*)gb->dsplat, rk,
                      reg->n_visible, gb->grads, gb->densify_stats, 0.5f * (float)cam->width, 0.5f * (float)cam->height, gb->dface, gb->drgb_out);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;

@@ -129,7 +129,7 @@ class Rasterizer:
             self.loss_scratch = torch.zeros(3, 3, self.height, self.width, device=dev)
 
     def loss_l1_ssim(self, target: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
-        """Adds this view's loss into self.loss (device scalar, zero it yourself) and writes self.dimage."""
+        """Writes this view's loss into self.loss (device scalar) and dL/dimage into self.dimage."""
         self._ensure_bwd()
         if target.shape != self.image.shape or target.dtype != torch.float32 or not target.is_contiguous():
             raise ValueError("target must be a contiguous float32 [3][H][W] tensor")

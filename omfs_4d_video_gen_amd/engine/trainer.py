@@ -203,9 +203,7 @@ class Trainer:
         L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
         L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
         r.composite(cam); tm.mark("composite_fwd")
-        r.loss.zero_()
         r.loss_l1_ssim(view.target, self.lambda_dssim); tm.mark("loss")
-        r.dsplat.zero_()
         if self.compact_dp and (self.drgb_local is None or self.drgb_local.shape[1] != self.model.n_pad):
             self.drgb_local = torch.zeros(3, self.model.n_pad, device=self.device)
             self.drgb_scratch = torch.zeros(3, self.model.n_pad, device=self.device)
