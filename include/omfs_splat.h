@@ -156,6 +156,9 @@ typedef struct omfs_raster_buffers {
   uint32_t* n_contrib;    /* [height][width]                                                     */
   uint32_t flags;         /* OMFS_RB_FORWARD_ONLY: no backward pass will follow (render_surgery): the forward skips
                              the segment checkpoints (only the hand-over slots between its two kernels are written) */
+  uint32_t* n_visible;    /* optional [1]: number of Gaussians with radius > 0 in this view; omfs_project_fwd clears it,
+                             omfs_bin_count accumulates it (what omfs_count_visible computes, without its two
+                             dispatches); may be NULL                                                              */
 } omfs_raster_buffers;
 #define OMFS_RB_FORWARD_ONLY 1u
 

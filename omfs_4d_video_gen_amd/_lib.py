@@ -57,7 +57,8 @@ class RasterBuffersC(C.Structure):
                 ("tile_order", c_void_p), ("keys", c_void_p), ("keys_tmp", c_void_p), ("sorted_ids", c_void_p),
                 ("dup_capacity", C.c_uint32), ("sort_lds_pairs", C.c_uint32), ("status", c_void_p),
                 ("seg_ckpt", c_void_p), ("order_seg0", c_void_p), ("seg_capacity", C.c_uint32),
-                ("image", c_void_p), ("final_T", c_void_p), ("n_contrib", c_void_p), ("flags", C.c_uint32)]
+                ("image", c_void_p), ("final_T", c_void_p), ("n_contrib", c_void_p), ("flags", C.c_uint32),
+                ("n_visible", c_void_p)]
 
 
 class GradBuffersC(C.Structure):

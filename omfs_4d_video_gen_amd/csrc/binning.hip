@@ -153,17 +153,20 @@ __device__ __forceinline__ void for_each_touched_tile(const PairSource& ps, int 
 }
 
 // Every lane of the wave must call this (i >= n publishes an empty rectangle).  Returns the wave's rectangle-tile total.
-__device__ __forceinline__ uint32_t publish_rects(const PairSource& ps, int i, int n, WaveRects* wr) {
+__device__ __forceinline__ uint32_t publish_rects(const PairSource& ps, int i, int n, WaveRects* wr, bool* visible = nullptr) {
   const int lane = lane_id();
   uint32_t rect = 0u, depth = 0u;
+  bool vis = false;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
   float2 r1 = make_float2(0.f, 0.f);
   if (i < n) {
     const float4 r2 = ps.g2[i];
     rect = __float_as_uint(r2.w);
     depth = __float_as_uint(r2.y);
+    vis = (__float_as_uint(r2.z) & 0xFFFFFu) != 0u;     // radius > 0
     if (rect) { r0 = ps.g0[i]; const float4 t = ps.g1[i]; r1 = make_float2(t.x, t.y); }
   }
+  if (visible) *visible = vis;
   const uint32_t area = (((rect >> 16) & 255u) - (rect & 255u)) * ((rect >> 24) - ((rect >> 8) & 255u));
   const uint32_t incl = wave_incl_scan_u32(area, lane);
   wr->r0[lane] = r0; wr->r1[lane] = r1; wr->scan[lane] = incl; wr->rect[lane] = rect; wr->depth[lane] = depth;
@@ -215,14 +218,22 @@ __device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* 
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSource ps, int gx, int n_tiles,
                                                                 uint32_t* __restrict__ tile_count,
-                                                                unsigned long long* __restrict__ hits_all) {
+                                                                unsigned long long* __restrict__ hits_all,
+                                                                uint32_t* __restrict__ n_visible) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ uint32_t s_vis;
   WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
+  if (threadIdx.x == 0) s_vis = 0u;
   const int i = blockIdx.x * BIN_THREADS + threadIdx.x;
-  const uint32_t total = publish_rects(ps, i, n, wr);
+  bool vis;
+  const uint32_t total = publish_rects(ps, i, n, wr, &vis);
   __syncthreads();
+  if (n_visible) {     // #Gaussians with radius > 0: one LDS atomic per wave, one global atomic per block
+    const uint32_t cnt = (uint32_t)__popcll(__ballot(vis));
+    if (lane_id() == 0 && cnt) atomicAdd(&s_vis, cnt);
+  }
   unsigned long long* hits = hits_all ? hits_all + ((size_t)blockIdx.x * BIN_WAVES + (threadIdx.x >> 6)) * HITS_PER_WAVE : nullptr;
   for_each_touched_tile_balanced<HITS_RECORD>(wr, total, gx, hits, [&](int t, int) { atomicAdd(&hist[t], 1u); });
   __syncthreads();
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSourc
     const uint32_t c = hist[t];
     if (c) atomicAdd(&tile_count[t], c);
   }
+  if (n_visible && threadIdx.x == 0 && s_vis) atomicAdd(n_visible, s_vis);
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSource ps, int gx, int n_tiles,
@@ -261,8 +273,14 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSou
 }
 
 // Fallback for images with more tiles than fit in LDS: one global atomic per pair.
-__global__ __launch_bounds__(256) void bin_count_direct_kernel(int n, PairSource ps, int gx, uint32_t* __restrict__ tile_count) {
+__global__ __launch_bounds__(256) void bin_count_direct_kernel(int n, PairSource ps, int gx, uint32_t* __restrict__ tile_count,
+                                                               uint32_t* __restrict__ n_visible) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_visible) {
+    const bool vis = i < n && (__float_as_uint(ps.g2[i].z) & 0xFFFFFu) != 0u;
+    const uint32_t cnt = (uint32_t)__popcll(__ballot(vis));
+    if (lane_id() == 0 && cnt) atomicAdd(n_visible, cnt);
+  }
   if (i < n) for_each_touched_tile(ps, i, gx, [&](int t) { atomicAdd(&tile_count[t], 1u); });
 }
 
@@ -536,13 +554,13 @@ extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, c
   if (lds <= BIN_LDS_LIMIT) {
     static bool attr_set = false;
     if (!attr_set) {
-      OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));   // + a static word
       attr_set = true;
     }
     hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles, rb->tile_count,
-                       hits_buffer(g->n, rb));
+                       hits_buffer(g->n, rb), rb->n_visible);
   } else {
-    hipLaunchKernelGGL(bin_count_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, rb->tile_count);
+    hipLaunchKernelGGL(bin_count_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, rb->tile_count, rb->n_visible);
   }
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;

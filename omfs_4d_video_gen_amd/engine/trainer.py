@@ -86,6 +86,7 @@ class Trainer:
         self.model = GaussianModel(gaussians, device=device)
         self.rast = Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity, n_capacity=n_capacity)
         self.rast._ensure_bwd()
+        self.rast.rb.n_visible = L.ptr(self.rast.n_visible)   # counted by omfs_bin_count (no omfs_count_visible dispatches)
         self.views = views
         self.bg = tuple(bg)
         self.iterations = iterations
@@ -216,7 +217,6 @@ class Trainer:
             from .distributed import allgather_into_
             L.check(lib.omfs_extract_drgb(r.rb, L.ptr(r.dsplat), self.model.n, self.model.n_pad, L.ptr(self.drgb_local), s), "omfs_extract_drgb")
             gather = allgather_into_(self.drgb_all, self.drgb_local, self.pg, async_op=True)
-        L.check(lib.omfs_count_visible(r.rb, r.n, L.ptr(r.n_visible), s), "omfs_count_visible")
         rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
         L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
         if ft is not None:

@@ -145,3 +145,17 @@ def test_long_tile_uses_global_sort_path():
     assert torch.equal(rast.tile_start, tiny.tile_start)
     assert torch.equal(rast.sorted_ids[:D], tiny.sorted_ids[:D])
     assert torch.equal(rast.image, tiny.image)
+
+
+def test_visible_count_accumulated_by_the_binning_pass():
+    """omfs_raster_buffers.n_visible: cleared by project_fwd, accumulated by bin_count == omfs_count_visible."""
+    from omfs_4d_video_gen_amd import _lib as L
+    rig, g, seq, cam, dflame, model, rast, mk = _setup(5000, 160, 120)
+    _, face_xf = dflame.face_frames(0, 1)
+    counter = torch.full((1,), 12345, dtype=torch.int32, device="cuda")
+    rast.rb.n_visible = L.ptr(counter)
+    for _ in range(2):                                   # twice: the counter is cleared every frame
+        rast.forward(model, face_xf[0], mk(cam))
+    torch.cuda.synchronize()
+    radius = rast.g2[:, 2].contiguous().view(torch.int32) & 0xFFFFF
+    assert int(counter.item()) == int((radius > 0).sum().item()) > 0
