@@ -134,6 +134,11 @@ class DeviceFlame:
         so = flame_params.get("static_offset")
         if so is not None:
             so = np.asarray(so, np.float64).reshape(-1, 3)
+            if so.shape[0] > V:
+                # datasets written for upstream carry offsets for its procedural teeth (5023 FLAME + 120 appended
+                # vertices, flame_fitter.py:439); a rig without them uses the leading V rows
+                print(f"[engine] static_offset has {so.shape[0]} vertices, the rig {V}: using the first {V} (no teeth geometry)")
+                so = so[:V]
             if so.shape[0] != V:
                 raise ValueError(f"static_offset has {so.shape[0]} vertices, rig has {V}")
             v_static = v_static + so
@@ -154,7 +159,10 @@ class DeviceFlame:
         dyn = flame_params.get("dynamic_offset")
         self.h_dynamic = None
         if dyn is not None and np.any(dyn):
-            self.h_dynamic = np.asarray(dyn, np.float32).reshape(self.n_frames, V, 3)
+            dyn = np.asarray(dyn, np.float32).reshape(self.n_frames, -1, 3)
+            if dyn.shape[1] < V:
+                raise ValueError(f"dynamic_offset has {dyn.shape[1]} vertices, rig has {V}")
+            self.h_dynamic = np.ascontiguousarray(dyn[:, :V])
         dev = self.device
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         self.basis_tiled = up(tile_basis(self.h_basis, self.k_pad, self.v_pad))
