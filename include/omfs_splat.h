@@ -186,8 +186,9 @@ int omfs_image_to_rgb8(const float* image, int width, int height, uint8_t* rgb8,
 
 /* ------------------------------------------------------------------ backward + optimiser */
 typedef struct omfs_grad_buffers {
-  float* dsplat;          /* [n][16] per-Gaussian 2D-splat gradient record (atomically accumulated by omfs_composite_bwd):
-                             dmean2d.xy, dconic.abc, dopacity, drgb; zero before the first use -- omfs_project_bwd
+  float* dsplat;          /* [n][16] per-Gaussian record atomically accumulated by omfs_composite_bwd: the moments
+                             S_x, S_y, S_xx, S_xy, S_yy of dL/dG*G over the pixels (dx = mean - pixel; omfs_project_bwd
+                             turns them into d mean2d / d conic), dopacity, drgb; zero before the first use -- omfs_project_bwd
                              clears every record it consumes, so a composite_bwd / project_bwd pair leaves it zeroed */
   float* grads;           /* [59][n_pad] parameter gradients (overwritten)                         */
   const float* dimage;    /* [3][H][W] dL/dimage                                                   */

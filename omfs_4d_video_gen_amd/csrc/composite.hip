@@ -516,7 +516,6 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
   __shared__ uint32_t sid[WB];
   __shared__ float red[PEND][8][9];       // [pending slot][8-lane group][value]
   __shared__ uint32_t pend_id[PEND];      // Gaussian id of each pending slot
-  __shared__ float pend_abc[PEND][3];     // its conic in the staged form (A2, B2, C2)
   const uint32_t seg = blockIdx.x >> 2;
   if (seg >= order_seg0[n_tiles]) return;
   // launch-order position p with order_seg0[p] <= seg < order_seg0[p+1] (bisection, ~13 L2-resident loads)
@@ -578,14 +577,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
         float sum = 0.f;
 #pragma unroll
         for (int p8 = 0; p8 < 8; ++p8) sum += src[p8 * 9];
-        // moments -> gradients of the 2-D splat (lanes q = 0, 1 exchange S_x, S_y)
-        const float other = __shfl_xor(sum, 1, 64);
-        const float A2 = pend_abc[slot][0], B2 = pend_abc[slot][1], C2 = pend_abc[slot][2];
-        float out = sum;
-        if (q == 0) out = (1.f / LOG2E) * fma_(2.f * A2, sum, B2 * other);        // d mean2d.x
-        else if (q == 1) out = (1.f / LOG2E) * fma_(2.f * C2, sum, B2 * other);   // d mean2d.y
-        else if (q == 2 || q == 4) out = -0.5f * sum;                             // d conic.a, d conic.c
-        else if (q == 3) out = -sum;                                              // d conic.b (B multiplies dx*dy once)
+        const float out = sum;   // moments; omfs_project_bwd turns them into d mean2d / d conic
         if (out != 0.f) atomicAdd(&dsplat[(size_t)pend_id[slot] * 16 + q], out);
       }
     }
@@ -674,8 +666,8 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
         // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream rasteriser does
         // (DESIGN.md "Frozen conventions").  Only the moments of gL = dL/dG * G over the pixels are reduced here:
         //   S_x = sum gL dx, S_y, S_xx, S_xy, S_yy  (dx = mean - pixel);
-        // the flush turns them into d mean2d = (2 A2 S_x + B2 S_y, 2 C2 S_y + B2 S_x) / log2e and
-        // d conic = (-S_xx / 2, -S_xy, -S_yy / 2)  (A2 = -0.5 log2e A etc. as staged).
+        // omfs_project_bwd turns them into d mean2d = -(A S_x + B S_y, C S_y + B S_x) and
+        // d conic = (-S_xx / 2, -S_xy, -S_yy / 2), once per Gaussian.
         const float gL = oG * dLa;                     // opacity folded in
         v[0] = gL * dx;
         v[1] = gL * dy;
@@ -690,10 +682,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
 #pragma unroll
         for (int q = 0; q < 9; ++q) dst[q] = v[q];
       }
-      if (lane == 0) {
-        pend_id[n_pending] = sid[jb];
-        pend_abc[n_pending][0] = a.z; pend_abc[n_pending][1] = a.w; pend_abc[n_pending][2] = c.x;   // A2, B2, C2
-      }
+      if (lane == 0) pend_id[n_pending] = sid[jb];
       if (++n_pending == PEND) { flush_pending(); n_pending = 0; }
     };
     while (m) {

@@ -26,6 +26,7 @@ struct RegK {
 __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, const float* __restrict__ params,
                                                           const int32_t* __restrict__ binding,
                                                           const float* __restrict__ face_xf, ProjCamB cam,
+                                                          const float4* __restrict__ g0, const float4* __restrict__ g1,
                                                           const float4* __restrict__ g2,
                                                           float4* __restrict__ dsplat, RegK reg,
                                                           const uint32_t* __restrict__ n_visible,
@@ -54,7 +55,13 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, cons
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     dsplat[(size_t)i * 4 + 0] = z; dsplat[(size_t)i * 4 + 1] = z; dsplat[(size_t)i * 4 + 2] = z;
   }
-  const float dpx = d0.x, dpy = d0.y, dA = d0.z, dB = d0.w, dC = d1.x, dop = d1.y;
+  // composite_bwd accumulates the MOMENTS of dL/dG * G over the pixels (dx = mean - pixel):
+  //   d0 = (S_x, S_y, S_xx, S_xy), d1.x = S_yy;   with the projected conic (A, B, C) of g0 / g1
+  //   d mean2d = -(A S_x + B S_y, C S_y + B S_x),   d conic = (-S_xx / 2, -S_xy, -S_yy / 2)
+  const float4 c0 = g0[i];
+  const float cA = c0.z, cB = c0.w, cC = g1[i].x;
+  const float dpx = -fma_(cA, d0.x, cB * d0.y), dpy = -fma_(cC, d0.y, cB * d0.x);
+  const float dA = -0.5f * d0.z, dB = -d0.w, dC = -0.5f * d1.x, dop = d1.y;
   if (densify_stats) {   // adaptive density control statistics
     const float gx = dpx * half_w, gy = dpy * half_h;
     densify_stats[i] += sqrtf(gx * gx + gy * gy);
@@ -365,14 +372,14 @@ extern "C" int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, c
                                 const omfs_raster_buffers* rb, const omfs_grad_buffers* gb,
                                 const omfs_reg_params* reg, void* stream) {
   OMFS_REQUIRE(g && face_xf && cam && rb && gb && reg, "null pointer");
-  OMFS_REQUIRE(g->n > 0 && g->n_pad >= g->n && g->params && g->binding && rb->g2 && gb->dsplat && gb->grads && reg->n_visible, "buffers");
+  OMFS_REQUIRE(g->n > 0 && g->n_pad >= g->n && g->params && g->binding && rb->g0 && rb->g1 && rb->g2 && gb->dsplat && gb->grads && reg->n_visible, "buffers");
   ProjCamB pc;
   for (int i = 0; i < 12; ++i) pc.view[i] = cam->view[i];
   for (int i = 0; i < 3; ++i) pc.cam_pos[i] = cam->cam_pos[i];
   pc.fx = cam->fx; pc.fy = cam->fy; pc.limx = cam->limx; pc.limy = cam->limy; pc.sh_degree = cam->sh_degree;
   RegK rk{reg->lambda_xyz, reg->thr_xyz, reg->lambda_scale, reg->thr_scale};
   hipLaunchKernelGGL(project_bwd_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, (hipStream_t)stream, g->n, g->n_pad,
-                     g->params, g->binding, face_xf, pc, (const float4*)rb->g2, (float4*)gb->dsplat, rk,
+                     g->params, g->binding, face_xf, pc, (const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2, (float4*)gb->dsplat, rk,
                      reg->n_visible, gb->grads, gb->densify_stats, 0.5f * (float)cam->width, 0.5f * (float)cam->height, gb->dface, gb->drgb_out);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
