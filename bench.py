@@ -231,6 +231,16 @@ def main():
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes": int(sb[dom]), "avg_ms": round(dom_ms, 4)}
+    # what actually bounds that kernel: VALU issue utilisation from the committed PMC pass (profiles/*_pmc_instruction_mix.json)
+    try:
+        import glob
+        mix = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_instruction_mix.json")))[-1]
+        for kname, vals in json.load(open(mix)).items():
+            if f"{dom}_kernel" in kname and "valu_issue_util" in vals:
+                roofline["valu_issue_util"] = vals["valu_issue_util"]
+                roofline["valu_note"] = "SQ_ACTIVE_INST_VALU*4/(1024 SIMDs x kernel cycles), " + os.path.basename(mix)
+    except Exception:
+        pass
     total_bytes = sum(sb[k] for k in stages if k in sb)
 
     out = {
