@@ -88,11 +88,13 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
         const float C1 = 0.0001f, C2 = 0.0009f;
         const float s11 = exx - mu1 * mu1, s22 = eyy - mu2 * mu2, s12 = exy - mu1 * mu2;
         const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
-        const float iB = 1.f / (B1 * B2);
+        // v_rcp_f32 (1 ulp) instead of three correctly rounded divisions: this stage is tolerance-level
+        const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
+        const float iB = iB1 * iB2;
         const float ssim = A1 * A2 * iB;
         const size_t o = ch * plane + (size_t)yout * width + xo;
-        map_mu1[o] = (2.f * mu2 * (A2 - A1)) * iB - 2.f * mu1 * ssim / B1 + 2.f * mu1 * ssim / B2;
-        map_xx[o] = -ssim / B2;
+        map_mu1[o] = (2.f * mu2 * (A2 - A1)) * iB - 2.f * mu1 * ssim * iB1 + 2.f * mu1 * ssim * iB2;
+        map_xx[o] = -ssim * iB2;
         map_xy[o] = 2.f * A1 * iB;
         contrib -= w_ssim * ssim;
       }
