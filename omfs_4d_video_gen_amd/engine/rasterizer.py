@@ -113,11 +113,33 @@ class Rasterizer:
                 "omfs_image_to_rgb8")
         return self.rgb8
 
+    def overflowed(self) -> bool:
+        """Host sync: did the device flag a tile-list capacity overflow since the flag was last cleared?"""
+        return bool(int(self.status.item()) & 1)
+
     def check_status(self):
         """Host sync: raise if the device flagged a capacity overflow."""
-        st = int(self.status.item())
-        if st & 1:
+        if self.overflowed():
             raise L.OmfsError(f"tile-list capacity {self.dup_capacity} exceeded; re-create the Rasterizer with a larger dup_capacity")
+
+    def grow_dup_capacity(self, factor: float = 2.0) -> int:
+        """Re-allocate the pair-sized buffers (keys, keys_tmp, sorted_ids, checkpoints) `factor` times larger and clear the
+        overflow flag.  An iteration that overflowed rendered empty lists (the scan zeroes them), i.e. contributed next to
+        no gradient; the caller simply goes on."""
+        torch.cuda.synchronize(self.device)
+        self.dup_capacity = int(self.dup_capacity * factor)
+        dev = self.device
+        z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
+        self.keys = z(self.dup_capacity, 2, dt=torch.int32)
+        self.keys_tmp = z(self.dup_capacity, 2, dt=torch.int32)
+        self.sorted_ids = z(self.dup_capacity, dt=torch.int32)
+        self.seg_capacity = self.n_tiles + self.dup_capacity // L.SEG + 1
+        self.seg_ckpt = z(self.seg_capacity, 256, 4)
+        self.status.zero_()
+        rb = self.rb
+        rb.keys, rb.keys_tmp, rb.sorted_ids = L.ptr(self.keys), L.ptr(self.keys_tmp), L.ptr(self.sorted_ids)
+        rb.dup_capacity, rb.seg_ckpt, rb.seg_capacity = self.dup_capacity, L.ptr(self.seg_ckpt), self.seg_capacity
+        return self.dup_capacity
 
     # ------------------------------------------------------------------ backward
     def _ensure_bwd(self):

@@ -193,8 +193,10 @@ def main(argv=None):
             if rank == 0:
                 print(f"Training progress: iteration {it}/{args.iterations} loss={trainer.loss_value():.5f} "
                       f"({(it - it0) / (time.time() - t0):.1f} it/s)", flush=True)
-            if it % (10 * args.log_every) == 0:
-                trainer.rast.check_status()
+            if it % (10 * args.log_every) == 0 and trainer.rast.overflowed():
+                new_cap = trainer.rast.grow_dup_capacity(2.0)      # every rank sees the same schedule of views, hence the same overflow
+                if rank == 0:
+                    print(f"[ITER {it}] tile-list capacity exceeded: grown to {new_cap} pairs", flush=True)
         if rank == 0 and it in save_at:
             print(f"\n[ITER {it}] Saving Gaussians", flush=True)
             g = trainer.model.to_dict()

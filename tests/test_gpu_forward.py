@@ -128,6 +128,14 @@ def test_empty_and_capacity():
     torch.cuda.synchronize()
     with pytest.raises(L.OmfsError):
         small.check_status()
+    # the overflowed frame has empty lists (background only); growing the capacity recovers the image
+    assert float(small.image[0].max()) == float(small.image[0].min())
+    ref = rast.forward(model, face_xf[0], mk(cam)).clone()
+    while small.overflowed():
+        small.grow_dup_capacity(4.0)
+        small.forward(model, face_xf[0], mk(cam))
+        torch.cuda.synchronize()
+    assert small.dup_capacity >= int(rast.tile_start[-1]) and torch.equal(small.image, ref)
 
 
 def test_long_tile_uses_global_sort_path():
