@@ -274,6 +274,10 @@ typedef struct omfs_adam_params {
 /* torch.optim.Adam semantics on params/m/v [59][n_pad] */
 int omfs_adam_step(float* params, const float* grads, float* m, float* v, int n, int n_pad,
                    const omfs_adam_params* ap, void* stream);
+/* the same step on planes [plane0, plane0 + n_planes) only (same ap->step for every part of one iteration): lets the
+ * data-parallel trainer update the planes whose gradients are complete while the others are still being reduced */
+int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v, int n, int n_pad,
+                          const omfs_adam_params* ap, int plane0, int n_planes, void* stream);
 
 /* #Gaussians with radius>0 of the last projected view -> count_out[0] (device) */
 int omfs_count_visible(const omfs_raster_buffers* rb, int n, uint32_t* count_out, void* stream);

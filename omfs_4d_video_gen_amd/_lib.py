@@ -114,6 +114,8 @@ SIGNATURES = {
                                    C.POINTER(GradBuffersC), C.POINTER(RegParamsC), c_void_p]),
     "omfs_loss_l1_ssim": (C.c_int, [c_void_p, c_void_p, C.c_int, C.c_int, C.c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_adam_step": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), c_void_p]),
+    "omfs_adam_step_planes": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), C.c_int, C.c_int,
+                                        c_void_p]),
     "omfs_count_visible": (C.c_int, [C.POINTER(RasterBuffersC), C.c_int, c_void_p, c_void_p]),
 }
 

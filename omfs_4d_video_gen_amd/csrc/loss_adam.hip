@@ -194,8 +194,8 @@ struct AdamK {
 // grid = (n_pad/1024 [float4 x 256], 59)
 __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
                                                    float4* __restrict__ m, float4* __restrict__ v, int n4_per_plane,
-                                                   AdamK k) {
-  const int plane = blockIdx.y;
+                                                   AdamK k, int plane0) {
+  const int plane = plane0 + blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4_per_plane) return;
   const size_t o = (size_t)plane * n4_per_plane + i;
@@ -247,18 +247,29 @@ extern "C" int omfs_loss_l1_ssim(const float* image, const float* target, int wi
   return OMFS_OK;
 }
 
-extern "C" int omfs_adam_step(float* params, const float* grads, float* m, float* v, int n, int n_pad,
-                              const omfs_adam_params* ap, void* stream) {
+static int adam_launch(float* params, const float* grads, float* m, float* v, int n, int n_pad, const omfs_adam_params* ap,
+                       int plane0, int n_planes, void* stream) {
   OMFS_REQUIRE(params && grads && m && v && ap, "null pointer");
   OMFS_REQUIRE(n > 0 && n_pad >= n && n_pad % 256 == 0 && ap->step >= 1, "shape");
+  OMFS_REQUIRE(plane0 >= 0 && n_planes >= 1 && plane0 + n_planes <= OMFS_NPLANES, "plane range");
   AdamK k;
   const double bc1 = 1.0 - pow((double)ap->beta1, ap->step), bc2 = 1.0 - pow((double)ap->beta2, ap->step);
   for (int i = 0; i < OMFS_NPLANES; ++i) k.lr_step[i] = (float)(ap->lr[i] / bc1);
   k.b1 = ap->beta1; k.b2 = ap->beta2; k.eps = ap->eps; k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   k.grad_scale = ap->grad_scale;
   const int n4 = n_pad / 4;
-  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n4, 256), OMFS_NPLANES), dim3(256), 0, (hipStream_t)stream, (float4*)params,
-                     (const float4*)grads, (float4*)m, (float4*)v, n4, k);
+  hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n4, 256), n_planes), dim3(256), 0, (hipStream_t)stream, (float4*)params,
+                     (const float4*)grads, (float4*)m, (float4*)v, n4, k, plane0);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
+}
+
+extern "C" int omfs_adam_step(float* params, const float* grads, float* m, float* v, int n, int n_pad,
+                              const omfs_adam_params* ap, void* stream) {
+  return adam_launch(params, grads, m, v, n, n_pad, ap, 0, OMFS_NPLANES, stream);
+}
+
+extern "C" int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v, int n, int n_pad,
+                                     const omfs_adam_params* ap, int plane0, int n_planes, void* stream) {
+  return adam_launch(params, grads, m, v, n, n_pad, ap, plane0, n_planes, stream);
 }

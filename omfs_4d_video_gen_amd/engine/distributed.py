@@ -23,10 +23,13 @@ def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
     return range(rank, n_frames, world)
 
 
-def allreduce_sum_(buf: torch.Tensor, group=None) -> torch.Tensor:
-    """In-place sum over ranks of the gradient SoA (one collective for all 59 planes)."""
+def allreduce_sum_(buf: torch.Tensor, group=None, async_op: bool = False):
+    """In-place sum over ranks of the gradient SoA (or a contiguous plane range of it).  With async_op the work handle
+    is returned (call .wait() before reading buf)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            return work
     return buf
 
 

@@ -199,6 +199,17 @@ class Adam:
             raise ValueError("need one learning rate per parameter plane (59)")
         self.ap.lr[:] = [float(x) for x in lr]
 
+    def begin_step(self, grad_scale: float = 1.0):
+        """Open the next iteration for `apply_planes` (several partial updates that share one step count)."""
+        self.step_count += 1
+        self.ap.step = self.step_count
+        self.ap.grad_scale = float(grad_scale)
+
+    def apply_planes(self, grads: torch.Tensor, plane0: int, n_planes: int):
+        m = self.model
+        L.check(L.load().omfs_adam_step_planes(L.ptr(m.params), L.ptr(grads), L.ptr(self.m), L.ptr(self.v), m.n, m.n_pad,
+                                               C.byref(self.ap), int(plane0), int(n_planes), L.stream_ptr()), "omfs_adam_step_planes")
+
     def step(self, grads: torch.Tensor, grad_scale: float = 1.0):
         self.step_count += 1
         self.ap.step = self.step_count

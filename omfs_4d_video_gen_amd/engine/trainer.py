@@ -224,20 +224,31 @@ class Trainer:
         if self.world > 1:
             from .distributed import allgather_into_, allreduce_sum_
             if self.compact_dp:
-                allreduce_sum_(self.grads[:P_SH + 3], self.pg)            # 14 contiguous planes
+                # 14 contiguous planes, asynchronously: the 45 rebuilt SH planes are updated while they are on the links
+                reduce14 = allreduce_sum_(self.grads[:P_SH + 3], self.pg, async_op=True)
                 gather.wait()
                 L.check(lib.omfs_sh_rest_grads(g, L.ptr(face_xf), self.dflame.rig.n_faces, L.ptr(self.cam_pos_table), pat[1],
                                                L.ptr(self.drgb_all), self.sh_degree, L.ptr(self.grads), s), "omfs_sh_rest_grads")
             else:
                 allreduce_sum_(self.grads, self.pg)
-            if ft is not None:         # every rank touched a different timestep: dense (tiny) gradient tensors, summed
+            if ft is not None and not self.compact_dp:   # every rank touched a different timestep: dense (tiny) tensors, summed
                 for gr in ft.grads():
                     allreduce_sum_(gr, self.pg)
             tm.mark("allreduce")
         lr = expon_lr(it, self.pos_lr[0], self.pos_lr[1], self.iterations)
         self.lr_planes[0:3] = lr
         self.opt.set_lr(self.lr_planes)
-        self.opt.step(self.grads, 1.0 / self.world)
+        if self.compact_dp:
+            self.opt.begin_step(1.0 / self.world)
+            self.opt.apply_planes(self.grads, P_SH + 3, NPLANES - (P_SH + 3))     # the rebuilt SH planes
+            if ft is not None:
+                from .distributed import allreduce_sum_
+                for gr in ft.grads():
+                    allreduce_sum_(gr, self.pg)
+            reduce14.wait()
+            self.opt.apply_planes(self.grads, 0, P_SH + 3)
+        else:
+            self.opt.step(self.grads, 1.0 / self.world)
         if ft is not None:
             ft.step(1.0 / self.world)
         tm.mark("adam")
