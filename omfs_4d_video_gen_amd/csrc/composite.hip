@@ -706,6 +706,22 @@ __global__ void image_to_rgb8_kernel(const float* __restrict__ image, int width,
   }
 }
 
+// The same 8-bit conversion laid out as the raw scanlines of a PNG: every row starts with filter byte 0, so the host only
+// has to deflate the buffer (no per-frame reshuffle under the interpreter lock).
+__global__ void image_to_png_rows_kernel(const float* __restrict__ image, int width, int height, uint8_t* __restrict__ rows) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = width * height;
+  if (i >= n) return;
+  const int y = i / width, x = i - y * width;
+  uint8_t* o = rows + (size_t)y * (1 + 3 * (size_t)width) + 1 + 3 * (size_t)x;
+  if (x == 0) o[-1] = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = fminf(fmaxf(image[(size_t)c * n + i], 0.f), 1.f);
+    o[c] = (uint8_t)(v * 255.f + 0.5f);
+  }
+}
+
 static CompCam make_compcam(const omfs_camera* c) {
   CompCam k;
   k.width = c->width; k.height = c->height; k.gx = cdiv(c->width, OMFS_TILE);
@@ -766,6 +782,14 @@ extern "C" int omfs_image_to_rgb8(const float* image, int width, int height, uin
   OMFS_REQUIRE(image && rgb8 && width > 0 && height > 0, "args");
   hipLaunchKernelGGL(image_to_rgb8_kernel, dim3(cdiv(width * height, 256)), dim3(256), 0, (hipStream_t)stream, image,
                      width, height, rgb8);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_image_to_png_rows(const float* image, int width, int height, uint8_t* rows, void* stream) {
+  OMFS_REQUIRE(image && rows && width > 0 && height > 0, "args");
+  hipLaunchKernelGGL(image_to_png_rows_kernel, dim3(cdiv(width * height, 256)), dim3(256), 0, (hipStream_t)stream, image,
+                     width, height, rows);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -113,6 +113,14 @@ class Rasterizer:
                 "omfs_image_to_rgb8")
         return self.rgb8
 
+    def to_png_rows(self) -> torch.Tensor:
+        """[H][1 + 3W] uint8: the frame as PNG scanlines (filter byte 0 per row), ready for io_formats.encode_png_rows."""
+        if getattr(self, "png_rows", None) is None:
+            self.png_rows = torch.zeros(self.height, 1 + 3 * self.width, dtype=torch.uint8, device=self.device)
+        L.check(L.load().omfs_image_to_png_rows(L.ptr(self.image), self.width, self.height, L.ptr(self.png_rows), L.stream_ptr()),
+                "omfs_image_to_png_rows")
+        return self.png_rows
+
     def overflowed(self) -> bool:
         """Host sync: did the device flag a tile-list capacity overflow since the flag was last cleared?"""
         return bool(int(self.status.item()) & 1)

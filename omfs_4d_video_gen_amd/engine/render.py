@@ -101,13 +101,22 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     pool = ThreadPoolExecutor(max_workers=max(1, args.png_workers))
     pending = []
     mine = range(rank, len(cams), world)
+    n_slots = max(4, 2 * args.png_workers)
+
+    def encode_and_write(path, rows, event):
+        event.synchronize()                                   # the frame's device-to-host copy has landed
+        with open(path, "wb") as f:
+            f.write(IO.encode_png_rows(rows, w, h))
+
     for idx in mine:
         view = View(cams[idx], split["timestep_of_frame"][idx])
-        rgb8 = r.render(view, rgb8=True).cpu().numpy()          # sync per frame; encode overlaps the next frame
-        pending.append(pool.submit(IO.write_png, out_dir / "renders" / f"{idx:05d}.png", rgb8))
+        if len(pending) >= n_slots:                           # the pinned ring is reused: keep at most n_slots frames in flight
+            pending.pop(0).result()
+        rows, event = r.render_png_rows_to_host(view, n_slots)   # GPU-side scanlines, asynchronous copy to pinned memory
+        pending.append(pool.submit(encode_and_write, out_dir / "renders" / f"{idx:05d}.png", rows, event))
         src = os.path.join(args.source_path, split["frames"][idx]["file_path"])
         if os.path.exists(src):
-            pending.append(pool.submit(shutil.copyfile, src, out_dir / "gt" / f"{idx:05d}.png"))
+            shutil.copyfile(src, out_dir / "gt" / f"{idx:05d}.png")
     for f in pending:
         f.result()
     pool.shutdown()

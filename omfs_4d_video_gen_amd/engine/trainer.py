@@ -274,6 +274,22 @@ class Renderer:
         self.timer = StageTimer(False)
         self._cams = {}
 
+    def render_png_rows_to_host(self, view: View, n_slots: int = 4):
+        """Enqueue one frame and its asynchronous copy to a pinned host buffer as PNG scanlines ([H][1+3W] uint8).
+        Returns (numpy view of the pinned buffer, event): wait for the event (`event.synchronize()`, e.g. in the encoder
+        thread) before reading; the buffer is reused after n_slots further calls."""
+        self.render(view)
+        rows = self.rast.to_png_rows()
+        if getattr(self, "_host_ring", None) is None or len(self._host_ring) != n_slots:
+            self._host_ring = [torch.empty(rows.shape, dtype=torch.uint8, pin_memory=True) for _ in range(n_slots)]
+            self._host_events = [torch.cuda.Event() for _ in range(n_slots)]
+            self._host_next = 0
+        k = self._host_next
+        self._host_next = (k + 1) % n_slots
+        self._host_ring[k].copy_(rows, non_blocking=True)
+        self._host_events[k].record()
+        return self._host_ring[k].numpy(), self._host_events[k]
+
     def render(self, view: View, rgb8: bool = False):
         """Enqueue one frame; returns the reused image tensor ([3][H][W] fp32 or [H][W][3] uint8)."""
         key = id(view)

@@ -67,6 +67,14 @@ def test_png_and_ply_roundtrip(tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.png").write_bytes(b"not a png")
         IO.read_png(tmp_path / "bad.png")
+    # ready-made scanlines (what the GPU hands over: filter byte 0 + RGB per row) encode to the same picture
+    img = rng.integers(0, 255, (11, 13, 3)).astype(np.uint8)
+    rows = np.zeros((11, 1 + 3 * 13), np.uint8)
+    rows[:, 1:] = img.reshape(11, -1)
+    (tmp_path / "rows.png").write_bytes(IO.encode_png_rows(rows, 13, 11))
+    assert np.array_equal(IO.read_png(tmp_path / "rows.png"), img)
+    with pytest.raises(ValueError):
+        IO.encode_png_rows(rows[:, 1:], 13, 11)
     g = synthetic.make_gaussians(257, 100, 3)
     IO.save_gaussian_ply(tmp_path / "pc" / "point_cloud.ply", g)
     back = IO.load_gaussian_ply(tmp_path / "pc" / "point_cloud.ply")

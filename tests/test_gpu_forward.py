@@ -167,3 +167,13 @@ def test_visible_count_accumulated_by_the_binning_pass():
     torch.cuda.synchronize()
     radius = rast.g2[:, 2].contiguous().view(torch.int32) & 0xFFFFF
     assert int(counter.item()) == int((radius > 0).sum().item()) > 0
+
+
+def test_png_scanlines_match_rgb8():
+    rig, g, seq, cam, dflame, model, rast, mk = _setup(2000, 100, 52)
+    _, face_xf = dflame.face_frames(0, 1)
+    rast.forward(model, face_xf[0], mk(cam, bg=(0.2, 0.4, 0.6)))
+    rgb8 = rast.to_rgb8().cpu().numpy()
+    rows = rast.to_png_rows().cpu().numpy()
+    assert rows.shape == (52, 1 + 3 * 100) and not rows[:, 0].any()
+    assert np.array_equal(rows[:, 1:].reshape(52, 100, 3), rgb8)
