@@ -113,9 +113,11 @@ def main(argv=None):
     rig = load_rig()
     bg = (1.0, 1.0, 1.0) if args.white_background else (0.0, 0.0, 0.0)
     views, size = [], None
-    for fr, trow in zip(split["frames"], split["timestep_of_frame"]):
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as pool:          # PNG decode releases the interpreter lock
+        images = list(pool.map(lambda fr: IO.load_image_rgb(os.path.join(args.source_path, fr["file_path"])), split["frames"]))
+    for fr, trow, img in zip(split["frames"], split["timestep_of_frame"], images):
         cam = IO.camera_from_frame(fr, split["top"])
-        img = IO.load_image_rgb(os.path.join(args.source_path, fr["file_path"]))
         if args.resolution in (1, 2, 4, 8):
             w, h = cam["width"] // args.resolution, cam["height"] // args.resolution
         elif args.resolution > 8:
