@@ -183,6 +183,8 @@ int omfs_bin_sort(const omfs_gaussians* g, const omfs_camera* cam, const omfs_ra
 int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 /* image [3][H][W] fp32 -> rgb8 [H][W][3], clamp to [0,1], round(x*255) */
 int omfs_image_to_rgb8(const float* image, int width, int height, uint8_t* rgb8, void* stream);
+/* [H][W][3] uint8 -> [3][H][W] fp32 (value / 255): training targets stored as 8-bit RGB in HBM */
+int omfs_rgb8_to_image(const uint8_t* rgb8, int width, int height, float* image, void* stream);
 /* the same conversion as PNG scanlines: rows [height][1 + 3*width], byte 0 of every row is the filter type 0 */
 int omfs_image_to_png_rows(const float* image, int width, int height, uint8_t* rows, void* stream);
 

@@ -110,6 +110,7 @@ SIGNATURES = {
     "omfs_composite_fwd": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
     "omfs_image_to_rgb8": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_image_to_png_rows": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
+    "omfs_rgb8_to_image": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_composite_bwd": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), C.POINTER(GradBuffersC), c_void_p]),
     "omfs_project_bwd": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC),
                                    C.POINTER(GradBuffersC), C.POINTER(RegParamsC), c_void_p]),

@@ -706,6 +706,17 @@ __global__ void image_to_rgb8_kernel(const float* __restrict__ image, int width,
   }
 }
 
+// Training targets kept as 8-bit RGB in HBM (a quarter of the fp32 size: thousands of 1080p views stay resident) are
+// expanded to the planar fp32 layout of the loss kernels one view at a time: value / 255, exactly what a host-side
+// conversion gives.
+__global__ void rgb8_to_image_kernel(const uint8_t* __restrict__ rgb8, int width, int height, float* __restrict__ image) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = width * height;
+  if (i >= n) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) image[(size_t)c * n + i] = (float)rgb8[(size_t)i * 3 + c] / 255.0f;
+}
+
 // The same 8-bit conversion laid out as the raw scanlines of a PNG: every row starts with filter byte 0, so the host only
 // has to deflate the buffer (no per-frame reshuffle under the interpreter lock).
 __global__ void image_to_png_rows_kernel(const float* __restrict__ image, int width, int height, uint8_t* __restrict__ rows) {
@@ -790,6 +801,14 @@ extern "C" int omfs_image_to_png_rows(const float* image, int width, int height,
   OMFS_REQUIRE(image && rows && width > 0 && height > 0, "args");
   hipLaunchKernelGGL(image_to_png_rows_kernel, dim3(cdiv(width * height, 256)), dim3(256), 0, (hipStream_t)stream, image,
                      width, height, rows);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_rgb8_to_image(const uint8_t* rgb8, int width, int height, float* image, void* stream) {
+  OMFS_REQUIRE(rgb8 && image && width > 0 && height > 0, "args");
+  hipLaunchKernelGGL(rgb8_to_image_kernel, dim3(cdiv(width * height, 256)), dim3(256), 0, (hipStream_t)stream, rgb8, width,
+                     height, image);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

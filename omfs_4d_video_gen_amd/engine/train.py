@@ -60,6 +60,8 @@ def parse(argv=None):
     p.add_argument("--flame_pose_lr", type=float, default=1e-5)
     p.add_argument("--flame_trans_lr", type=float, default=1e-6)
     p.add_argument("--start_checkpoint", type=str, default=None)
+    p.add_argument("--target_storage", choices=("auto", "f32", "u8"), default="auto",
+                   help="how training images are kept in HBM: fp32 planes, 8-bit RGB expanded per step, or by dataset size")
     args, unknown = p.parse_known_args(argv)
     if unknown:
         print(f"[engine] ignoring unknown arguments: {unknown}")
@@ -116,6 +118,9 @@ def main(argv=None):
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=8) as pool:          # PNG decode releases the interpreter lock
         images = list(pool.map(lambda fr: IO.load_image_rgb(os.path.join(args.source_path, fr["file_path"])), split["frames"]))
+    # fp32 targets are 4x the bytes of the images: kept while they fit comfortably beside the model, 8-bit otherwise
+    n_px = sum(int(im.shape[0]) * int(im.shape[1]) for im in images)
+    store_u8 = args.target_storage == "u8" or (args.target_storage == "auto" and n_px * 12 > 64 << 30)
     for fr, trow, img in zip(split["frames"], split["timestep_of_frame"], images):
         cam = IO.camera_from_frame(fr, split["top"])
         if args.resolution in (1, 2, 4, 8):
@@ -133,14 +138,23 @@ def main(argv=None):
             size = (w, h)
         elif size != (w, h):
             raise SystemExit("[engine] all training views must share one resolution")
-        rgb = torch.from_numpy(img.astype(np.float32) / 255.0).permute(2, 0, 1).contiguous()
         mask_rel = fr.get("fg_mask_path")
+        mask = None
         if mask_rel and os.path.exists(os.path.join(args.source_path, mask_rel)):
-            m = IO.read_png(os.path.join(args.source_path, mask_rel))[:, :, 0].astype(np.float32) / 255.0
-            if m.shape != (h, w):
-                m = resize_nearest(m, w, h)
-            mt = torch.from_numpy(m)[None]
-            rgb = rgb * mt + (1.0 - mt) * torch.tensor(bg)[:, None, None]
+            mask = IO.read_png(os.path.join(args.source_path, mask_rel))[:, :, 0].astype(np.float32) / 255.0
+            if mask.shape != (h, w):
+                mask = resize_nearest(mask, w, h)
+        if store_u8:
+            # [H][W][3] bytes in HBM, expanded to fp32 one view at a time by omfs_rgb8_to_image; a soft mask edge is
+            # composited before the 8-bit rounding (at most half a level away from the fp32 composite)
+            if mask is not None:
+                img = np.rint(img.astype(np.float32) * mask[:, :, None] + (1.0 - mask[:, :, None]) * (255.0 * np.asarray(bg, np.float32))).astype(np.uint8)
+            rgb = torch.from_numpy(np.ascontiguousarray(img[:, :, :3]))
+        else:
+            rgb = torch.from_numpy(img.astype(np.float32) / 255.0).permute(2, 0, 1).contiguous()
+            if mask is not None:
+                mt = torch.from_numpy(mask)[None]
+                rgb = rgb * mt + (1.0 - mt) * torch.tensor(bg)[:, None, None]
         views.append(View(cam, int(trow), target=rgb.cuda(), name=os.path.basename(fr["file_path"])))
     n = args.n_gaussians if args.n_gaussians > 0 else 10 * rig.n_faces
     g0 = initial_gaussians(n, rig.n_faces, args.seed)

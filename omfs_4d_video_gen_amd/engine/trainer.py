@@ -112,6 +112,7 @@ class Trainer:
         self._side_stream = torch.cuda.Stream(device=self.device)
         self._events = [(torch.cuda.Event(), torch.cuda.Event()), (torch.cuda.Event(), torch.cuda.Event())]
         self._prefetch = None
+        self._target_f32 = None
         self.flame_ft = None           # FLAME-parameter fine-tuning (engine/flame_finetune.py)
         if finetune_flame:
             from .flame_finetune import FlameFineTuner
@@ -204,7 +205,13 @@ class Trainer:
         L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
         L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
         r.composite(cam); tm.mark("composite_fwd")
-        r.loss_l1_ssim(view.target, self.lambda_dssim); tm.mark("loss")
+        target = view.target
+        if target.dtype == torch.uint8:        # 8-bit [H][W][3] targets (large datasets): expanded per view on the device
+            if self._target_f32 is None:
+                self._target_f32 = torch.empty(3, r.height, r.width, device=self.device)
+            L.check(lib.omfs_rgb8_to_image(L.ptr(target), r.width, r.height, L.ptr(self._target_f32), s), "omfs_rgb8_to_image")
+            target = self._target_f32
+        r.loss_l1_ssim(target, self.lambda_dssim); tm.mark("loss")
         if self.compact_dp and (self.drgb_local is None or self.drgb_local.shape[1] != self.model.n_pad):
             self.drgb_local = torch.zeros(3, self.model.n_pad, device=self.device)
             self.drgb_scratch = torch.zeros(3, self.model.n_pad, device=self.device)

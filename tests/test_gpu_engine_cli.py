@@ -133,7 +133,8 @@ def test_finetune_flame_checkpoint_resume_and_tuned_render(dataset, tmp_path, mo
     assert r1.returncode == 0, r1.stderr[-2000:]
     assert (a / "chkpnt25.pth").exists()
     r2 = subprocess.run([sys.executable, train, *common, "--model_path", str(b), "--iterations", "40",
-                         "--start_checkpoint", str(a / "chkpnt25.pth")], env=env, capture_output=True, text=True)
+                         "--start_checkpoint", str(a / "chkpnt25.pth"), "--target_storage", "u8"],   # 8-bit targets: same values
+                        env=env, capture_output=True, text=True)
     assert r2.returncode == 0, r2.stderr[-2000:]
     assert "resumed from" in r2.stdout and "iteration 40/40" in r2.stdout
     ga = IO.load_gaussian_ply(a / "point_cloud" / "iteration_40" / "point_cloud.ply")

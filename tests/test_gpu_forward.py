@@ -177,3 +177,17 @@ def test_png_scanlines_match_rgb8():
     rows = rast.to_png_rows().cpu().numpy()
     assert rows.shape == (52, 1 + 3 * 100) and not rows[:, 0].any()
     assert np.array_equal(rows[:, 1:].reshape(52, 100, 3), rgb8)
+
+
+def test_rgb8_targets_expand_to_the_host_conversion():
+    """omfs_rgb8_to_image: [H][W][3] bytes -> planar fp32, bit-identical to numpy's uint8 / 255 in fp32."""
+    from omfs_4d_video_gen_amd import _lib as L
+    rng = np.random.default_rng(4)
+    w, h = 131, 77
+    img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    img[0, :256 // 2 + 3, 0] = np.arange(256 // 2 + 3)            # make sure low levels are all present
+    src = torch.from_numpy(img).cuda()
+    out = torch.empty(3, h, w, device="cuda")
+    L.check(L.load().omfs_rgb8_to_image(L.ptr(src), w, h, L.ptr(out), L.stream_ptr()), "omfs_rgb8_to_image")
+    want = (img.astype(np.float32) / 255.0).transpose(2, 0, 1)
+    assert np.array_equal(out.cpu().numpy(), want)
