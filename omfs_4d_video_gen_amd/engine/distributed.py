@@ -11,6 +11,8 @@ render_surgery: frame f belongs to rank f mod W; no collective.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -26,7 +28,7 @@ def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
 def allreduce_sum_(buf: torch.Tensor, group=None, async_op: bool = False):
     """In-place sum over ranks of the gradient SoA (or a contiguous plane range of it).  With async_op the work handle
     is returned (call .wait() before reading buf)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or os.environ.get("OMFS_DP_FORCE") == "1"):
         work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
         if async_op:
             return work

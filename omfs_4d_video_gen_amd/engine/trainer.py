@@ -103,7 +103,10 @@ class Trainer:
         self.densify_stats = None      # [2][n_pad] when adaptive density control is on (engine/densify.py)
         # data-parallel exchange: "compact" (default) = all-reduce of the 14 non-rank-1 planes + all-gather of dL/dcolour,
         # the 45 higher SH planes are rebuilt on every rank (engine/distributed.py); "full" = one all-reduce of all 59
-        self.compact_dp = self.world > 1 and self.world <= 16 and os.environ.get("OMFS_DP_EXCHANGE", "compact") != "full"
+        # OMFS_DP_FORCE=1 takes the exchange path with a single rank too: the RCCL calls and their stream ordering can then
+        # be exercised on a one-GPU box (tests/test_gpu_distributed.py); the result is the plain single-GPU step's
+        self.dp = self.world > 1 or (os.environ.get("OMFS_DP_FORCE") == "1" and process_group is not None)
+        self.compact_dp = self.dp and self.world <= 16 and os.environ.get("OMFS_DP_EXCHANGE", "compact") != "full"
         self._dp_patterns = {}
         self.drgb_local = self.drgb_scratch = self.drgb_all = self.cam_pos_table = None
         if self.compact_dp:
@@ -228,7 +231,7 @@ class Trainer:
         L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
         if ft is not None:
             ft.backward(verts[col], nb, col); tm.mark("flame_bwd")
-        if self.world > 1:
+        if self.dp:
             from .distributed import allgather_into_, allreduce_sum_
             if self.compact_dp:
                 # 14 contiguous planes, asynchronously: the 45 rebuilt SH planes are updated while they are on the links

@@ -106,3 +106,46 @@ def test_two_ranks_match_single_process_gradient_sum(exchange):
     # executions agree to fp32 accumulation noise, not bitwise (the two RANKS are bitwise equal: see above)
     got = tr.model.params.cpu().numpy()
     assert np.allclose(got, p0, rtol=2e-4, atol=2e-6), np.abs(got - p0).max()
+
+
+def _worker_rccl(port, q, exchange):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", OMFS_DP_EXCHANGE=exchange,
+                      OMFS_DP_FORCE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from omfs_4d_video_gen_amd.engine.trainer import Trainer
+    rig, seq, g, views = _scene()
+    tr = Trainer(rig, seq, g, views, W, H, start_sh_degree=3, rank=0, world_size=1, process_group=dist.group.WORLD)
+    assert tr.dp and tr.compact_dp == (exchange == "compact")
+    for _ in range(STEPS):
+        tr.step()
+    torch.cuda.synchronize()
+    tr.rast.check_status()
+    q.put(tr.model.params.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["compact", "full"])
+def test_exchange_path_over_rccl_with_one_rank_equals_the_plain_step(exchange):
+    """The collectives of the data-parallel step issued on the real backend ("nccl" = RCCL; one rank is all a one-GPU
+    box has): asynchronous all-gather under project_bwd, asynchronous all-reduce of the 14 planes under the SH update.
+    With one rank the sums are the rank's own gradients, so the trajectory is the single-GPU one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = ctx.Process(target=_worker_rccl, args=(port, q, exchange))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    from omfs_4d_video_gen_amd.engine.trainer import Trainer
+    rig, seq, g, views = _scene()
+    tr = Trainer(rig, seq, g, views, W, H, start_sh_degree=3)
+    assert not tr.dp
+    for _ in range(STEPS):
+        tr.step()
+    torch.cuda.synchronize()
+    want = tr.model.params.cpu().numpy()
+    assert np.allclose(got, want, rtol=2e-4, atol=2e-6), np.abs(got - want).max()
