@@ -1,0 +1,67 @@
+"""Fixed cost of the data-parallel exchange path on ONE GPU: the bench workload stepped with the exchange forced over a
+one-rank RCCL group (OMFS_DP_FORCE=1), compact and full, against the plain step.  What is measured is everything but the
+link time: the collectives' launches, their stream hand-overs, the rebuilt SH gradients and the split Adam.
+usage (GPU box): python tools/dp_overhead.py [--steps 200]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def run(mode, steps):
+    import torch
+    import torch.distributed as dist
+    from omfs_4d_video_gen_amd.engine import synthetic
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, Trainer, View
+    N, W, H, V = 300000, 1920, 1080, 16
+    srig = synthetic.make_rig(0)
+    rig = FlameRig.from_synthetic(srig)
+    seq = synthetic.make_flame_sequence(V, 0)
+    cams = synthetic.make_camera_arc(W, H, V)
+    tr = Renderer(rig, seq, synthetic.make_gaussians(N, rig.n_faces, 1), W, H)
+    views = []
+    for i, cam in enumerate(cams):
+        v = View(cam, timestep=i % V)
+        v.target = tr.render(v).clone()
+        views.append(v)
+    del tr
+    pg = None
+    if mode != "plain":
+        os.environ["OMFS_DP_FORCE"] = "1"
+        os.environ["OMFS_DP_EXCHANGE"] = mode
+        pg = dist.group.WORLD
+    else:
+        os.environ.pop("OMFS_DP_FORCE", None)
+    t = Trainer(rig, seq, synthetic.make_gaussians(N, rig.n_faces, 0), views, W, H, iterations=30000, start_sh_degree=3,
+                rank=0, world_size=1, process_group=pg)
+    for _ in range(20):
+        t.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t.step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=200)
+    a = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    out = {m: round(run(m, a.steps), 4) for m in ("plain", "compact", "full")}
+    print(json.dumps({"ms_per_step": out, "note": "one-rank RCCL group: exchange path without link time"}))
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
