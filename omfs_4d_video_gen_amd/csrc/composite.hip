@@ -77,6 +77,21 @@ __device__ unsigned long long omfs_dbg[8];   // bwd: visits, visits with a hit, 
 #else
 #define OMFS_DBG_ADD(i, v) do { } while (0)
 #endif
+#ifdef OMFS_DEBUG_TIMELINE
+// per-wave (workgroup for the deep forward) start / end on the 100 MHz real-time counter: tools/wave_timeline.py
+constexpr int OMFS_DBG_TL = 1 << 19;
+__device__ unsigned long long omfs_dbg_tl[3][2][OMFS_DBG_TL];
+struct DbgSpan {
+  int k; uint32_t i; unsigned long long t0;
+  __device__ DbgSpan(int k_, uint32_t i_) : k(k_), i(i_), t0(__builtin_amdgcn_s_memrealtime()) {}
+  __device__ ~DbgSpan() {
+    if (threadIdx.x == 0 && i < (uint32_t)OMFS_DBG_TL) { omfs_dbg_tl[k][0][i] = t0; omfs_dbg_tl[k][1][i] = __builtin_amdgcn_s_memrealtime(); }
+  }
+};
+#define OMFS_DBG_SPAN(k) DbgSpan omfs_dbg_span_(k, blockIdx.x)
+#else
+#define OMFS_DBG_SPAN(k) do { } while (0)
+#endif
 constexpr int WB = 64;   // splats staged per wave and step
 #ifndef OMFS_FWD_SEQ_SEGS
 #define OMFS_FWD_SEQ_SEGS 4
@@ -105,6 +120,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
   __shared__ float4 s0[WB];
   __shared__ float4 s1[WB];
   __shared__ float s2[WB];
+  OMFS_DBG_SPAN(0);
   const uint32_t tile = tile_order[blockIdx.x >> 2];
   const int quad = blockIdx.x & 3, lane = threadIdx.x;
   const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
@@ -273,6 +289,7 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
   __shared__ uint32_t comp_last[DEEP_WAVES][64];
   __shared__ float4 res[64];                  // exactly resolved pixels: (T, C.rgb)
   __shared__ uint32_t res_last[64];           // last contributor | terminated << 31
+  OMFS_DBG_SPAN(1);
   const uint32_t tile = tile_order[blockIdx.x >> 2];
   const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
   if (tend - tbeg <= (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG)) return;
@@ -517,6 +534,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
   __shared__ uint32_t sid[WB];
   __shared__ float red[PEND][8][9];       // [pending slot][8-lane group][value]
   __shared__ uint32_t pend_id[PEND];      // Gaussian id of each pending slot
+  OMFS_DBG_SPAN(2);
   const uint32_t seg = blockIdx.x >> 2;
   if (seg >= order_seg0[n_tiles]) return;
   // launch-order position p with order_seg0[p] <= seg < order_seg0[p+1] (bisection, ~13 L2-resident loads)
@@ -780,6 +798,21 @@ extern "C" int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buff
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
+
+#ifdef OMFS_DEBUG_TIMELINE
+extern "C" int omfs_debug_timeline(int kernel, unsigned long long* out, int n, int reset) {   // out [2][n]
+  OMFS_REQUIRE(kernel >= 0 && kernel < 3 && n > 0 && n <= OMFS_DBG_TL, "args");
+  for (int e = 0; e < 2; ++e)
+    OMFS_CHECK_HIP(hipMemcpyFromSymbol(out + (size_t)e * n, HIP_SYMBOL(omfs_dbg_tl), (size_t)n * 8,
+                                       ((size_t)kernel * 2 + e) * OMFS_DBG_TL * 8));
+  if (reset) {
+    void* p = nullptr;
+    OMFS_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(omfs_dbg_tl)));
+    OMFS_CHECK_HIP(hipMemset(p, 0, sizeof(unsigned long long) * 3 * 2 * OMFS_DBG_TL));
+  }
+  return OMFS_OK;
+}
+#endif
 
 #ifdef OMFS_DEBUG_COUNTERS
 extern "C" int omfs_debug_counters(unsigned long long* out8, int reset) {

@@ -1,0 +1,48 @@
+"""Debug build only (EXTRA_HIPCC_FLAGS=-DOMFS_DEBUG_TIMELINE): when do the waves of the three composite kernels run?
+Per kernel: span of the launch, number of waves that did work, sum of wave durations / (span x 1024 SIMDs) = resident
+working waves per SIMD, duration percentiles, and the number of waves in flight in ten slices of the span.
+usage (GPU box): EXTRA_HIPCC_FLAGS=-DOMFS_DEBUG_TIMELINE bash omfs_4d_video_gen_amd/csrc/build.sh && python tools/wave_timeline.py"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from omfs_4d_video_gen_amd import _lib as L
+from omfs_4d_video_gen_amd.engine import synthetic
+from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+from omfs_4d_video_gen_amd.engine.trainer import Renderer, Trainer, View
+
+W, H, N = 1920, 1080, 300000
+srig = synthetic.make_rig(0); rig = FlameRig.from_synthetic(srig); seq = synthetic.make_flame_sequence(16, 0)
+cams = synthetic.make_camera_arc(W, H, 16)
+tr = Renderer(rig, seq, synthetic.make_gaussians(N, rig.n_faces, 1), W, H); views = []
+for i, c in enumerate(cams):
+    v = View(c, i); v.target = tr.render(v).clone(); views.append(v)
+t = Trainer(rig, seq, synthetic.make_gaussians(N, rig.n_faces, 0), views, W, H, start_sh_degree=3)
+for _ in range(20):
+    t.step()
+torch.cuda.synchronize()
+cd = ctypes.CDLL(os.path.join(os.path.dirname(L.__file__), "libomfs_splat.so"))
+NTL = 1 << 19
+buf = (ctypes.c_ulonglong * (2 * NTL))()
+cd.omfs_debug_timeline(0, buf, NTL, 1)
+t.step()
+torch.cuda.synchronize()
+for k, name, waves_per in ((0, "composite_fwd (one wave per entry)", 1), (1, "composite_fwd_deep (8-wave workgroups)", 8), (2, "composite_bwd", 1)):
+    assert cd.omfs_debug_timeline(k, buf, NTL, 0) == 0
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(2, NTL).astype(np.int64)
+    ok = a[0] > 0
+    t0, t1 = a[0][ok], a[1][ok]
+    if t0.size == 0:
+        print(name, ": nothing recorded"); continue
+    span = (t1.max() - t0.min()) * 10e-3          # us (100 MHz counter)
+    dur = (t1 - t0) * 10e-3
+    busy = dur.sum() * waves_per / (span * 1024)
+    edges = np.linspace(t0.min(), t1.max(), 11)
+    inflight = [int(((t0 < edges[i + 1]) & (t1 > edges[i])).sum()) * waves_per for i in range(10)]
+    print(f"{name}: span {span:.1f} us, {t0.size} recorded, resident working waves/SIMD {busy:.2f}, "
+          f"duration us p50 {np.percentile(dur, 50):.2f} p90 {np.percentile(dur, 90):.2f} p99 {np.percentile(dur, 99):.2f} max {dur.max():.2f}")
+    print("   waves in flight per tenth of the span:", inflight)
