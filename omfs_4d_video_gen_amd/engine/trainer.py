@@ -283,6 +283,8 @@ class Renderer:
         self.bg, self.sh_degree = tuple(bg), sh_degree
         self.timer = StageTimer(False)
         self._cams = {}
+        self.flame_batch = int(flame_batch)
+        self._frames = None            # (first timestep, count, face_xf [count][F][16]) of the last posed batch
 
     def render_png_rows_to_host(self, view: View, n_slots: int = 4):
         """Enqueue one frame and its asynchronous copy to a pinned host buffer as PNG scanlines ([H][1+3W] uint8).
@@ -309,11 +311,19 @@ class Renderer:
             self._cams[key] = cam
         r, tm = self.rast, self.timer
         tm.begin()
-        _, face_xf = self.dflame.face_frames(view.timestep, 1); tm.mark("flame")
+        # a sequence is rendered in order: FLAME is posed for `flame_batch` consecutive timesteps at once (the pass reads
+        # the whole basis whatever the batch), later frames of the batch find their triangle frames ready
+        t = view.timestep
+        fr = self._frames
+        if fr is None or not (fr[0] <= t < fr[0] + fr[1]):
+            nb = max(1, min(self.flame_batch, self.dflame.n_frames - t))
+            fr = self._frames = (t, nb, self.dflame.face_frames(t, nb)[1])
+        fxf = fr[2][t - fr[0]]
+        tm.mark("flame")
         lib = L.load()
         g = r._gauss(self.model)
         s = L.stream_ptr()
-        r.project(self.model, face_xf[0], cam); tm.mark("project")
+        r.project(self.model, fxf, cam); tm.mark("project")
         L.check(lib.omfs_bin_count(g, cam, r.rb, s), "omfs_bin_count"); tm.mark("bin_count")
         L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); tm.mark("bin_scan")
         L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")

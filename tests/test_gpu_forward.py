@@ -191,3 +191,22 @@ def test_rgb8_targets_expand_to_the_host_conversion():
     L.check(L.load().omfs_rgb8_to_image(L.ptr(src), w, h, L.ptr(out), L.stream_ptr()), "omfs_rgb8_to_image")
     want = (img.astype(np.float32) / 255.0).transpose(2, 0, 1)
     assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_renderer_poses_flame_in_batches_with_identical_frames():
+    """Renderer poses `flame_batch` consecutive timesteps per FLAME pass: the frames equal the one-timestep-per-pass ones
+    bit for bit, in sequence order, out of order and at the end of the sequence."""
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, View
+    rig = synthetic.make_rig(0)
+    frig = FlameRig.from_synthetic(rig)
+    seq = synthetic.make_flame_sequence(11, 0)
+    g = synthetic.make_gaussians(3000, rig.faces.shape[0], 0)
+    cam = synthetic.make_camera(96, 64, yaw=0.1)
+    one, many = Renderer(frig, seq, g, 96, 64, flame_batch=1), Renderer(frig, seq, g, 96, 64, flame_batch=4)
+    for t in list(range(11)) + [7, 2, 10, 3, 4, 5]:
+        a = one.render(View(cam, t)).clone()
+        b = many.render(View(cam, t))
+        assert torch.equal(a, b), t
+    torch.cuda.synchronize()
+    many.rast.check_status()
