@@ -283,6 +283,32 @@ int omfs_adam_step(float* params, const float* grads, float* m, float* v, int n,
 int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v, int n, int n_pad,
                           const omfs_adam_params* ap, int plane0, int n_planes, void* stream);
 
+/* ---- adaptive density control (clone / split / prune), SURVEY.md Appendix A item 10: what the absent upstream train.py does
+ * between iterations (call site 02_Visual_Engine/train_ghost.py:227-271).  Three steps, the caller allocates:
+ *   classify : cls[i] = 1 (kept) | 2 (cloned) | 4 (split) from the accumulated statistics (stats [2][n_pad]: sum of the
+ *              view-space positional gradient norms, number of views that saw the Gaussian), the largest world-space axis
+ *              exp(max log-scale) * triangle scale (face_xf [F][16], word 12) and the opacity:
+ *                hot = mean gradient >= grad_threshold;  clone = hot && size <= size_threshold;  split = hot && !clone;
+ *                pruned = split || sigmoid(opacity) < min_opacity || (prune_size > 0 && size > prune_size);
+ *              block_counts [3][ceil(n/256)] receives the per-256 counts of the three bits; grad_out [n] (optional) the
+ *              mean gradients
+ *   scan     : block_counts -> exclusive offsets in place, totals[3] = number kept / cloned / split
+ *   compact  : writes [kept | clones | first children | second children], each group in index order, into params_out
+ *              [59][n_out_pad], binding_out, m_out, v_out (all zero-filled by the caller, n_out = totals[0] + totals[1]
+ *              + 2 totals[2] <= n_out_pad); kept Gaussians carry their Adam moments, new ones start from zero; the children
+ *              of a split are two samples of the Gaussian in its local frame (counter-based generator keyed by seed_lo,
+ *              seed_hi, index, child, axis -- identical on every rank) with log-scales lowered by log 1.6          */
+typedef struct {
+  float grad_threshold, size_threshold, min_opacity, prune_size;
+  uint32_t seed_lo, seed_hi;
+} omfs_densify_params;
+int omfs_densify_classify(const omfs_gaussians* g, const float* face_xf, const float* stats, const omfs_densify_params* p,
+                          uint8_t* cls, float* grad_out, uint32_t* block_counts, void* stream);
+int omfs_densify_scan(uint32_t* block_counts, int n, uint32_t* totals, void* stream);
+int omfs_densify_compact(const omfs_gaussians* g, const float* adam_m, const float* adam_v, const uint8_t* cls,
+                         const uint32_t* block_offsets, const uint32_t* totals, const omfs_densify_params* p, int n_out_pad,
+                         float* params_out, int32_t* binding_out, float* m_out, float* v_out, void* stream);
+
 /* #Gaussians with radius>0 of the last projected view -> count_out[0] (device) */
 int omfs_count_visible(const omfs_raster_buffers* rb, int n, uint32_t* count_out, void* stream);
 

@@ -80,6 +80,11 @@ class AdamParamsC(C.Structure):
                 ("step", C.c_int), ("grad_scale", C.c_float)]
 
 
+class DensifyParamsC(C.Structure):
+    _fields_ = [("grad_threshold", C.c_float), ("size_threshold", C.c_float), ("min_opacity", C.c_float),
+                ("prune_size", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header
 SIGNATURES = {
     "omfs_abi_version": (C.c_int, []),
@@ -119,6 +124,11 @@ SIGNATURES = {
     "omfs_adam_step_planes": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), C.c_int, C.c_int,
                                         c_void_p]),
     "omfs_count_visible": (C.c_int, [C.POINTER(RasterBuffersC), C.c_int, c_void_p, c_void_p]),
+    "omfs_densify_classify": (C.c_int, [C.POINTER(GaussiansC), c_void_p, c_void_p, C.POINTER(DensifyParamsC), c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+    "omfs_densify_scan": (C.c_int, [c_void_p, C.c_int, c_void_p, c_void_p]),
+    "omfs_densify_compact": (C.c_int, [C.POINTER(GaussiansC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       C.POINTER(DensifyParamsC), C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -7,7 +7,7 @@ out="$here/../libomfs_splat.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
 objs=()
-for src in flame project binning composite project_bwd loss_adam simple_flame; do
+for src in flame project binning composite project_bwd loss_adam simple_flame densify; do
   "$HIPCC" $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$here/$src.hip" -o "$here/$src.o" &
   objs+=("$here/$src.o")
 done

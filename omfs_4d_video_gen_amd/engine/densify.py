@@ -10,10 +10,11 @@ Every `interval` iterations between `from_iter` and `until_iter`:
   * children inherit the parent's triangle (`binding`).
 Every `opacity_reset_interval` iterations opacities are clamped to 0.01 and their Adam moments cleared.
 
-This runs a handful of times per training run, so it is written with torch tensor ops on the SoA
-(stream compaction = boolean indexing); the per-iteration cost is the two extra words per Gaussian that
-`project_bwd` accumulates.  Data parallel: the statistics are all-reduced and the split samples come from
-a generator seeded with (seed, iteration), so every rank takes identical decisions and N stays equal.
+The device work is three HIP launches behind the C ABI (`omfs_densify_classify`, `_scan`, `_compact`: classification,
+offsets, stream compaction of parameters / parent triangles / Adam moments and the split samples); this module decides
+when to run them, sizes the new buffers and installs them.  The per-iteration cost is the two extra words per Gaussian
+that `project_bwd` accumulates.  Data parallel: the statistics are all-reduced and the split samples come from a
+counter-based generator keyed by (seed, iteration, index), so every rank takes identical decisions and N stays equal.
 """
 from __future__ import annotations
 
@@ -22,19 +23,12 @@ import math
 import numpy as np
 import torch
 
-from .gaussians import NPLANES, P_OPACITY, P_ROT, P_SCALE, P_XYZ
+from .. import _lib as L
+from .gaussians import NPLANES, P_OPACITY, P_ROT
 
 
 def _pad(n: int) -> int:
     return (n + 255) // 256 * 256
-
-
-def _quat_to_rotmat(q: torch.Tensor) -> torch.Tensor:
-    q = q / q.norm(dim=0, keepdim=True)
-    r, x, y, z = q[0], q[1], q[2], q[3]
-    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
 
 
 class DensityController:
@@ -66,74 +60,60 @@ class DensityController:
 
     def densify_and_prune(self, iteration: int, size_prune: bool = False) -> dict:
         t, m = self.t, self.t.model
-        n = m.n
+        n, dev = m.n, m.params.device
         stats = t.densify_stats
         if t.world > 1:
             from .distributed import allreduce_sum_
             allreduce_sum_(stats, t.pg)
-        grads = stats[0, :n] / stats[1, :n].clamp(min=1.0)
-        p = m.params[:, :n]
-        face_scale = t.dflame.face_frames(0, 1)[1][0, :, 12]                     # world size of each triangle
-        world_max = torch.exp(p[P_SCALE:P_SCALE + 3]).amax(0) * face_scale[m.binding.long()]
-        hot = grads >= self.grad_threshold
-        small = world_max <= self.percent_dense * self.extent
+        lib, s = L.load(), L.stream_ptr()
+        face_xf = t.dflame.face_frames(0, 1)[1][0]                    # word 12 of a record: world size of the triangle
+        g = L.GaussiansC(n, m.n_pad, L.ptr(m.params), L.ptr(m.binding))
+        n_blocks = (n + 255) // 256
+        cls = torch.empty(n, dtype=torch.uint8, device=dev)
+        grads = torch.empty(n, device=dev)
+        counts = torch.empty(3, n_blocks, dtype=torch.int32, device=dev)
+        totals = torch.empty(3, dtype=torch.int32, device=dev)
+        dp = L.DensifyParamsC(self.grad_threshold, self.percent_dense * self.extent, self.min_opacity,
+                              0.1 * self.extent if size_prune else 0.0, int(iteration) & 0xFFFFFFFF, int(self.seed) & 0xFFFFFFFF)
+
+        def classify():
+            L.check(lib.omfs_densify_classify(g, L.ptr(face_xf), L.ptr(stats), dp, L.ptr(cls), L.ptr(grads), L.ptr(counts), s),
+                    "omfs_densify_classify")
+            L.check(lib.omfs_densify_scan(L.ptr(counts), n, L.ptr(totals), s), "omfs_densify_scan")
+            return [int(x) for x in totals.tolist()]                  # host sync: the new buffers are sized from it
+
+        n_keep, n_clone, n_split = classify()
         room = max(0, self.max_gaussians - n)
-        clone = hot & small
-        split = hot & ~small
-        # respect the capacity: keep the strongest gradients
-        want = int(clone.sum()) + int(split.sum())
-        if want > room:
-            order = torch.argsort(torch.where(hot, grads, torch.zeros_like(grads)), descending=True)[:room]
-            keep = torch.zeros_like(hot)
-            keep[order] = True
-            clone &= keep
-            split &= keep
-        gen = torch.Generator(device="cpu").manual_seed(self.seed * 1_000_003 + iteration)
-        ns = int(split.sum())
-        sp = p[:, split]
-        stds = torch.exp(sp[P_SCALE:P_SCALE + 3])                                # local (triangle-relative) scales
-        noise = torch.randn(2, 3, ns, generator=gen).to(p.device) * stds.unsqueeze(0)
-        R = _quat_to_rotmat(sp[P_ROT:P_ROT + 4])                                   # (ns,3,3)
-        children = []
-        for k in range(2):
-            c = sp.clone()
-            c[P_XYZ:P_XYZ + 3] = sp[P_XYZ:P_XYZ + 3] + torch.einsum("nij,jn->in", R, noise[k])
-            c[P_SCALE:P_SCALE + 3] = torch.log(stds / 1.6)
-            children.append(c)
-        opacity = torch.sigmoid(p[P_OPACITY])
-        prune = split | (opacity < self.min_opacity)
-        if size_prune:
-            prune |= world_max > 0.1 * self.extent
-        keep_mask = ~prune
-        new_p = torch.cat([p[:, keep_mask], p[:, clone]] + children, 1)
-        sb = m.binding[split]
-        new_b = torch.cat([m.binding[keep_mask], m.binding[clone], sb, sb])
-        zeros = lambda k: torch.zeros(NPLANES, k, device=p.device)
-        new_m = torch.cat([t.opt.m[:, :n][:, keep_mask], zeros(int(clone.sum()) + 2 * ns)], 1)
-        new_v = torch.cat([t.opt.v[:, :n][:, keep_mask], zeros(int(clone.sum()) + 2 * ns)], 1)
-        info = {"iteration": iteration, "before": n, "cloned": int(clone.sum()), "split": ns,
-                "pruned": int(prune.sum()) - ns, "after": int(new_p.shape[1])}
-        self._install(new_p, new_b, new_m, new_v)
+        if n_clone + n_split > room:
+            # respect the capacity: only the `room` strongest gradients densify -- the threshold is raised to just above
+            # the (room+1)-th largest mean gradient and the classification repeated
+            top = torch.topk(grads, room + 1).values
+            dp.grad_threshold = float(np.nextafter(np.float32(top[-1].item()), np.float32(np.inf)))
+            n_keep, n_clone, n_split = classify()
+        n_out = n_keep + n_clone + 2 * n_split
+        if n_out > t.rast.n_capacity:
+            raise RuntimeError(f"{n_out} Gaussians exceed the rasteriser capacity {t.rast.n_capacity}")
+        if n_out == 0:
+            raise RuntimeError("densification pruned every Gaussian")
+        n_pad = _pad(n_out)
+        new_p = torch.zeros(NPLANES, n_pad, device=dev)
+        new_m, new_v = torch.zeros_like(new_p), torch.zeros_like(new_p)
+        new_b = torch.zeros(n_out, dtype=torch.int32, device=dev)
+        L.check(lib.omfs_densify_compact(g, L.ptr(t.opt.m), L.ptr(t.opt.v), L.ptr(cls), L.ptr(counts), L.ptr(totals), dp, n_pad,
+                                         L.ptr(new_p), L.ptr(new_b), L.ptr(new_m), L.ptr(new_v), s), "omfs_densify_compact")
+        new_p[P_ROT, n_out:] = 1.0                                    # keep padded quaternions normalisable
+        info = {"iteration": iteration, "before": n, "cloned": n_clone, "split": n_split,
+                "pruned": n - n_keep - n_split, "after": n_out}
+        self._install(new_p, new_b, new_m, new_v, n_out)
         self.log.append(info)
         return info
 
-    def _install(self, params, binding, adam_m, adam_v) -> None:
+    def _install(self, params, binding, adam_m, adam_v, n: int) -> None:
+        """Swap in the compacted buffers ([59][n_pad] / [n]) and everything sized by them."""
         t, m = self.t, self.t.model
-        n = int(params.shape[1])
-        if n > t.rast.n_capacity:
-            raise RuntimeError(f"{n} Gaussians exceed the rasteriser capacity {t.rast.n_capacity}")
-        if n == 0:
-            raise RuntimeError("densification pruned every Gaussian")
-        n_pad = _pad(n)
-
-        def padded(x, fill_rot=False):
-            out = torch.zeros(NPLANES, n_pad, device=x.device)
-            out[:, :n] = x
-            if fill_rot:
-                out[P_ROT, n:] = 1.0
-            return out
-        m.params, m.binding, m.n, m.n_pad = padded(params, True), binding.to(torch.int32).contiguous(), n, n_pad
-        t.opt.m, t.opt.v = padded(adam_m), padded(adam_v)
+        n_pad = int(params.shape[1])
+        m.params, m.binding, m.n, m.n_pad = params, binding, n, n_pad
+        t.opt.m, t.opt.v = adam_m, adam_v
         t.grads = torch.zeros(NPLANES, n_pad, device=params.device)
         t.densify_stats = torch.zeros(2, n_pad, device=params.device)
         # stale projections beyond the new count must not look visible

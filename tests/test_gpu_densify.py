@@ -65,3 +65,70 @@ def test_densification_is_deterministic_across_replicas():
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
     # scales / rotations of the children depend only on the parents' (already differing by atomics noise) values
     assert np.allclose(outs[0][2], outs[1][2], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("size_prune", [False, True])
+def test_classify_scan_compact_match_the_numpy_restatement(size_prune):
+    """The three HIP entries against oracle/densify_ref.py on the same seeded inputs: classification bits (away from the
+    thresholds), output order, parent triangles and Adam moments bit-exact; the split samples to 1e-5."""
+    from omfs_4d_video_gen_amd import _lib as L
+    from omfs_4d_video_gen_amd.engine.gaussians import GaussianModel
+    from oracle import densify_ref as R
+    rng = np.random.default_rng(9)
+    rig = synthetic.make_rig(0)
+    F = rig.faces.shape[0]
+    n = 7003
+    model = GaussianModel(synthetic.make_gaussians(n, F, 3))
+    n_pad = model.n_pad
+    face_xf = torch.zeros(F, 16)
+    face_xf[:, 12] = torch.from_numpy(rng.uniform(0.002, 0.02, F).astype(np.float32))
+    face_xf = face_xf.cuda()
+    stats = np.zeros((2, n_pad), np.float32)
+    stats[0, :n] = rng.uniform(0, 8e-4, n) * rng.integers(0, 5, n)
+    stats[1, :n] = rng.integers(0, 5, n)
+    stats_d = torch.from_numpy(stats).cuda()
+    adam_m = torch.from_numpy(rng.normal(size=(59, n_pad)).astype(np.float32)).cuda()
+    adam_v = torch.from_numpy(rng.uniform(size=(59, n_pad)).astype(np.float32)).cuda()
+    model.params[10, :n] = torch.from_numpy(rng.uniform(-7, 4, n).astype(np.float32)).cuda()     # some nearly transparent
+    size_thr, prune_size = 0.004, (0.012 if size_prune else 0.0)
+    dp = L.DensifyParamsC(2e-4, size_thr, 0.005, prune_size, 1234, 77)
+    lib, s = L.load(), L.stream_ptr()
+    g = L.GaussiansC(n, n_pad, L.ptr(model.params), L.ptr(model.binding))
+    nb = (n + 255) // 256
+    cls = torch.empty(n, dtype=torch.uint8, device="cuda")
+    grads = torch.empty(n, device="cuda")
+    counts = torch.empty(3, nb, dtype=torch.int32, device="cuda")
+    totals = torch.empty(3, dtype=torch.int32, device="cuda")
+    L.check(lib.omfs_densify_classify(g, L.ptr(face_xf), L.ptr(stats_d), dp, L.ptr(cls), L.ptr(grads), L.ptr(counts), s), "classify")
+    L.check(lib.omfs_densify_scan(L.ptr(counts), n, L.ptr(totals), s), "scan")
+    p_h, b_h = model.params.cpu().numpy()[:, :n], model.binding.cpu().numpy()
+    want_cls, margin = R.classify(p_h, b_h, face_xf[:, 12].cpu().numpy(), stats[:, :n], 2e-4, size_thr, 0.005, prune_size)
+    got_cls = cls.cpu().numpy()
+    clear = margin > 1e-5
+    assert clear.mean() > 0.99 and np.array_equal(got_cls[clear], want_cls[clear])
+    assert np.array_equal(grads.cpu().numpy(), stats[0, :n] / np.maximum(stats[1, :n], 1.0))
+    tk, tc, ts = [int(x) for x in totals.tolist()]
+    assert (tk, tc, ts) == (int((got_cls & 1).astype(bool).sum()), int((got_cls & 2).astype(bool).sum()), int((got_cls & 4).astype(bool).sum()))
+    assert min(tk, tc, ts) > 100 and tk < n                                  # every class is exercised
+    n_out = tk + tc + 2 * ts
+    n_out_pad = (n_out + 255) // 256 * 256
+    new_p = torch.zeros(59, n_out_pad, device="cuda")
+    new_m, new_v = torch.zeros_like(new_p), torch.zeros_like(new_p)
+    new_b = torch.full((n_out,), -1, dtype=torch.int32, device="cuda")
+    L.check(lib.omfs_densify_compact(g, L.ptr(adam_m), L.ptr(adam_v), L.ptr(cls), L.ptr(counts), L.ptr(totals), dp, n_out_pad,
+                                     L.ptr(new_p), L.ptr(new_b), L.ptr(new_m), L.ptr(new_v), s), "compact")
+    torch.cuda.synchronize()
+    wp, wb, wm, wv = R.compact(p_h, b_h, adam_m.cpu().numpy()[:, :n], adam_v.cpu().numpy()[:, :n], got_cls, 1234, 77)
+    assert wp.shape[1] == n_out
+    gp = new_p.cpu().numpy()
+    assert np.array_equal(new_b.cpu().numpy(), wb)
+    assert np.array_equal(new_m.cpu().numpy()[:, :n_out], wm) and np.array_equal(new_v.cpu().numpy()[:, :n_out], wv)
+    assert np.array_equal(gp[:, :tk + tc], wp[:, :tk + tc])                     # kept and cloned: copies
+    assert not gp[:, n_out:].any()
+    ch_g, ch_w = gp[:, tk + tc:n_out], wp[:, tk + tc:]
+    assert np.array_equal(ch_g[6:], ch_w[6:])                                    # rotation, opacity, SH: the parent's
+    assert np.allclose(ch_g[3:6], ch_w[3:6], atol=1e-6)                          # log-scale - log 1.6
+    assert np.allclose(ch_g[0:3], ch_w[0:3], atol=1e-5, rtol=1e-5)              # sampled positions
+    # the two children of one parent differ, and the samples have the parent's spread
+    d = (ch_g[0:3, :ts] - ch_g[0:3, ts:])
+    assert (np.abs(d).sum(0) > 0).all()

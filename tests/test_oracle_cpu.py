@@ -73,3 +73,29 @@ def test_tile_culling_does_not_change_the_image(rig_small):
         assert len(a["ids"]) < 0.9 * len(b["ids"]), (len(a["ids"]), len(b["ids"]))
         assert np.array_equal(a["image"].view(np.uint32), b["image"].view(np.uint32))
         assert np.array_equal(a["final_T"].view(np.uint32), b["final_T"].view(np.uint32))
+
+
+def test_densify_reference_generator_and_layout():
+    """oracle/densify_ref.py: the counter-based generator is deterministic, keyed, and standard normal; compact() lays the
+    output out as [kept | clones | first children | second children] with fresh moments for everything new."""
+    from oracle import densify_ref as R
+    assert int(R.mix32(np.uint32(0))) == 0 and len({int(x) for x in R.mix32(np.arange(1, 1000, dtype=np.uint32))}) == 999   # a bijection
+    ids = np.arange(200000)
+    a, b = R.normal_samples(5, 9, ids, 0), R.normal_samples(5, 9, ids, 0)
+    assert np.array_equal(a, b)
+    assert not np.array_equal(a, R.normal_samples(5, 9, ids, 1)) and not np.array_equal(a, R.normal_samples(6, 9, ids, 0))
+    assert abs(float(a.mean())) < 0.01 and abs(float(a.std()) - 1.0) < 0.01 and np.isfinite(a).all()
+    rng = np.random.default_rng(0)
+    n = 50
+    params = rng.normal(size=(59, n)).astype(np.float32)
+    binding = rng.integers(0, 7, n).astype(np.int32)
+    m, v = rng.normal(size=(59, n)).astype(np.float32), rng.uniform(size=(59, n)).astype(np.float32)
+    cls = np.array([1, 3, 4, 0, 2] * 10, np.uint8)
+    p2, b2, m2, v2 = R.compact(params, binding, m, v, cls, 1, 2)
+    keep, clone, split = (cls & 1) > 0, (cls & 2) > 0, (cls & 4) > 0
+    nk, nc, ns = int(keep.sum()), int(clone.sum()), int(split.sum())
+    assert p2.shape == (59, nk + nc + 2 * ns) and b2.shape == (nk + nc + 2 * ns,)
+    assert np.array_equal(p2[:, :nk], params[:, keep]) and np.array_equal(p2[:, nk:nk + nc], params[:, clone])
+    assert np.array_equal(m2[:, :nk], m[:, keep]) and not m2[:, nk:].any() and not v2[:, nk:].any()
+    assert np.array_equal(b2[nk + nc:nk + nc + ns], binding[split]) and np.array_equal(b2[nk + nc + ns:], binding[split])
+    assert np.allclose(p2[3:6, nk + nc:nk + nc + ns], params[3:6, split] - np.log(1.6), atol=1e-6)
