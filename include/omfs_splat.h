@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMFS_ABI_VERSION 3
+#define OMFS_ABI_VERSION 4
 #define OMFS_TILE 16
 #define OMFS_SEG 128     /* list entries per backward segment                                          */
 #define OMFS_NPLANES 59

@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see module d
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 RB_FORWARD_ONLY = 1
 NPLANES = 59
 TILE = 16
