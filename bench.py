@@ -360,7 +360,7 @@ def main():
                 d_cpu = time.perf_counter() - t6
             out["aux"]["flame_fit"] = {"frames": Tf, "hip_iters_per_sec": round(100 / d_gpu, 1), "cpu_port_iters_per_sec": round(5 / d_cpu, 2),
                                        "note": "fit_flame_to_landmarks end to end (setup included) on 300 frames x 68 landmarks; "
-                                               "HIP SimpleFLAME fwd/bwd vs the PyTorch-CPU port of the reference loop"}
+                                               "one omfs_flame_fit_step call per iteration (all HIP, no autograd) vs the PyTorch-CPU port of the reference loop"}
             log("flame fit aux done")
 
     # ---- CPU baseline (rank 0, single GPU run only): the PyTorch-CPU oracle on a bounded sample

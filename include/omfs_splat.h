@@ -109,6 +109,26 @@ int omfs_simpleflame_bwd(const omfs_simpleflame* m, const float* rotation, const
                          const float* dlandmarks, int n_frames, float* g_scratch, float* dshape, float* dexpr,
                          float* drotation, float* djaw, float* dtranslation, void* stream);
 
+/* One iteration of fit_flame_to_landmarks (flame_fitter.py:377-413) entirely on the device, no autograd: landmarks of all
+ * frames (shared shape), pseudo-perspective x/(-z+1e-8) against the 2-D targets with the masked MSE of :390-392, the L2
+ * regularisers (:395-397) and the temporal smoothness terms (:400-404) in closed form, then torch.optim.Adam semantics on the
+ * five tensors (order everywhere: shape, expr, rotation, jaw, translation).  loss_out receives the loss BEFORE the update.
+ * scratch: omfs_flame_fit_scratch_floats(m, n_frames) floats.                                                        */
+typedef struct omfs_flame_fit {
+  int n_frames, n_use;       /* frames; landmarks that enter the loss (min(68, n_landmarks))                          */
+  const float* target;       /* [n_frames][n_use][2] in [-1,1]                                                        */
+  const float* valid;        /* [n_frames] 1 = frame has landmarks                                                    */
+  float inv_denom;           /* 1 / (valid frames * n_use)                                                            */
+  float lr[5], beta1, beta2, eps;
+  int step;                  /* 1-based iteration (bias correction)                                                   */
+  float *shape, *expr, *rotation, *jaw, *translation;   /* [n_shape], [T][n_expr], [T][3] x3: updated in place        */
+  float *m[5], *v[5];        /* Adam moments, same shapes                                                             */
+  float* scratch;
+  float* loss_out;           /* [1]                                                                                   */
+} omfs_flame_fit;
+size_t omfs_flame_fit_scratch_floats(const omfs_simpleflame* m, int n_frames);
+int omfs_flame_fit_step(const omfs_simpleflame* m, const omfs_flame_fit* f, void* stream);
+
 /* ------------------------------------------------------------------ rasteriser */
 typedef struct omfs_camera {
   float view[12];   /* world->view, rows of [R|t] (3x4 row-major)                               */

@@ -80,6 +80,13 @@ class AdamParamsC(C.Structure):
                 ("step", C.c_int), ("grad_scale", C.c_float)]
 
 
+class FlameFitC(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("n_use", C.c_int), ("target", c_void_p), ("valid", c_void_p), ("inv_denom", C.c_float),
+                ("lr", C.c_float * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int),
+                ("shape", c_void_p), ("expr", c_void_p), ("rotation", c_void_p), ("jaw", c_void_p), ("translation", c_void_p),
+                ("m", c_void_p * 5), ("v", c_void_p * 5), ("scratch", c_void_p), ("loss_out", c_void_p)]
+
+
 class DensifyParamsC(C.Structure):
     _fields_ = [("grad_threshold", C.c_float), ("size_threshold", C.c_float), ("min_opacity", C.c_float),
                 ("prune_size", C.c_float), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
@@ -124,6 +131,8 @@ SIGNATURES = {
     "omfs_adam_step_planes": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), C.c_int, C.c_int,
                                         c_void_p]),
     "omfs_count_visible": (C.c_int, [C.POINTER(RasterBuffersC), C.c_int, c_void_p, c_void_p]),
+    "omfs_flame_fit_scratch_floats": (C.c_size_t, [C.POINTER(SimpleFlameC), C.c_int]),
+    "omfs_flame_fit_step": (C.c_int, [C.POINTER(SimpleFlameC), C.POINTER(FlameFitC), c_void_p]),
     "omfs_densify_classify": (C.c_int, [C.POINTER(GaussiansC), c_void_p, c_void_p, C.POINTER(DensifyParamsC), c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
     "omfs_densify_scan": (C.c_int, [c_void_p, C.c_int, c_void_p, c_void_p]),

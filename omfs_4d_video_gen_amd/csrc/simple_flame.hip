@@ -120,6 +120,97 @@ __global__ void simpleflame_bwd_coef_kernel(int B, int L, int K, int n_shape, co
   else dexpr[(size_t)b * (K - n_shape) + (k - n_shape)] = acc;
 }
 
+
+// ---- the fit loop of fit_flame_to_landmarks (flame_fitter.py:377-413) without autograd: loss, its gradient and the
+// regularisers in closed form.
+__global__ void fit_broadcast_shape_kernel(int B, int S, const float* __restrict__ shape, float* __restrict__ shape_T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * S) shape_T[i] = shape[i % S];
+}
+
+// pseudo-perspective x/(-z+1e-8), y/(-z+1e-8) against the 2-D targets (:385-392): one thread per (frame, landmark);
+// landmarks beyond n_use get a zero gradient.  loss_out += sum w (proj - target)^2 / denom.
+__global__ void fit_loss_kernel(int B, int L, int n_use, const float* __restrict__ l3, const float* __restrict__ target,
+                                const float* __restrict__ valid, float inv_denom, float* __restrict__ dl3,
+                                float* __restrict__ loss_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float term = 0.f;
+  if (i < B * L) {
+    const int b = i / L, l = i - b * L;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (l < n_use) {
+      const float x = l3[(size_t)i * 3], y = l3[(size_t)i * 3 + 1], z = l3[(size_t)i * 3 + 2];
+      const float depth = -z + 1e-8f, w = valid[b];
+      const float rx = x / depth - target[((size_t)b * n_use + l) * 2], ry = y / depth - target[((size_t)b * n_use + l) * 2 + 1];
+      term = w * (rx * rx + ry * ry) * inv_denom;
+      const float c = 2.f * w * inv_denom / depth;
+      gx = c * rx; gy = c * ry;
+      gz = c * (rx * x + ry * y) / depth;
+    }
+    dl3[(size_t)i * 3] = gx; dl3[(size_t)i * 3 + 1] = gy; dl3[(size_t)i * 3 + 2] = gz;
+  }
+  term = wave_sum_to_lane63(term);
+  if ((threadIdx.x & 63) == 63 && term != 0.f) atomicAdd(loss_out, term);
+}
+
+// Sums the per-frame shape gradients, adds the L2 regularisers (1e-3 mean shape^2, 1e-4 mean expr^2, 1e-3 mean jaw^2,
+// :395-397) and the temporal smoothness terms (1e-3 mean (x[t+1]-x[t])^2 on expr / jaw / rotation / translation,
+// :400-404) to the gradients in place, and their values to loss_out.  One thread per parameter element:
+// [0,S) shape, then expr [B][E], rotation, jaw, translation [B][3].
+__global__ void fit_finish_grads_kernel(int B, int S, int E, const float* __restrict__ shape, const float* __restrict__ expr,
+                                        const float* __restrict__ rot, const float* __restrict__ jaw,
+                                        const float* __restrict__ trans, const float* __restrict__ dshape_T,
+                                        float* __restrict__ dshape, float* __restrict__ dexpr, float* __restrict__ drot,
+                                        float* __restrict__ djaw, float* __restrict__ dtrans, float* __restrict__ loss_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_expr = B * E, n3 = B * 3;
+  float term = 0.f;
+  auto smooth = [&](const float* x, int D, int j, float& g) {     // element j of x [B][D]
+    if (B < 2) return;
+    const int t = j / D;
+    const float c = 1e-3f / (float)((B - 1) * D);
+    float d = 0.f;
+    if (t > 0) d += x[j] - x[j - D];
+    if (t < B - 1) { const float f = x[j + D] - x[j]; d -= f; term += c * f * f; }
+    g += 2.f * c * d;
+  };
+  if (i < S) {
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dshape_T[(size_t)b * S + i];
+    const float v = shape[i];
+    dshape[i] = a + 2e-3f * v / (float)S;
+    term += 1e-3f * v * v / (float)S;
+  } else if (i < S + n_expr) {
+    const int j = i - S;
+    float g = dexpr[j];
+    const float v = expr[j];
+    g += 2e-4f * v / (float)n_expr;
+    term += 1e-4f * v * v / (float)n_expr;
+    smooth(expr, E, j, g);
+    dexpr[j] = g;
+  } else if (i < S + n_expr + n3) {
+    const int j = i - S - n_expr;
+    float g = drot[j];
+    smooth(rot, 3, j, g);
+    drot[j] = g;
+  } else if (i < S + n_expr + 2 * n3) {
+    const int j = i - S - n_expr - n3;
+    float g = djaw[j];
+    const float v = jaw[j];
+    g += 2e-3f * v / (float)n3;
+    term += 1e-3f * v * v / (float)n3;
+    smooth(jaw, 3, j, g);
+    djaw[j] = g;
+  } else if (i < S + n_expr + 3 * n3) {
+    const int j = i - S - n_expr - 2 * n3;
+    float g = dtrans[j];
+    smooth(trans, 3, j, g);
+    dtrans[j] = g;
+  }
+  term = wave_sum_to_lane63(term);
+  if ((threadIdx.x & 63) == 63 && term != 0.f) atomicAdd(loss_out, term);
+}
+
 }  // namespace omfs
 
 using namespace omfs;
@@ -149,5 +240,51 @@ extern "C" int omfs_simpleflame_bwd(const omfs_simpleflame* m, const float* rota
   hipLaunchKernelGGL(simpleflame_bwd_coef_kernel, dim3(cdiv(n_frames * K, 128)), dim3(128), 0, s, n_frames, m->n_landmarks, K,
                      m->n_shape, m->lmk_basis, g_scratch, dshape, dexpr);
   OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" size_t omfs_flame_fit_scratch_floats(const omfs_simpleflame* m, int n_frames) {
+  if (!m || n_frames <= 0) return 0;
+  const size_t B = (size_t)n_frames, L3 = (size_t)m->n_landmarks * 3;
+  return 2 * B * m->n_shape + 4 * B * L3 + B * m->n_expr + 9 * B + m->n_shape;
+}
+
+extern "C" int omfs_flame_fit_step(const omfs_simpleflame* m, const omfs_flame_fit* f, void* stream) {
+  OMFS_REQUIRE(m && f && f->target && f->valid && f->shape && f->expr && f->rotation && f->jaw && f->translation && f->scratch &&
+                   f->loss_out, "null pointer");
+  for (int k = 0; k < 5; ++k) OMFS_REQUIRE(f->m[k] && f->v[k], "Adam moments");
+  const int B = f->n_frames, L = m->n_landmarks, S = m->n_shape, E = m->n_expr;
+  OMFS_REQUIRE(B > 0 && f->n_use > 0 && f->n_use <= L && f->step > 0, "shape");
+  hipStream_t s = (hipStream_t)stream;
+  float* shape_T = f->scratch;
+  float* l3 = shape_T + (size_t)B * S;
+  float* p = l3 + (size_t)B * L * 3;
+  float* dl3 = p + (size_t)B * L * 3;
+  float* g = dl3 + (size_t)B * L * 3;
+  float* dshape_T = g + (size_t)B * L * 3;
+  float* dexpr = dshape_T + (size_t)B * S;
+  float* drot = dexpr + (size_t)B * E;
+  float* djaw = drot + (size_t)B * 3;
+  float* dtrans = djaw + (size_t)B * 3;
+  float* dshape = dtrans + (size_t)B * 3;
+  OMFS_CHECK_HIP(hipMemsetAsync(f->loss_out, 0, sizeof(float), s));
+  hipLaunchKernelGGL(fit_broadcast_shape_kernel, dim3(cdiv(B * S, 256)), dim3(256), 0, s, B, S, f->shape, shape_T);
+  OMFS_CHECK_HIP(hipGetLastError());
+  if (int rc = omfs_simpleflame_fwd(m, shape_T, f->expr, f->rotation, f->jaw, f->translation, B, l3, p, stream)) return rc;
+  hipLaunchKernelGGL(fit_loss_kernel, dim3(cdiv(B * L, 256)), dim3(256), 0, s, B, L, f->n_use, l3, f->target, f->valid, f->inv_denom,
+                     dl3, f->loss_out);
+  OMFS_CHECK_HIP(hipGetLastError());
+  if (int rc = omfs_simpleflame_bwd(m, f->rotation, p, dl3, B, g, dshape_T, dexpr, drot, djaw, dtrans, stream)) return rc;
+  const int n_el = S + B * E + 9 * B;
+  hipLaunchKernelGGL(fit_finish_grads_kernel, dim3(cdiv(n_el, 256)), dim3(256), 0, s, B, S, E, f->shape, f->expr, f->rotation, f->jaw,
+                     f->translation, dshape_T, dshape, dexpr, drot, djaw, dtrans, f->loss_out);
+  OMFS_CHECK_HIP(hipGetLastError());
+  float* params[5] = {f->shape, f->expr, f->rotation, f->jaw, f->translation};
+  const float* grads[5] = {dshape, dexpr, drot, djaw, dtrans};
+  const int count[5] = {S, B * E, B * 3, B * 3, B * 3};
+  for (int k = 0; k < 5; ++k)
+    if (int rc = omfs_adam_flat(params[k], grads[k], f->m[k], f->v[k], count[k], f->lr[k], f->beta1, f->beta2, f->eps, f->step, 1.0f,
+                                stream))
+      return rc;
   return OMFS_OK;
 }

@@ -8,8 +8,9 @@ Same call surface: `MEDIAPIPE_TO_68`, `SimpleFLAME(flame_model_path, n_shape, n_
 `SimpleFLAME.forward` and its gradient run in HIP kernels (`csrc/simple_flame.hip`, C ABI
 `omfs_simpleflame_fwd/bwd`) behind a `torch.autograd.Function`; the barycentric landmark mix is
 folded into a 68-landmark basis on the host, so each iteration touches 68 points, not 5023 vertices.
-The few-hundred-scalar loss, regularisers and Adam update of the fit loop stay torch ops on the
-same device.  There is no CPU path: tensors must live on the GPU.
+The fit loop itself is one C-ABI call per iteration (`omfs_flame_fit_step`: forward, masked MSE of the
+pseudo-perspective projection, closed-form gradients including the regularisers and the temporal smoothness,
+Adam) -- no autograd.  There is no CPU path: tensors must live on the GPU.
 """
 from __future__ import annotations
 
@@ -199,35 +200,39 @@ def fit_flame_to_landmarks(landmarks_2d_list: list, image_size: tuple, flame_mod
     mask_h[valid] = True
     target, vmask = torch.from_numpy(target_h).to(dev), torch.from_numpy(mask_h).to(dev)
 
-    P = torch.nn.Parameter
-    shape = P(torch.zeros(1, n_shape, device=dev))
-    expr = P(torch.zeros(T, n_expr, device=dev))
-    rotation = P(torch.from_numpy(init_rot).to(dev))
-    jaw = P(torch.zeros(T, 3, device=dev))
-    translation = P(torch.from_numpy(trans_h).to(dev))
-    optimizer = torch.optim.Adam([{"params": shape, "lr": lr * 0.1}, {"params": expr, "lr": lr}, {"params": rotation, "lr": lr * 0.3},
-                                  {"params": jaw, "lr": lr}, {"params": translation, "lr": lr * 0.5}])
+    # parameters, Adam moments and the whole iteration live on the device: one C-ABI call per iteration
+    # (omfs_flame_fit_step: forward, loss, closed-form gradients incl. regularisers and smoothness, Adam)
+    shape = torch.zeros(n_shape, device=dev)
+    expr = torch.zeros(T, n_expr, device=dev)
+    rotation = torch.from_numpy(init_rot).to(dev)
+    jaw = torch.zeros(T, 3, device=dev)
+    translation = torch.from_numpy(trans_h).to(dev)
+    tensors = [shape, expr, rotation, jaw, translation]
+    adam_m, adam_v = [torch.zeros_like(t) for t in tensors], [torch.zeros_like(t) for t in tensors]
     n_lmk = min(n_pts, flame.n_lmk)
-    denom = max(int(vmask.sum()) * n_lmk, 1)
-    w_valid = vmask.float()[:, None, None]
-
-    def smooth(x):
-        return ((x[1:] - x[:-1]) ** 2).mean() * 0.001
+    target_use = target[:, :n_lmk].contiguous()
+    valid_f = vmask.float().contiguous()
+    lib = L.load()
+    scratch = torch.empty(int(lib.omfs_flame_fit_scratch_floats(flame._c, T)), device=dev)
+    loss_dev = torch.zeros(1, device=dev)
+    fit = L.FlameFitC()
+    fit.n_frames, fit.n_use = T, n_lmk
+    fit.target, fit.valid = L.ptr(target_use), L.ptr(valid_f)
+    fit.inv_denom = 1.0 / max(int(mask_h.sum()) * n_lmk, 1)
+    fit.lr[:] = [lr * 0.1, lr, lr * 0.3, lr, lr * 0.5]                # group learning rates (reference :356-362)
+    fit.beta1, fit.beta2, fit.eps = 0.9, 0.999, 1e-8                   # torch.optim.Adam defaults
+    fit.shape, fit.expr, fit.rotation, fit.jaw, fit.translation = (L.ptr(t) for t in tensors)
+    for k in range(5):
+        fit.m[k], fit.v[k] = L.ptr(adam_m[k]), L.ptr(adam_v[k])
+    fit.scratch, fit.loss_out = L.ptr(scratch), L.ptr(loss_dev)
 
     print(f"[flame_fitter] Fitting FLAME to {len(valid)} frames …")
+    stream = L.stream_ptr()
     for it in range(n_iters):
-        optimizer.zero_grad()
-        l3 = flame(shape.expand(T, -1), expr, rotation, jaw, translation)[:, :n_lmk]
-        depth = -l3[..., 2] + 1e-8
-        proj = torch.stack([l3[..., 0] / depth, l3[..., 1] / depth], dim=-1)
-        loss = (((proj - target[:, :n_lmk]) ** 2) * w_valid).sum() / denom
-        loss = loss + (shape ** 2).mean() * 0.001 + (expr ** 2).mean() * 0.0001 + (jaw ** 2).mean() * 0.001
-        if T > 1:
-            loss = loss + smooth(expr) + smooth(jaw) + smooth(rotation) + smooth(translation)
-        loss.backward()
-        optimizer.step()
+        fit.step = it + 1
+        L.check(lib.omfs_flame_fit_step(flame._c, fit, stream), "omfs_flame_fit_step")
         if (it + 1) % 50 == 0:
-            print(f"  iter {it + 1}/{n_iters} — loss: {loss.item():.6f}")
+            print(f"  iter {it + 1}/{n_iters} — loss: {loss_dev.item():.6f}")
 
     with torch.no_grad():
         final_rot = rotation.cpu().numpy()
@@ -235,7 +240,7 @@ def fit_flame_to_landmarks(landmarks_2d_list: list, image_size: tuple, flame_mod
         for name, col in (("Pitch", 0), ("Yaw", 1), ("Roll", 2)):
             print(f"  {name + ':':6s} {final_rot[:, col].min():.3f} to {final_rot[:, col].max():.3f}")
         shape_full = np.zeros(300, np.float32)
-        shape_full[:n_shape] = shape[0].cpu().numpy()
+        shape_full[:n_shape] = shape.cpu().numpy()
         expr_full = np.zeros((T, 100), np.float32)
         expr_full[:, :n_expr] = expr.cpu().numpy()
         result = {"shape": shape_full, "expr": expr_full, "rotation": final_rot, "neck_pose": np.zeros((T, 3), np.float32),
