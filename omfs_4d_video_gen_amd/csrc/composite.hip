@@ -81,16 +81,21 @@ __device__ unsigned long long omfs_dbg[8];   // bwd: visits, visits with a hit, 
 // per-wave (workgroup for the deep forward) start / end on the 100 MHz real-time counter: tools/wave_timeline.py
 constexpr int OMFS_DBG_TL = 1 << 19;
 __device__ unsigned long long omfs_dbg_tl[3][2][OMFS_DBG_TL];
+__device__ uint32_t omfs_dbg_work[3][OMFS_DBG_TL];       // splats visited by the wave
 struct DbgSpan {
-  int k; uint32_t i; unsigned long long t0;
-  __device__ DbgSpan(int k_, uint32_t i_) : k(k_), i(i_), t0(__builtin_amdgcn_s_memrealtime()) {}
+  int k; uint32_t i; unsigned long long t0; uint32_t work;
+  __device__ DbgSpan(int k_, uint32_t i_) : k(k_), i(i_), t0(__builtin_amdgcn_s_memrealtime()), work(0) {}
   __device__ ~DbgSpan() {
-    if (threadIdx.x == 0 && i < (uint32_t)OMFS_DBG_TL) { omfs_dbg_tl[k][0][i] = t0; omfs_dbg_tl[k][1][i] = __builtin_amdgcn_s_memrealtime(); }
+    if (threadIdx.x == 0 && i < (uint32_t)OMFS_DBG_TL) {
+      omfs_dbg_tl[k][0][i] = t0; omfs_dbg_tl[k][1][i] = __builtin_amdgcn_s_memrealtime(); omfs_dbg_work[k][i] = work;
+    }
   }
 };
 #define OMFS_DBG_SPAN(k) DbgSpan omfs_dbg_span_(k, blockIdx.x)
+#define OMFS_DBG_WORK() (++omfs_dbg_span_.work)
 #else
 #define OMFS_DBG_SPAN(k) do { } while (0)
+#define OMFS_DBG_WORK() do { } while (0)
 #endif
 constexpr int WB = 64;   // splats staged per wave and step
 #ifndef OMFS_FWD_SEQ_SEGS
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
     float recA2 = s2[jn], recB2 = recA2;
     auto visit = [&](const float4& a, const float4& c, const float& cb, float4& nx0, float4& nx1, float& nx2, bool check) {
       const int j = jn;
+      OMFS_DBG_WORK();
       m &= m - 1ull;
       jn = m ? __builtin_ctzll(m) : 0;
       nx0 = s0[jn]; nx1 = s1[jn]; nx2 = s2[jn];
@@ -651,6 +657,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
     float2 recA2 = s2[jbn], recB2 = recA2;
     auto visit = [&](const float4& an, const float4& cn, const float2& cbn, float4& nx0, float4& nx1, float2& nx2) {
       const int jb = jbn;
+      OMFS_DBG_WORK();
       m &= ~(1ull << jb);
       const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
       float v[9];
@@ -805,6 +812,10 @@ extern "C" int omfs_debug_timeline(int kernel, unsigned long long* out, int n, i
   for (int e = 0; e < 2; ++e)
     OMFS_CHECK_HIP(hipMemcpyFromSymbol(out + (size_t)e * n, HIP_SYMBOL(omfs_dbg_tl), (size_t)n * 8,
                                        ((size_t)kernel * 2 + e) * OMFS_DBG_TL * 8));
+  if (out && n > 0 && reset >= 2) {      // reset == 2: out [n] also receives the work counters after the two time rows
+    OMFS_CHECK_HIP(hipMemcpyFromSymbol(out + (size_t)2 * n, HIP_SYMBOL(omfs_dbg_work), (size_t)n * 4, (size_t)kernel * OMFS_DBG_TL * 4));
+    return OMFS_OK;
+  }
   if (reset) {
     void* p = nullptr;
     OMFS_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(omfs_dbg_tl)));

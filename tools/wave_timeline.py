@@ -27,13 +27,15 @@ for _ in range(20):
 torch.cuda.synchronize()
 cd = ctypes.CDLL(os.path.join(os.path.dirname(L.__file__), "libomfs_splat.so"))
 NTL = 1 << 19
-buf = (ctypes.c_ulonglong * (2 * NTL))()
+buf = (ctypes.c_ulonglong * (3 * NTL))()
 cd.omfs_debug_timeline(0, buf, NTL, 1)
 t.step()
 torch.cuda.synchronize()
 for k, name, waves_per in ((0, "composite_fwd (one wave per entry)", 1), (1, "composite_fwd_deep (8-wave workgroups)", 8), (2, "composite_bwd", 1)):
-    assert cd.omfs_debug_timeline(k, buf, NTL, 0) == 0
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(2, NTL).astype(np.int64)
+    assert cd.omfs_debug_timeline(k, buf, NTL, 2) == 0       # time rows + work counters
+    raw = np.frombuffer(buf, dtype=np.uint64)
+    a = raw[:2 * NTL].reshape(2, NTL).astype(np.int64)
+    work = raw[2 * NTL:2 * NTL + NTL // 2].view(np.uint32)[:NTL].astype(np.int64)
     ok = a[0] > 0
     t0, t1 = a[0][ok], a[1][ok]
     if t0.size == 0:
@@ -46,3 +48,9 @@ for k, name, waves_per in ((0, "composite_fwd (one wave per entry)", 1), (1, "co
     print(f"{name}: span {span:.1f} us, {t0.size} recorded, resident working waves/SIMD {busy:.2f}, "
           f"duration us p50 {np.percentile(dur, 50):.2f} p90 {np.percentile(dur, 90):.2f} p99 {np.percentile(dur, 99):.2f} max {dur.max():.2f}")
     print("   waves in flight per tenth of the span:", inflight)
+    w = work[ok]
+    if w.max() > 0:
+        big = dur > np.percentile(dur, 99)
+        fit = np.polyfit(w[big], dur[big], 1)
+        print(f"   longest 1 %: {int(big.sum())} waves, splats visited p50 {np.percentile(w[big], 50):.0f} max {w[big].max()}, "
+              f"duration = {fit[0] * 1e3:.0f} ns per visited splat + {fit[1]:.1f} us")
