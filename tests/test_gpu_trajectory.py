@@ -1,0 +1,83 @@
+"""GPU: several whole training iterations (FLAME pose -> render -> L1 + D-SSIM + regularisers -> backward -> Adam) of the
+HIP trainer against the same iterations of the PyTorch-CPU oracle (oracle/torch_splat.py, autograd): the loss values
+follow each other and the parameters end in the same place.  Adam's first steps are sign-like (|m|/sqrt(v) = 1), so an
+element whose gradient is at rounding level may step the other way: the comparison is by quantiles, not element-wise."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from omfs_4d_video_gen_amd.engine import synthetic
+
+pytestmark = pytest.mark.gpu
+
+N, W, H, STEPS = 1500, 64, 48, 6
+GROUPS = (("xyz", 0, 3), ("log_scale", 3, 6), ("rot", 6, 10), ("opacity", 10, 11), ("sh", 11, 59))
+
+
+def test_training_trajectory_matches_the_oracle_loop():
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig, pose_rotmats
+    from omfs_4d_video_gen_amd.engine.trainer import Trainer, View, expon_lr
+    from omfs_4d_video_gen_amd.engine.gaussians import unpack_params
+    from oracle import torch_splat as O
+    rig = synthetic.make_rig(0)
+    seq = synthetic.make_flame_sequence(3, 0)
+    g = synthetic.make_gaussians(N, rig.faces.shape[0], 0)
+    cams = [synthetic.make_camera(W, H, yaw=0.25), synthetic.make_camera(W, H, yaw=-0.3)]
+    gen = torch.Generator().manual_seed(2)
+    targets = [torch.rand(3, H, W, generator=gen) for _ in cams]
+    views = [View(c, t, target=targets[i].cuda()) for i, (c, t) in enumerate(zip(cams, (1, 2)))]
+    tr = Trainer(FlameRig.from_synthetic(rig), seq, g, views, W, H, start_sh_degree=3, iterations=30000)
+    losses = []
+    for _ in range(STEPS):
+        tr.step()
+        losses.append(tr.loss_value())
+    got = unpack_params(tr.model.params[:, :N].cpu().numpy())
+
+    torch.set_num_threads(8)
+    org = {"v_template": torch.from_numpy(rig.v_template), "shapedirs": torch.from_numpy(rig.shapedirs),
+           "posedirs": torch.from_numpy(rig.posedirs), "J_regressor": torch.from_numpy(rig.J_regressor),
+           "weights": torch.from_numpy(rig.weights), "faces": torch.from_numpy(rig.faces.astype(np.int64))}
+    rm = pose_rotmats(seq)
+    og = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in g.items()}
+    names = ("xyz", "log_scale", "rot", "opacity", "sh")
+    for k in names:
+        og[k].requires_grad_(True)
+    m = {k: torch.zeros_like(og[k]) for k in names}
+    v = {k: torch.zeros_like(og[k]) for k in names}
+    sh_lr = torch.full((1, 16, 1), 2.5e-3 / 20.0)
+    sh_lr[0, 0, 0] = 2.5e-3
+    want_losses = []
+    for it in range(STEPS):
+        view = views[it % 2]
+        t = view.timestep
+        frame = {"shape": torch.from_numpy(seq["shape"]), "expr": torch.from_numpy(seq["expr"][t]), "rotmats": torch.from_numpy(rm[t]),
+                 "translation": torch.from_numpy(seq["translation"][t]), "static_offset": torch.from_numpy(seq["static_offset"][0]),
+                 "dynamic_offset": None}
+        out = O.render(org, og, frame, view.camera, bg=(0.0, 0.0, 0.0), sh_degree=3)
+        photo = O.photometric_loss(out["image"], targets[it % 2])
+        loss = photo + O.regularisers(og, out["proj"]["visible"])
+        for k in names:
+            og[k].grad = None
+        loss.backward()
+        want_losses.append(float(photo.detach()))
+        lrs = {"xyz": expon_lr(it, 5e-3, 5e-5, 30000), "log_scale": 1.7e-2, "rot": 1e-3, "opacity": 5e-2, "sh": sh_lr}
+        with torch.no_grad():
+            for k in names:
+                if isinstance(lrs[k], torch.Tensor):       # per-coefficient rate: scale the step, not the moments
+                    before = og[k].clone()
+                    O.adam_step(og[k], og[k].grad, m[k], v[k], it + 1, 1.0)
+                    og[k].copy_(before + (og[k] - before) * lrs[k])
+                else:
+                    O.adam_step(og[k], og[k].grad, m[k], v[k], it + 1, lrs[k])
+    assert np.allclose(losses, want_losses, rtol=2e-3, atol=2e-5), (losses, want_losses)
+    assert losses[4] < losses[0] and losses[5] < losses[1]            # both views improve (view 0: steps 0, 2, 4; view 1: 1, 3, 5)
+    lr_of = {"xyz": 5e-3, "log_scale": 1.7e-2, "rot": 1e-3, "opacity": 5e-2, "sh": 2.5e-3}
+    for k in names:
+        a, b = np.asarray(got[k], np.float64).reshape(N, -1), og[k].detach().numpy().astype(np.float64).reshape(N, -1)
+        d = np.abs(a - b)
+        moved = np.abs(b - np.asarray(g[k], np.float64).reshape(N, -1)).max()
+        assert moved > 2 * lr_of[k] * 0.5                                  # the parameters really trained
+        assert np.median(d) <= 1e-3 * lr_of[k], (k, np.median(d))
+        assert np.quantile(d, 0.99) <= 0.6 * lr_of[k], (k, np.quantile(d, 0.99))   # the tail: a few sign flips of one step
