@@ -23,7 +23,13 @@ struct RegK {
   float lambda_xyz, thr_xyz, lambda_scale, thr_scale;
 };
 
-__global__ __launch_bounds__(256) void project_bwd_kernel(int n, int n_pad, const float* __restrict__ params,
+// 180 VGPRs as the compiler allocates them leave two waves per SIMD for a kernel that waits on ~110 loads per lane; asking for
+// three costs four spilled words and buys latency hiding (0.057 -> 0.049 ms at 300 k Gaussians; four waves spill 50 words: 0.077)
+#ifndef OMFS_PBWD_WAVES
+#define OMFS_PBWD_WAVES 3
+#endif
+#define OMFS_PBWD_ATTR __attribute__((amdgpu_waves_per_eu(OMFS_PBWD_WAVES, 8)))
+__global__ __launch_bounds__(256) OMFS_PBWD_ATTR void project_bwd_kernel(int n, int n_pad, const float* __restrict__ params,
                                                           const int32_t* __restrict__ binding,
                                                           const float* __restrict__ face_xf, ProjCamB cam,
                                                           const float4* __restrict__ g0, const float4* __restrict__ g1,
