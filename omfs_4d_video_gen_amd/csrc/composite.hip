@@ -523,7 +523,17 @@ __device__ __forceinline__ void reduce9_groups_of_8(float (&v)[9]) {
 // parked in one of PEND wave-private slots, and flushed 4 splats per wave-instruction: 16 lanes per 64-byte
 // dsplat record, lane q < 9 sums the 8 partials of value q and adds them with one float atomic, so every
 // atomic wave-instruction covers whole 64-byte segments (MI355X_MICROARCH "Global float atomics").
-__global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order,
+// Residency is what this kernel lives on (every lever that lowered it lost): 4 pending slots instead of 16 bring the
+// wave-private LDS from 7.5 KB to 4 KB -- the wave slots, not the LDS, now bound the residency -- and 64 VGPRs keep all
+// 8 slots per SIMD usable (0.277 -> 0.245 ms; 2, 6, 8, 12 slots: 0.251, 0.251, 0.261, 0.258).
+#ifndef OMFS_BWD_PEND
+#define OMFS_BWD_PEND 4
+#endif
+#ifndef OMFS_BWD_WAVES
+#define OMFS_BWD_WAVES 8
+#endif
+#define OMFS_BWD_ATTR __attribute__((amdgpu_waves_per_eu(OMFS_BWD_WAVES, 8)))
+__global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order,
                                                            const uint32_t* __restrict__ order_seg0,
                                                            const float4* __restrict__ seg_ckpt,
                                                            const uint32_t* __restrict__ tile_start,
@@ -533,7 +543,7 @@ __global__ __launch_bounds__(64) void composite_bwd_kernel(CompCam cam, int n_ti
                                                            const float* __restrict__ final_T,
                                                            const uint32_t* __restrict__ n_contrib,
                                                            const float* __restrict__ dimage, float* __restrict__ dsplat) {
-  constexpr int PEND = 16;                // reduced splats parked before a flush
+  constexpr int PEND = OMFS_BWD_PEND;     // reduced splats parked before a flush
   __shared__ float4 s0[WB];
   __shared__ float4 s1[WB];
   __shared__ float2 s2[WB];               // (blue, opacity)
