@@ -87,8 +87,7 @@ class FlameRig:
     @classmethod
     def from_pickle(cls, path: str):
         """Same keys `SimpleFLAME.__init__` reads (`flame_fitter.py:80-120`) plus `posedirs`."""
-        with open(path, "rb") as f:
-            m = pickle.load(f, encoding="latin1")
+        m = load_flame_pickle(path)
         jr = m["J_regressor"]
         jr = np.asarray(jr.todense() if hasattr(jr, "todense") else jr, np.float32)
         kt = np.asarray(m["kintree_table"], np.int64)
@@ -97,6 +96,42 @@ class FlameRig:
         return cls(np.asarray(m["v_template"], np.float32), np.asarray(m["shapedirs"], np.float32),
                    np.asarray(m["posedirs"], np.float32), jr, np.asarray(m["weights"], np.float32),
                    np.asarray(m["f"], np.int64).astype(np.int32), parents)
+
+
+class _ChumpyArray:
+    """Stands in for `chumpy.ch.Ch` (and relatives) when the FLAME pickle is read without chumpy installed: the released
+    FLAME pickles store several arrays as chumpy objects whose state carries the ndarray under `x`."""
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {"x": state})
+
+    def __array__(self, dtype=None, copy=None):
+        x = self.__dict__.get("x")
+        if x is None:
+            x = next((v for v in self.__dict__.values() if isinstance(v, np.ndarray)), None)
+        if x is None:
+            raise ValueError("chumpy object in the FLAME pickle carries no array")
+        return np.asarray(x, dtype=dtype)
+
+
+class _FlameUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module == "chumpy" or module.startswith("chumpy."):
+            return _ChumpyArray
+        return super().find_class(module, name)
+
+
+def load_flame_pickle(path: str) -> dict:
+    """`pickle.load(f, encoding="latin1")` as the reference does (`flame_fitter.py:80-82`), but independent of the
+    chumpy package: with it installed the objects load as usual, without it they load as plain array holders."""
+    with open(path, "rb") as f:
+        try:
+            return pickle.load(f, encoding="latin1")
+        except ModuleNotFoundError as e:
+            if "chumpy" not in str(e):
+                raise
+        f.seek(0)
+        return _FlameUnpickler(f, encoding="latin1").load()
 
 
 def tile_basis(basis_kcv: np.ndarray, k_pad: int, v_pad: int) -> np.ndarray:

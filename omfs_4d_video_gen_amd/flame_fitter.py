@@ -16,7 +16,6 @@ from __future__ import annotations
 
 import argparse
 import os
-import pickle
 from pathlib import Path
 
 import numpy as np
@@ -75,8 +74,8 @@ class SimpleFLAME:
 
     def __init__(self, flame_model_path: str, n_shape: int = 100, n_expr: int = 50):
         self.n_shape, self.n_expr = n_shape, n_expr
-        with open(flame_model_path, "rb") as f:
-            model = pickle.load(f, encoding="latin1")
+        from .engine.flame_rig import load_flame_pickle
+        model = load_flame_pickle(flame_model_path)          # latin1 pickle as in the reference; chumpy not required
         v_template = np.array(model["v_template"], dtype=np.float64)
         shapedirs = np.array(model["shapedirs"], dtype=np.float64)
         faces = np.array(model["f"], dtype=np.int64)

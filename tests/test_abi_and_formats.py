@@ -106,3 +106,41 @@ def test_dataset_write_load_roundtrip(tmp_path):
     # the default VHAP transform (preprocess_video.py:370) is a camera one unit in front of the head
     c = IO.camera_from_frame({"transform_matrix": [[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 1], [0, 0, 0, 1]], "w": 8, "h": 8, "camera_angle_x": 0.5}, {})
     assert np.allclose(c["cam_pos"], [0, 0, 1]) and np.allclose(c["world_to_view"][:3, :3], np.diag([1, -1, -1]))
+
+
+def test_flame_pickle_with_chumpy_objects_loads_without_chumpy(tmp_path):
+    """The released FLAME pickles hold chumpy arrays; the loader must not need the chumpy package."""
+    import pickle
+    import sys
+    import types
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig, load_flame_pickle
+    from omfs_4d_video_gen_amd.engine import synthetic
+    rig = synthetic.make_rig(0)
+    fake = types.ModuleType("chumpy")
+    fake_ch = types.ModuleType("chumpy.ch")
+
+    class Ch:                                   # pickled by reference to chumpy.ch.Ch, state = {"x": ndarray, ...}
+        def __init__(self, x):
+            self.x = np.asarray(x)
+            self._dirty_vars = set()
+    Ch.__module__, Ch.__qualname__ = "chumpy.ch", "Ch"
+    fake_ch.Ch = Ch
+    fake.ch = fake_ch
+    sys.modules["chumpy"], sys.modules["chumpy.ch"] = fake, fake_ch
+    try:
+        import scipy.sparse as sp
+        kt = np.stack([np.array([2 ** 32 - 1, 0, 1, 1, 1], np.int64), np.arange(5)])
+        blob = {"v_template": Ch(rig.v_template), "shapedirs": Ch(rig.shapedirs), "posedirs": Ch(rig.posedirs),
+                "J_regressor": sp.csc_matrix(rig.J_regressor), "weights": Ch(rig.weights), "f": rig.faces.astype(np.uint32),
+                "kintree_table": kt}
+        path = tmp_path / "flame_like.pkl"
+        with open(path, "wb") as f:
+            pickle.dump(blob, f, protocol=2)
+    finally:
+        del sys.modules["chumpy"], sys.modules["chumpy.ch"]
+    m = load_flame_pickle(str(path))
+    assert type(m["v_template"]).__name__ == "_ChumpyArray"
+    assert np.array_equal(np.asarray(m["v_template"], np.float32), rig.v_template)
+    r = FlameRig.from_pickle(str(path))
+    assert r.n_verts == rig.v_template.shape[0] and r.n_faces == rig.faces.shape[0]
+    assert np.array_equal(r.shapedirs, rig.shapedirs.astype(np.float32)) and np.array_equal(r.faces, rig.faces.astype(np.int32))
