@@ -118,6 +118,26 @@ def read_png(path) -> np.ndarray:
     return img
 
 
+def load_image_rgba(path):
+    """((H,W,3) uint8, alpha (H,W) uint8 or None): training images of upstream-style datasets may carry the foreground
+    matte as an alpha channel instead of a separate `fg_mask_path`."""
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            if im.mode in ("RGBA", "LA") or (im.mode == "P" and "transparency" in im.info):
+                a = np.asarray(im.convert("RGBA"))
+                return np.ascontiguousarray(a[:, :, :3]), np.ascontiguousarray(a[:, :, 3])
+            return np.asarray(im.convert("RGB")), None
+    except ImportError:
+        pass
+    img = read_png(path)
+    if img.shape[2] in (2, 4):
+        alpha = np.ascontiguousarray(img[:, :, -1])
+        rgb = np.repeat(img[:, :, :1], 3, 2) if img.shape[2] == 2 else np.ascontiguousarray(img[:, :, :3])
+        return rgb, alpha
+    return (np.repeat(img, 3, 2) if img.shape[2] == 1 else img[:, :, :3]), None
+
+
 def load_image_rgb(path) -> np.ndarray:
     """(H,W,3) uint8; an alpha channel, if any, is returned separately by load_image_rgba.  Decoded by PIL when it is
     installed (the reference's own dependency, `validation_reporting.py:11`; ~20x faster than the numpy decoder below on

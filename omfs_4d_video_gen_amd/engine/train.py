@@ -117,11 +117,13 @@ def main(argv=None):
     views, size = [], None
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=8) as pool:          # PNG decode releases the interpreter lock
-        images = list(pool.map(lambda fr: IO.load_image_rgb(os.path.join(args.source_path, fr["file_path"])), split["frames"]))
+        loaded = list(pool.map(lambda fr: IO.load_image_rgba(os.path.join(args.source_path, fr["file_path"])), split["frames"]))
+    images, alphas = [im for im, _ in loaded], [a for _, a in loaded]
+    del loaded
     # fp32 targets are 4x the bytes of the images: kept while they fit comfortably beside the model, 8-bit otherwise
     n_px = sum(int(im.shape[0]) * int(im.shape[1]) for im in images)
     store_u8 = args.target_storage == "u8" or (args.target_storage == "auto" and n_px * 12 > 64 << 30)
-    for fr, trow, img in zip(split["frames"], split["timestep_of_frame"], images):
+    for fr, trow, img, alpha in zip(split["frames"], split["timestep_of_frame"], images, alphas):
         cam = IO.camera_from_frame(fr, split["top"])
         if args.resolution in (1, 2, 4, 8):
             w, h = cam["width"] // args.resolution, cam["height"] // args.resolution
@@ -142,6 +144,10 @@ def main(argv=None):
         mask = None
         if mask_rel and os.path.exists(os.path.join(args.source_path, mask_rel)):
             mask = IO.read_png(os.path.join(args.source_path, mask_rel))[:, :, 0].astype(np.float32) / 255.0
+            if mask.shape != (h, w):
+                mask = resize_nearest(mask, w, h)
+        elif alpha is not None:                 # the matte travels as the image's alpha channel (upstream-style datasets)
+            mask = alpha.astype(np.float32) / 255.0
             if mask.shape != (h, w):
                 mask = resize_nearest(mask, w, h)
         if store_u8:

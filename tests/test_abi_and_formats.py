@@ -144,3 +144,16 @@ def test_flame_pickle_with_chumpy_objects_loads_without_chumpy(tmp_path):
     r = FlameRig.from_pickle(str(path))
     assert r.n_verts == rig.v_template.shape[0] and r.n_faces == rig.faces.shape[0]
     assert np.array_equal(r.shapedirs, rig.shapedirs.astype(np.float32)) and np.array_equal(r.faces, rig.faces.astype(np.int32))
+
+
+def test_rgba_images_return_their_matte(tmp_path):
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    rng = np.random.default_rng(1)
+    rgba = rng.integers(0, 256, (9, 13, 4), dtype=np.uint8)
+    IO.write_png(tmp_path / "a.png", rgba)
+    IO.write_png(tmp_path / "b.png", rgba[:, :, :3])
+    rgb, alpha = IO.load_image_rgba(tmp_path / "a.png")
+    assert np.array_equal(rgb, rgba[:, :, :3]) and np.array_equal(alpha, rgba[:, :, 3])
+    rgb2, alpha2 = IO.load_image_rgba(tmp_path / "b.png")
+    assert np.array_equal(rgb2, rgba[:, :, :3]) and alpha2 is None
+    assert np.array_equal(IO.load_image_rgb(tmp_path / "a.png"), rgba[:, :, :3])
