@@ -10,7 +10,9 @@ from omfs_4d_video_gen_amd.engine import synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,width,height,yaw,seed", [(4000, 160, 120, 0.3, 1), (20000, 320, 256, -0.7, 2), (2500, 100, 52, 0.0, 5)])
+# the last case is BASELINE.json's full size: the C oracle renders it in well under a minute on one host core
+@pytest.mark.parametrize("n,width,height,yaw,seed", [(4000, 160, 120, 0.3, 1), (20000, 320, 256, -0.7, 2), (2500, 100, 52, 0.0, 5),
+                                                     (300000, 1920, 1080, 0.35, 0)])
 def test_bitexact_vs_c_oracle(n, width, height, yaw, seed):
     from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig, DeviceFlame
     from omfs_4d_video_gen_amd.engine.gaussians import GaussianModel, pack_params

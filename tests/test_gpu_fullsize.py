@@ -1,5 +1,6 @@
-"""Size-independent properties of the HIP path at BASELINE.json's full size (1920x1080, 300 000 Gaussians), where
-the oracle is too slow to run: determinism, sortedness of every tile list, list/offset consistency, invariance of
+"""Size-independent properties of the HIP path at BASELINE.json's full size (1920x1080, 300 000 Gaussians).  The forward is
+also compared bit for bit with the C oracle at this size (tests/test_gpu_bitexact.py, last case); the autograd oracle of the
+backward pass is too slow here, hence: determinism, sortedness of every tile list, list/offset consistency, invariance of
 the image under a permutation of the Gaussians, linearity of the backward pass in dL/dimage, checkpoints consistent
 with the final image, and the loss gradient against a finite difference of the loss value."""
 import numpy as np
