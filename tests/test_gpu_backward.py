@@ -36,7 +36,8 @@ def _grads_to_groups(grads, n):
 
 
 @pytest.mark.parametrize("n,width,height,bg,big", [(1200, 80, 64, (1.0, 1.0, 1.0), False), (3000, 128, 96, (0.1, 0.2, 0.3), True),
-                                                   (16000, 64, 48, (0.3, 0.1, 0.2), False)])   # last: deep lists
+                                                   (16000, 64, 48, (0.3, 0.1, 0.2), False),    # deep lists
+                                                   (40000, 448, 252, (0.0, 0.0, 0.0), False)])   # as large as autograd takes in a few seconds
 def test_backward_matches_autograd(n, width, height, bg, big):
     from oracle import torch_splat as O
     rig, g, seq, cam, dflame, model, rast, mk = _scene(n, width, height, seed=4, big_scale=big)
@@ -61,7 +62,9 @@ def test_backward_matches_autograd(n, width, height, bg, big):
         r = og[name].grad.numpy()
         d = np.abs(got[name] - r).max()
         scale = np.abs(r).max()
-        assert d <= 2e-3 * scale + 1e-7, f"{name}: max diff {d} vs max ref {scale}"
+        # per element: the torch oracle orders near-equal depths by its own fp32 depth (the engine's order is the C oracle's,
+        # bit for bit), so among tens of thousands of Gaussians a few composite in another order
+        assert d <= (2e-3 if n < 30000 else 1e-2) * scale + 1e-7, f"{name}: max diff {d} vs max ref {scale}"
         # and in aggregate much tighter
         assert np.abs(got[name] - r).sum() <= 2e-4 * np.abs(r).sum() + 1e-6, name
 
