@@ -142,3 +142,32 @@ def test_loss_gradient_matches_a_directional_difference(scene):
     an = float((grad.double() * direction.double()).sum())
     # the L1 term is not differentiable where |image - target| < eps (about 1 % of the pixels)
     assert abs(fd - an) <= 3e-2 * abs(an) + 1e-7, (fd, an)
+
+
+def test_colour_gradient_matches_directional_differences_of_the_forward(scene):
+    """At full size the backward pass is checked against the forward itself: L = <image, W> is linear in the SH coefficients
+    (up to the clamp of a colour at 0), so along a random direction v of the SH planes sum(grad * v) must equal the central
+    difference of L.  (Geometry and opacity move list membership and the 1/255 / 1e-4 cut-offs: L is not smooth there.)"""
+    g, model, rast, fxf, cam = scene
+    gen = torch.Generator().manual_seed(21)
+    Wt = torch.randn(3, H, W, generator=gen).cuda().contiguous()
+    rast.forward(model, fxf, cam)
+    grads = torch.zeros(59, model.n_pad, device="cuda")
+    rast.backward(model, fxf, cam, grads, dimage=Wt, reg=(0.0, 1.0, 0.0, 0.6))
+    torch.cuda.synchronize()
+    params0 = model.params.clone()
+
+    def L_at(delta_planes, lo, hi, eps):
+        model.params[lo:hi, :N] = params0[lo:hi, :N] + eps * delta_planes
+        img = rast.forward(model, fxf, cam)
+        val = float((img.double() * Wt.double()).sum())
+        model.params.copy_(params0)
+        return val
+
+    for (lo, hi, eps) in ((11, 14, 1e-2), (14, 59, 1e-2), (11, 59, 1e-3)):     # degree 0, degrees 1-3, all
+        v = torch.randn(hi - lo, N, generator=gen).cuda()
+        terms = grads[lo:hi, :N].double() * v.double()
+        analytic, spread = float(terms.sum()), float(terms.pow(2).sum().sqrt())   # the sum and the size of a random sum of its terms
+        fd = (L_at(v, lo, hi, eps) - L_at(v, lo, hi, -eps)) / (2 * eps)
+        assert spread > 0 and abs(fd - analytic) <= 1e-2 * abs(analytic) + 2e-2 * spread, (lo, hi, fd, analytic, spread)
+    rast.check_status()
