@@ -485,6 +485,23 @@ __device__ __forceinline__ void fix_ties(uint2* s, int n) {
 // grid = n_tiles (blocks walk tile_order: heavy tiles first), block = NT.  A launch handles the tiles with
 // n_lo < n <= n_hi.  dynamic LDS = lds_cap*8 (the bucket-ordered pairs) + ((NT/64)*256 + 8)*4; lists longer than
 // lds_cap keep that copy in keys_tmp (global) instead.
+#ifdef OMFS_DEBUG_TIMELINE
+// per-workgroup start / end (100 MHz real-time counter), list length and path taken: tools/sort_timeline.py
+__device__ unsigned long long omfs_dbg_sort[2][3][16384];
+#define OMFS_DBG_SORT_BEGIN() const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime()
+#define OMFS_DBG_SORT_END(path)                                                                        \
+  do {                                                                                                  \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                       \
+      unsigned long long(*d)[16384] = omfs_dbg_sort[NT == 1024 ? 0 : 1];                                \
+      d[0][blockIdx.x] = dbg_t0; d[1][blockIdx.x] = __builtin_amdgcn_s_memrealtime();                   \
+      d[2][blockIdx.x] = (unsigned long long)n | ((unsigned long long)(path) << 32);                    \
+    }                                                                                                   \
+  } while (0)
+#else
+#define OMFS_DBG_SORT_BEGIN() do { } while (0)
+#define OMFS_DBG_SORT_END(path) do { } while (0)
+#endif
+
 template <int NT>
 __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
                                                        const uint32_t* __restrict__ tile_start,
@@ -499,18 +516,23 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
   const uint32_t s = tile_start[tile];
   const int n = (int)(tile_start[tile + 1] - s);
   if (n <= n_lo || n > n_hi) return;
+  OMFS_DBG_SORT_BEGIN();
   const int tid = threadIdx.x;
   if (n == 1) {
     if (tid == 0) sorted_ids[s] = keys[s].y;
     return;
   }
-  if (bucket_sort_to_ids<NT>(keys + s, n <= lds_cap ? bufB : keys_tmp + s, n, hist, misc, sorted_ids + s)) return;
+  if (bucket_sort_to_ids<NT>(keys + s, n <= lds_cap ? bufB : keys_tmp + s, n, hist, misc, sorted_ids + s)) {
+    OMFS_DBG_SORT_END(n <= lds_cap ? 1 : 2);
+    return;
+  }
   // clustered depths: counting passes through keys / keys_tmp (uniform over the workgroup)
   uint2* res = radix_sort_pairs<NT>(keys + s, keys_tmp + s, n, hist, misc);
   __syncthreads();
   fix_ties<NT>(res, n);
   __syncthreads();
   for (int k = tid; k < n; k += NT) sorted_ids[s + k] = res[k].y;
+  OMFS_DBG_SORT_END(3);
 }
 
 #ifndef OMFS_SORT_SMALL_NT
@@ -632,3 +654,17 @@ extern "C" int omfs_bin_sort(const omfs_gaussians* g, const omfs_camera* cam, co
   if (int rc = omfs_bin_scatter(g, cam, rb, stream)) return rc;
   return omfs_tile_sort(cam, rb, stream);
 }
+
+#ifdef OMFS_DEBUG_TIMELINE
+extern "C" int omfs_debug_sort_timeline(int cls, unsigned long long* out, int reset) {   // out [3][16384]
+  OMFS_REQUIRE(cls >= 0 && cls < 2 && out, "args");
+  OMFS_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(omfs_dbg_sort), sizeof(unsigned long long) * 3 * 16384,
+                                     (size_t)cls * 3 * 16384 * sizeof(unsigned long long)));
+  if (reset) {
+    void* p = nullptr;
+    OMFS_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(omfs_dbg_sort)));
+    OMFS_CHECK_HIP(hipMemset(p, 0, sizeof(unsigned long long) * 2 * 3 * 16384));
+  }
+  return OMFS_OK;
+}
+#endif
