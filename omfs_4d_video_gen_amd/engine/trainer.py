@@ -120,6 +120,17 @@ class Trainer:
         if finetune_flame:
             from .flame_finetune import FlameFineTuner
             self.flame_ft = FlameFineTuner(self.dflame, flame_params, flame_lr)
+        # A fixed FLAME sequence is posed ONCE: the triangle frames of every timestep stay resident ([T][F][16] fp32, 0.65 MB
+        # per timestep at FLAME's size -- a few hundred MB of the 288 GB), and a step starts with its projection instead of
+        # a cross-stream wait for the frames (15 us of idle queue per iteration in the kernel trace).  Sequences too long for
+        # that, and fine-tuning (the frames change with every update), pose per step as before.
+        self._frames_all = None
+        T, F = self.dflame.n_frames, self.dflame.rig.n_faces
+        if not finetune_flame and T * F * 64 <= int(os.environ.get("OMFS_FRAME_TABLE_BYTES", 8 << 30)):
+            self._frames_all = torch.empty(T, F, 16, device=self.device)
+            for t0 in range(0, T, 16):
+                nb = min(16, T - t0)
+                self._frames_all[t0:t0 + nb].copy_(self.dflame.face_frames(t0, nb)[1])
 
     def _cam(self, view: View, sh_degree: int):
         key = (id(view), sh_degree)
@@ -156,7 +167,7 @@ class Trainer:
             vs.n_views = self.world
             for w, i in enumerate(ids):
                 vs.view[w] = i
-            pat = (ts, vs)
+            pat = (ts, vs, ts.to(torch.int64))
             self._dp_patterns[ids] = pat
         return pat
 
@@ -177,6 +188,14 @@ class Trainer:
         if ft is not None:             # rotation matrices from the current poses
             ft.begin(view.timestep, self.model.binding, all_timesteps=self.compact_dp)
             verts, face_xf, nb, col, pat = self._pose_frames(it)
+        elif self._frames_all is not None:
+            # the sequence is fixed and its frames are resident: nothing to pose
+            if self.compact_dp:            # the frames of ALL ranks' views of this step, one row per rank
+                pat = self._dp_pattern(it)
+                face_xf, nb, col, verts = self._frames_all.index_select(0, pat[2]), self.world, self.rank, None
+            else:
+                t = view.timestep
+                face_xf, nb, col, verts, pat = self._frames_all[t:t + 1], 1, 0, None, None
         else:
             # the sequence is fixed: this step's frames were posed on the side stream during the previous step,
             # the next step's are posed now, concurrently with this step's kernels (double-buffered outputs)
