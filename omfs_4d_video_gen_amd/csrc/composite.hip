@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
       const int j = jn;
       OMFS_DBG_WORK();
       m &= m - 1ull;
-      jn = m ? __builtin_ctzll(m) : 0;
+      jn = __builtin_ctzll(m | (1ull << 63));    // m == 0: any staged entry will do, it is not used
       nx0 = s0[jn]; nx1 = s1[jn]; nx2 = s2[jn];
       {
         const float dx_ = a.x - fx, dy_ = a.y - fy;
@@ -212,16 +212,15 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
         if (p2 <= 0.f && e >= LOG2_INV255) {
           const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
           const float Tn = T * (1.f - alpha);
-          if (Tn < 1e-4f) {
-            done = true;
-          } else {
-            const float w = alpha * T;
-            C0 = fma_(c.z, w, C0);
-            C1 = fma_(c.w, w, C1);
-            C2 = fma_(cb, w, C2);
-            T = Tn;
-            last = base + (uint32_t)j + 1u;
-          }
+          const bool stop = Tn < 1e-4f;
+          // the splat that would take T below the threshold is not composited: weight 0, T and last stay
+          const float w = stop ? 0.f : alpha * T;
+          C0 = fma_(c.z, w, C0);
+          C1 = fma_(c.w, w, C1);
+          C2 = fma_(cb, w, C2);
+          T = stop ? T : Tn;
+          last = stop ? last : base + (uint32_t)j + 1u;
+          done = stop;
         }
       }
       if (!check) return;     // saturation is looked at after every fourth splat
