@@ -369,7 +369,7 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
         auto visit = [&](const float4& a, const float4& c, const float& cb, float4& nx0, float4& nx1, float& nx2) {
           const int j = jn;
           m &= m - 1ull;
-          jn = m ? __builtin_ctzll(m) : 0;
+          jn = __builtin_ctzll(m | (1ull << 63));
           nx0 = pg0[wave][jn]; nx1 = pg1[wave][jn]; nx2 = pg2[wave][jn];
           const float dx = a.x - fx, dy = a.y - fy;
           const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
       const float4 a = an;
       const float4 c = cn;
       const float2 cb = cbn;
-      jbn = m ? 63 - __builtin_clzll(m) : 0;   // prefetch the next splat's record
+      jbn = 63 - __builtin_clzll(m | 1ull);   // prefetch the next splat's record
       nx0 = s0[jbn]; nx1 = s1[jbn]; nx2 = s2[jbn];
       const float dx = a.x - fx, dy = a.y - fy;
       const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
