@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_aux", action="store_true")
     ap.add_argument("--profile_steps", type=int, default=40)
+    ap.add_argument("--frozen_flame", action="store_true", help="headline step with a fixed FLAME sequence (--not_finetune_flame_params)")
     return ap.parse_args()
 
 
@@ -73,25 +74,34 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline_train(n_s=200000, w_s=1120, h_s=630):
-    """PyTorch-CPU oracle: one full training iteration (render, L1+D-SSIM, autograd backward, Adam)
-    on a bounded sample; returns (seconds, D_sample)."""
+def cpu_baseline_train(n_s, w_s, h_s, views=16):
+    """CPU restatement of ONE full training iteration at the bench workload itself (same seeded scene, FLAME fine-tuning on):
+    FLAME pose + projection + tile test + binning + per-tile sort by the plain-C bit-level oracle (oracle/splat_oracle.c,
+    one core), then composite, L1 + D-SSIM, autograd backward down to the FLAME parameters and Adam by the PyTorch-CPU
+    oracle (oracle/torch_splat.py, all usable cores).  Returns (seconds, D)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle import c_oracle as CO
     from oracle import torch_splat as O
     from omfs_4d_video_gen_amd.engine import synthetic
-    from omfs_4d_video_gen_amd.engine.flame_rig import pose_rotmats
+    from omfs_4d_video_gen_amd.engine.flame_rig import DeviceFlame, FlameRig
+    from omfs_4d_video_gen_amd.engine.gaussians import pack_params
+    from omfs_4d_video_gen_amd.engine.rasterizer import make_camera_struct
     torch.set_num_threads(host_cores())
     rig = synthetic.make_rig(0)
     g = synthetic.make_gaussians(n_s, rig.faces.shape[0], 0)
-    seq = synthetic.make_flame_sequence(2, 0)
-    cam = synthetic.make_camera(w_s, h_s, 0.2)
+    seq = synthetic.make_flame_sequence(max(views, 2), 0)
+    cam = synthetic.make_camera_arc(w_s, h_s, views)[1 % views]
+    t = 1
+    dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq)          # host arrays for the C oracle (inputs already resident)
+    ccam = CO.camera(make_camera_struct(cam, sh_degree=3))
+    params = pack_params(g)
     org = {"v_template": torch.from_numpy(rig.v_template), "shapedirs": torch.from_numpy(rig.shapedirs),
            "posedirs": torch.from_numpy(rig.posedirs), "J_regressor": torch.from_numpy(rig.J_regressor),
            "weights": torch.from_numpy(rig.weights), "faces": torch.from_numpy(rig.faces.astype(np.int64))}
-    rm = pose_rotmats(seq)
-    frame = {"shape": torch.from_numpy(seq["shape"]), "expr": torch.from_numpy(seq["expr"][1]),
-             "rotmats": torch.from_numpy(rm[1]), "translation": torch.from_numpy(seq["translation"][1]),
-             "static_offset": torch.from_numpy(seq["static_offset"][0]), "dynamic_offset": None}
+    pose = torch.from_numpy(np.concatenate([seq["rotation"][t], seq["neck_pose"][t], seq["jaw_pose"][t], seq["eyes_pose"][t]]).reshape(5, 3).copy())
+    expr = torch.from_numpy(seq["expr"][t].copy())
+    trans = torch.from_numpy(seq["translation"][t].copy())
+    flame_leaves = [pose.requires_grad_(True), expr.requires_grad_(True), trans.requires_grad_(True)]
     og = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in g.items()}
     names = ("xyz", "log_scale", "rot", "opacity", "sh")
     for k in names:
@@ -100,14 +110,21 @@ def cpu_baseline_train(n_s=200000, w_s=1120, h_s=630):
     m = {k: torch.zeros_like(og[k]) for k in names}
     v = {k: torch.zeros_like(og[k]) for k in names}
     t0 = time.perf_counter()
-    out = O.render(org, og, frame, cam, bg=(0.0, 0.0, 0.0), sh_degree=3)
+    verts, _ = CO.flame_frame(dflame, t)
+    proj = CO.project(params, g["binding"], CO.face_frames(verts, dflame.rig.faces), ccam, n_s)
+    ts, ids = CO.bin_sort(proj, w_s, h_s)
+    frame = {"shape": torch.from_numpy(seq["shape"]), "expr": expr, "rotmats": O.rodrigues(pose), "translation": trans,
+             "static_offset": torch.from_numpy(seq["static_offset"][0]), "dynamic_offset": None}
+    out = O.render(org, og, frame, cam, bg=(0.0, 0.0, 0.0), sh_degree=3, lists=O.lists_from_offsets(ts, ids))
     loss = O.photometric_loss(out["image"], target) + O.regularisers(og, out["proj"]["visible"])
     loss.backward()
     with torch.no_grad():
         for k in names:
             O.adam_step(og[k], og[k].grad, m[k], v[k], 1, 1e-3)
+        for p in flame_leaves:
+            O.adam_step(p, p.grad, torch.zeros_like(p), torch.zeros_like(p), 1, 1e-5)
     dt = time.perf_counter() - t0
-    return dt, sum(len(l) for l in out["lists"])
+    return dt, int(ts[-1])
 
 
 _T0 = time.perf_counter()
@@ -117,11 +134,43 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
+def launcher_argv(n_gpus: int, port: int, passthrough: list) -> list:
+    """The command `python bench.py --gpus N` runs as a CHILD when it was not itself started by torch.distributed.run:
+    one rank per GPU on this node, rendezvous on 127.0.0.1 (the contract's own launch line)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(passthrough)
+
+
+def launch_ranks(args) -> int:
+    """Parent of a multi-GPU run started without a launcher.  It never touches the GPU (no torch.cuda call before the
+    spawn, so nothing is exec'ed or forked from a process that initialised HIP): the ranks are children, rank 0's JSON line
+    is relayed on stdout, the exit code is the child's."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = launcher_argv(args.gpus, port, sys.argv[1:])
+    log(f"launching {args.gpus} ranks: {' '.join(cmd)}")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // args.gpus)))
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    print(f"[bench] rank {rank}/{world} started (pid {os.getpid()})", file=sys.stderr, flush=True)
+    if world != args.gpus:
+        # a line labelled with one GPU count and measured on another is worse than no line
+        print(json.dumps({"error": f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks"}))
+        sys.exit(2)
     if not torch.cuda.is_available():
         print(json.dumps({"error": "bench.py needs a GPU (MI355X); no CPU fallback exists"}))
         sys.exit(2)
@@ -137,9 +186,6 @@ def main():
         else:
             dist.init_process_group(backend)
         pg = dist.group.WORLD
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-
     from omfs_4d_video_gen_amd.engine import synthetic
     from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
     from omfs_4d_video_gen_amd.engine.trainer import Renderer, Trainer, View, StageTimer
@@ -167,8 +213,10 @@ def main():
     del tr
 
     log("targets rendered")
+    # upstream's default for --bind_to_mesh (the reference's argv passes no opt-out, train_ghost.py:227-237): the per-timestep
+    # FLAME parameters are optimised with the Gaussians, so FLAME LBS + triangle frames are posed INSIDE the timed step
     trainer = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3,
-                      rank=rank, world_size=world, process_group=pg)
+                      rank=rank, world_size=world, process_group=pg, finetune_flame=not args.frozen_flame)
 
     def barrier():
         if world > 1:
@@ -196,7 +244,11 @@ def main():
     trainer.rast.check_status()
     loss_end = trainer.loss_value()
     ms_per_step = dt / args.steps * 1e3
-    value = world * args.steps / dt
+    n_ranks = world
+    if world > 1:
+        import torch.distributed as dist
+        n_ranks = dist.get_world_size()      # the line reports the size of the RCCL group that actually ran
+    value = n_ranks * args.steps / dt
 
     # ---- per-kernel timing with HIP events on the launch stream (same step function)
     trainer.timer = StageTimer(True)
@@ -219,19 +271,24 @@ def main():
     # a fixed FLAME sequence is posed once before training (resident triangle frames): no per-step FLAME traffic
     sb["flame"] = 0 if getattr(trainer, "_frames_all", None) is not None else \
         trainer.dflame.k_pad * trainer.dflame.v_pad * 3 * 4 + trainer.dflame.v_pad * 16 + F * (64 + 12)
+    sb["flame_bwd"] = N * 64 + F * 48 + trainer.dflame.v_pad * 76 + trainer.dflame.k_pad * trainer.dflame.v_pad * 3 * 4
     dom = max((k for k in stages if k != "allreduce"), key=lambda k: stages[k][0])
     dom_ms = stages[dom][0]
     achieved = sb[dom] / (dom_ms * 1e-3) / 1e9
-    traffic = None
+    # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs): these cannot be
+    # collected inside this process, so the figure is the one of the committed profile -- tagged with where it comes from
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(f"{dom}@{W}x{H}x{N}")
+            traffic_src = tj.get("_source")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": (traffic_src or "profiles/traffic.json (committed PMC pass of an earlier run of this command, not this run)") if traffic else None,
                 "algorithmic_bytes": int(sb[dom]), "avg_ms": round(dom_ms, 4)}
     # what actually bounds that kernel: VALU issue utilisation from the committed PMC pass (profiles/*_pmc_instruction_mix.json)
     try:
@@ -246,11 +303,12 @@ def main():
     total_bytes = sum(sb[k] for k in stages if k in sb)
 
     out = {
-        "metric": "train_ghost_iters_per_sec", "value": round(value, 3), "unit": "iters/s", "n_gpus": world,
+        "metric": "train_ghost_iters_per_sec", "value": round(value, 3), "unit": "iters/s", "n_gpus": n_ranks,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"train_ghost {N} mesh-bound Gaussians, {W}x{H}, {args.views} synthetic views, "
-                               f"SH degree 3, L1+D-SSIM, Adam, fixed N (no densification)",
+                               f"SH degree 3, L1+D-SSIM, Adam, fixed N (no densification), "
+                               + ("fixed FLAME sequence" if args.frozen_flame else "FLAME-parameter fine-tuning on (upstream default): FLAME LBS + frames + their backward in every step"),
                    "n_gaussians": N, "width": W, "height": H, "views": args.views, "tile_pairs_D": D,
                    "parallelism": (f"dp{world} (views sharded; RCCL all-reduce of 14 planes = {14 * trainer.model.n_pad * 4 / 1e6:.1f} MB "
                                    f"+ all-gather of {3 * trainer.model.n_pad * 4 / 1e6:.1f} MB dL/dcolour per rank, 45 SH planes rebuilt locally)"
@@ -321,9 +379,10 @@ def main():
             out["aux"]["hbm_copy_gbs"] = round(10 * 2 * src.numel() * 4 / (time.perf_counter() - t3) / 1e9, 1)
             del src, dst
             log("png / copy aux done")
-            # the same training step with upstream's FLAME-parameter fine-tuning switched on (not the headline config)
+            # the same training step with the other setting of the FLAME switch (--not_finetune_flame_params: fixed sequence,
+            # triangle frames resident) -- not the headline
             del rr
-            tf = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3, finetune_flame=True)
+            tf = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3, finetune_flame=args.frozen_flame)
             for _ in range(20):
                 tf.step()
             torch.cuda.synchronize()
@@ -331,9 +390,10 @@ def main():
             for _ in range(100):
                 tf.step()
             torch.cuda.synchronize()
-            out["aux"]["train_iters_per_sec_with_flame_finetune"] = round(100 / (time.perf_counter() - t4), 2)
+            key = "train_iters_per_sec_with_flame_finetune" if args.frozen_flame else "train_iters_per_sec_fixed_flame_sequence"
+            out["aux"][key] = round(100 / (time.perf_counter() - t4), 2)
             del tf
-            log("flame fine-tune aux done")
+            log("flame switch aux done")
             # flame_fitter.fit_flame_to_landmarks (reference flame_fitter.py:294-444) on 300 frames of synthetic landmarks:
             # HIP SimpleFLAME forward/backward vs the PyTorch-CPU port of the reference's loop (oracle/simple_flame.py)
             import contextlib
@@ -374,15 +434,13 @@ def main():
 
     # ---- CPU baseline (rank 0, single GPU run only): the PyTorch-CPU oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_s, w_s, h_s = 200000, 1120, 630    # ~15 s of CPU work on 16 cores
-        sec, D_s = cpu_baseline_train(n_s, w_s, h_s)
+        sec, D_s = cpu_baseline_train(N, W, H, args.views)
         log(f"cpu baseline done: {sec:.2f}s")
-        scale = D_s / max(D, 1)
         out["cpu_baseline"] = {
-            "value": round((1.0 / sec) * scale, 6), "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"PyTorch-CPU oracle (oracle/torch_splat.py), 1 full iteration at {n_s} Gaussians {w_s}x{h_s} "
-                      f"(D={D_s} tile pairs) took {sec:.2f} s; value extrapolated to the bench workload by the "
-                      f"tile-pair ratio D_sample/D = {scale:.5f}",
+            "value": round(1.0 / sec, 6), "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 full training iteration of the bench workload itself, not extrapolated ({N} Gaussians {W}x{H}, D={D_s} tile pairs, "
+                      f"FLAME fine-tuning on): pose/project/bin/sort by the C oracle (oracle/splat_oracle.c, 1 core), composite + "
+                      f"L1/D-SSIM + autograd backward + Adam by the PyTorch-CPU oracle (oracle/torch_splat.py, {torch.get_num_threads()} threads): {sec:.2f} s",
             "sample_seconds": round(sec, 3)}
     if world > 1:
         from omfs_4d_video_gen_amd.engine.distributed import replicas_in_sync

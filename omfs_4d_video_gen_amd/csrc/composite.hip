@@ -198,13 +198,14 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
       m &= m - 1ull;
       jn = __builtin_ctzll(m | (1ull << 63));    // m == 0: any staged entry will do, it is not used
       nx0 = s0[jn]; nx1 = s1[jn]; nx2 = s2[jn];
+#ifdef OMFS_DEBUG_COUNTERS
       {
         const float dx_ = a.x - fx, dy_ = a.y - fy;
         const float p2_ = fma_(a.z * dx_, dx_, fma_(c.x * dy_, dy_, a.w * dx_ * dy_));
         const unsigned long long hb = __ballot(!done && p2_ <= 0.f && p2_ + c.y >= LOG2_INV255);
-        (void)hb;
         OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb));
       }
+#endif
       if (!done) {
         const float dx = a.x - fx, dy = a.y - fy;
         const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
@@ -300,13 +301,19 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
   if (tend - tbeg <= (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG)) return;
   const int quad = blockIdx.x & 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const size_t slot0 = (size_t)(tbeg / OMFS_SEG) + tile;
+  const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  // A quadrant wholly outside the image was left by composite_fwd_kernel before it wrote a hand-over: its slot holds
+  // whatever an earlier view left there.  Lanes outside the image are never live (the hand-over of a partly inside
+  // quadrant already excludes them; the mask below makes that independent of the slot's content).
+  const unsigned long long in_img = __ballot(px < cam.width && py < cam.height);
+  if (in_img == 0ull) return;
   const float4 hand = seg_ckpt[slot0 * 256 + quad * 64];
   unsigned long long live = (unsigned long long)__float_as_uint(hand.x) | ((unsigned long long)__float_as_uint(hand.y) << 32);
   live = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)live) |
          ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(live >> 32)) << 32);   // wave-uniform
+  live &= in_img;
   if (live == 0ull) return;
-  const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
-  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const float fx = (float)px, fy = (float)py;
   const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);

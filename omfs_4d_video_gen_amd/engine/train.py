@@ -9,9 +9,9 @@ Outputs (what `render_surgery.py:271-287` and `train_ghost.py:141-156` look for)
   M/point_cloud/iteration_<it>/point_cloud.ply (+ flame_param.npz), M/chkpnt<it>.pth, M/cfg_args.json.
 Progress lines contain "iteration <n>" for the UI regex (`app.py:1387-1398`).
 Multi-GPU: launch with torch.distributed.run; views shard across ranks, gradients are all-reduced.
-`--finetune_flame_params` optimises the per-timestep FLAME expression / poses / translation with the Gaussians
-(upstream's default for --bind_to_mesh; opt-in here, `--not_finetune_flame_params` is accepted and ignored): the tuned
-sequence is saved as point_cloud/iteration_<it>/flame_param.npz next to flame_param_source.npz (as loaded), and
+The per-timestep FLAME expression / poses / translation are optimised with the Gaussians BY DEFAULT, as upstream does for
+--bind_to_mesh (the reference's argv passes no opt-out, `train_ghost.py:227-237`); `--not_finetune_flame_params` keeps the
+sequence fixed (`--finetune_flame_params` is accepted for older command lines): the tuned sequence is saved as point_cloud/iteration_<it>/flame_param.npz next to flame_param_source.npz (as loaded), and
 render.py applies "tuned + (dataset - source)" so that render_surgery's edits still act on the tuned sequence.
 `--start_checkpoint M/chkpnt<it>.pth` resumes (parameters, Adam moments, SH degree, FLAME state, iteration).
 """
@@ -54,8 +54,8 @@ def parse(argv=None):
     p.add_argument("--max_gaussians", type=int, default=0, help="capacity for densification (0 = 4x the initial count)")
     p.add_argument("--no_densify", action="store_true")
     p.add_argument("--log_every", type=int, default=100)
-    p.add_argument("--finetune_flame_params", action="store_true")
-    p.add_argument("--not_finetune_flame_params", action="store_true", help="accepted for upstream compatibility (the default here)")
+    p.add_argument("--finetune_flame_params", action="store_true", help="the default (accepted for older command lines)")
+    p.add_argument("--not_finetune_flame_params", action="store_true", help="keep the FLAME sequence fixed (upstream's opt-out)")
     p.add_argument("--flame_expr_lr", type=float, default=1e-3)
     p.add_argument("--flame_pose_lr", type=float, default=1e-5)
     p.add_argument("--flame_trans_lr", type=float, default=1e-6)
@@ -65,6 +65,9 @@ def parse(argv=None):
     args, unknown = p.parse_known_args(argv)
     if unknown:
         print(f"[engine] ignoring unknown arguments: {unknown}")
+    if args.finetune_flame_params and args.not_finetune_flame_params:
+        p.error("--finetune_flame_params and --not_finetune_flame_params exclude each other")
+    args.finetune_flame_params = not args.not_finetune_flame_params
     return args
 
 
@@ -215,10 +218,13 @@ def main(argv=None):
             if rank == 0:
                 print(f"Training progress: iteration {it}/{args.iterations} loss={trainer.loss_value():.5f} "
                       f"({(it - it0) / (time.time() - t0):.1f} it/s)", flush=True)
-            if it % (10 * args.log_every) == 0 and trainer.rast.overflowed():
-                new_cap = trainer.rast.grow_dup_capacity(2.0)      # every rank sees the same schedule of views, hence the same overflow
-                if rank == 0:
-                    print(f"[ITER {it}] tile-list capacity exceeded: grown to {new_cap} pairs", flush=True)
+            # Tile-list capacity: an overflowed iteration rendered the background only (the scan empties every list), so it is
+            # looked for at every log interval -- loss_value() above has synced the host already.  Ranks render different
+            # views and overflow independently; no collective is involved, each rank grows its own buffers.
+            if trainer.rast.overflowed():
+                new_cap = trainer.rast.grow_dup_capacity(2.0)
+                print(f"[ITER {it}] rank {rank}: tile-list capacity exceeded within the last {args.log_every} iterations "
+                      f"(those rendered empty lists): grown to {new_cap} pairs", flush=True)
         if rank == 0 and it in save_at:
             print(f"\n[ITER {it}] Saving Gaussians", flush=True)
             g = trainer.model.to_dict()

@@ -238,9 +238,11 @@ def tile_lists(proj: dict, width: int, height: int, cull: bool = True):
     return lists
 
 
-def composite(proj: dict, lists, width: int, height: int, bg):
+def composite(proj: dict, lists, width: int, height: int, bg, tiles=None):
     """Front-to-back alpha compositing, exact order, vectorised per tile.
-    Returns image (3,H,W), final_T (H,W), n_contrib (H,W) int32."""
+    Returns image (3,H,W), final_T (H,W), n_contrib (H,W) int32.
+    tiles (optional set of tile indices): only these tiles are composited, every other tile shows the background
+    (full-size checks of a fixed tile subset: the autograd graph then holds those tiles only)."""
     gx, gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
     bg = torch.as_tensor(bg, dtype=torch.float32)
     img = torch.zeros(3, gy * TILE, gx * TILE)
@@ -252,7 +254,9 @@ def composite(proj: dict, lists, width: int, height: int, bg):
         cols = []
         for tx in range(gx):
             ids = lists[ty * gx + tx]
-            if not ids:
+            if tiles is not None and (ty * gx + tx) not in tiles:
+                ids = []
+            if len(ids) == 0:
                 cols.append((bg[:, None, None].expand(3, TILE, TILE), torch.ones(TILE, TILE), torch.zeros(TILE, TILE, dtype=torch.int32)))
                 continue
             idt = torch.as_tensor(ids, dtype=torch.long)
@@ -294,14 +298,25 @@ def composite(proj: dict, lists, width: int, height: int, bg):
     return img, fT, ncon
 
 
-def render(rig: dict, g: dict, frame: dict, cam: dict, bg=(0.0, 0.0, 0.0), sh_degree: int = 3):
-    """One frame: FLAME -> face frames -> deform/project -> bin/sort -> composite."""
+def lists_from_offsets(tile_start, ids):
+    """The C oracle's (= the engine's, bit for bit) tile-segmented id array as the per-tile lists composite() takes."""
+    ts = [int(x) for x in tile_start]
+    return [ids[ts[t]:ts[t + 1]].astype("int64") for t in range(len(ts) - 1)]
+
+
+def render(rig: dict, g: dict, frame: dict, cam: dict, bg=(0.0, 0.0, 0.0), sh_degree: int = 3, lists=None, tiles=None):
+    """One frame: FLAME -> face frames -> deform/project -> bin/sort -> composite.
+    lists: per-tile id lists to composite instead of this module's own binning.  The order inside a tile is defined on
+    the DEPTH BITS (DESIGN.md "Binning"); this module's fp32 depths differ from the bit-level spec (oracle/splat_oracle.c)
+    in the last bit here and there, so two near-equal depths can swap -- handing over the C oracle's lists makes both
+    oracles composite in ONE order (the backward comparison then has no order noise).  tiles: see composite()."""
     verts = flame_lbs(rig, frame["shape"], frame["expr"][None], frame["rotmats"][None], frame["translation"][None],
                       frame.get("static_offset"), frame.get("dynamic_offset"))[0]
     R_f, c_f, s_f = face_frames(verts, rig["faces"].long())
     proj = deform_project(g, R_f, c_f, s_f, cam, sh_degree)
-    lists = tile_lists(proj, cam["width"], cam["height"])
-    img, fT, ncon = composite(proj, lists, cam["width"], cam["height"], bg)
+    if lists is None:
+        lists = tile_lists(proj, cam["width"], cam["height"])
+    img, fT, ncon = composite(proj, lists, cam["width"], cam["height"], bg, tiles)
     return {"image": img, "final_T": fT, "n_contrib": ncon, "proj": proj, "lists": lists, "verts": verts,
             "frames": (R_f, c_f, s_f)}
 

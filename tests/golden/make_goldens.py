@@ -10,7 +10,7 @@ What is captured: outputs of the reference's own pure functions
   * 02_Visual_Engine/train_ghost.py    : run_quality_gates matrix, dataset fingerprint, the engine
     argv / save-iteration rule / manifest schema of train()
   * 02_Visual_Engine/flame_fitter.py   : SimpleFLAME._axis_angle_to_matrix, SimpleFLAME.forward,
-    estimate_head_pose_from_landmarks, a 3-iteration fit_flame_to_landmarks on the synthetic rig
+    estimate_head_pose_from_landmarks, 1-, 3- and default-length (200) fit_flame_to_landmarks on the synthetic rig
 Only DATA is written (npz / json); no reference source text is stored.
 
 flame_fitter imports cv2 and mediapipe at module level; neither is used by the functions
@@ -254,10 +254,12 @@ def golden_flame_fitter(out):
     lmk2d[3] = None   # a frame without a detected face
     poses = [list(ff.estimate_head_pose_from_landmarks(l, (W, H))) for l in lmk2d]
     fits = {}
-    for iters in (1, 3):
+    for iters in (1, 3, 200):
         with redirect_stdout(io.StringIO()):
+            # 200 is the reference's default fit length (flame_fitter.py:302): that run is made WITHOUT the argument
+            kw = {} if iters == 200 else {"n_iters": iters}
             res = ff.fit_flame_to_landmarks([None if l is None else l.copy() for l in lmk2d], (W, H), str(pkl), n_shape=100, n_expr=50,
-                                            lr=0.01, n_iters=iters, device="cpu")
+                                            lr=0.01, device="cpu", **kw)
         fits[iters] = res
     np.savez_compressed(
         HERE / "flame_fitter_golden.npz", rig_seed=np.array([0]), axis_angle=aa, rotmats=R,

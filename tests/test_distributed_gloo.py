@@ -65,3 +65,28 @@ def test_two_rank_data_parallel_plumbing():
     assert all(a != b for a, b in zip(v0, v1)) and sorted(v0 + v1) == sorted(list(range(16)))
     assert sorted(f0 + f1) == list(range(11)) and not set(f0) & set(f1)
     assert s0 == s1
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher must start 2 ranks as children (torch.distributed.run on 127.0.0.1) and
+    exit with their code.  No GPU here: every rank reports that and exits 2 -- but both must have started."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    argv = bench.launcher_argv(4, 29511, ["--gpus", "4", "--steps", "3"])
+    assert argv[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in argv and "--nnodes=1" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert argv[argv.index("--master-port") + 2].endswith("bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert "rank 0/2 started" in r.stderr and "rank 1/2 started" in r.stderr, r.stderr[-2000:]
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0          # the children's failure is the parent's exit code
+    # a launcher that started another number of ranks than --gpus says is an error, not a mislabelled line
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
+                       env={**env, "WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stdout

@@ -75,3 +75,23 @@ def test_fit_matches_reference_goldens(setup, iters, capsys):
     assert "[flame_fitter] Fitting complete." in capsys.readouterr().out
     with pytest.raises(ValueError, match="No faces detected"):
         ff.fit_flame_to_landmarks([None, None], (W, H), pkl, device="cuda")
+
+
+def test_default_length_fit_matches_the_reference_run(setup, capsys):
+    """The reference's DEFAULT fit (n_iters=200, flame_fitter.py:302; the golden run was made without the argument) through
+    the device-side loop, called without n_iters too.  200 Adam steps let fp32 summation-order differences drift: the
+    tolerance is 2e-4 of each tensor's own range (absolute 2e-5 for the small ones), two orders below what the fit moves
+    the parameters by between iteration 3 and 200."""
+    ff, rig, pkl, gold = setup
+    W, H = [int(v) for v in gold["image_size"]]
+    lmk = [gold["lmk2d"][i].copy() if gold["lmk2d_valid"][i] else None for i in range(len(gold["lmk2d"]))]
+    res = ff.fit_flame_to_landmarks(lmk, (W, H), pkl, n_shape=100, n_expr=50, lr=0.01, device="cuda")
+    for k in ("shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
+        want = gold[f"fit200_{k}"]
+        assert res[k].shape == want.shape and res[k].dtype == want.dtype, k
+        moved = np.abs(want - gold[f"fit3_{k}"]).max()
+        d = np.abs(res[k] - want).max()
+        assert d <= 2e-5 + 2e-4 * np.abs(want).max(), (k, d)
+        assert moved == 0 or d < 0.02 * moved, (k, d, moved)
+    out = capsys.readouterr().out
+    assert "/200 — loss:" in out and "[flame_fitter] Fitting complete." in out

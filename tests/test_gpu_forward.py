@@ -210,3 +210,37 @@ def test_renderer_poses_flame_in_batches_with_identical_frames():
         assert torch.equal(a, b), t
     torch.cuda.synchronize()
     many.rast.check_status()
+
+
+def test_deep_forward_bottom_row_outside_quadrants_with_reused_buffers():
+    """Image height not a multiple of 16 (72 = 4*16 + 8: quadrants 2 and 3 of the bottom tile row lie wholly outside the
+    image), bottom-row tiles with lists deeper than the one-wave forward walks, and ONE Rasterizer reused for two views so
+    that the hand-over slots of the second view hold the first view's checkpoints.  The image must equal the oracle's and
+    nothing may be written behind image / final_T / n_contrib (guard words)."""
+    from omfs_4d_video_gen_amd import _lib as L
+    from omfs_4d_video_gen_amd.engine.gaussians import pack_params
+    from oracle import c_oracle as CO
+    n, width, height = 30000, 96, 72
+    rig, g, seq, _, dflame, model, rast, mk = _setup(n, width, height)
+    P, guard = width * height, 4096
+    img_buf = torch.full((3 * P + guard,), 7.0, device="cuda")
+    ft_buf = torch.full((P + guard,), 7.0, device="cuda")
+    nc_buf = torch.full((P + guard,), 77, dtype=torch.int32, device="cuda")
+    rast.image, rast.final_T, rast.n_contrib = img_buf[:3 * P].view(3, height, width), ft_buf[:P].view(height, width), nc_buf[:P].view(height, width)
+    rast.rb.image, rast.rb.final_T, rast.rb.n_contrib = L.ptr(rast.image), L.ptr(rast.final_T), L.ptr(rast.n_contrib)
+    for t, yaw in ((0, -0.5), (2, 0.4), (1, 0.1)):
+        cam = synthetic.make_camera(width, height, yaw=yaw, fill=1.7)     # the head overflows the image: dense bottom row
+        ccam = mk(cam, sh_degree=3, bg=(0.1, 0.2, 0.3))
+        _, face_xf = dflame.face_frames(t, 1)
+        img = rast.forward(model, face_xf[0], ccam)
+        torch.cuda.synchronize()
+        rast.check_status()
+        ts = rast.tile_start.cpu().numpy().astype(np.int64)
+        bottom = np.diff(ts)[-rast.gx:]
+        assert int(bottom.max()) > 512, "the bottom tile row must reach the deep forward"
+        ref = CO.render(dflame, t, pack_params(g), g["binding"], n, CO.camera(ccam))
+        assert np.array_equal(rast.sorted_ids.cpu().numpy().view(np.uint32)[:ts[-1]], ref["ids"])
+        assert np.abs(img.cpu().numpy() - ref["image"]).mean() < 1e-4
+        assert float(np.abs(rast.final_T.cpu().numpy() - ref["final_T"]).max()) < 2e-3
+        assert bool((img_buf[3 * P:] == 7.0).all()) and bool((ft_buf[P:] == 7.0).all()) and bool((nc_buf[P:] == 77).all()), \
+            "write behind the end of a per-pixel buffer"

@@ -218,7 +218,7 @@ def test_head_pose_heuristic_matches_reference(ff_gold):
         assert np.allclose(got, ff_gold["head_pose_init"][i], rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize("iters", [1, 3])
+@pytest.mark.parametrize("iters", [1, 3, 200])      # 200 = the reference's default fit length (flame_fitter.py:302)
 def test_simpleflame_oracle_fit_matches_reference(ff_gold, rig_small, iters):
     from oracle.simple_flame import SimpleFlameOracle, fit
     W, H = [int(v) for v in ff_gold["image_size"]]
