@@ -54,6 +54,91 @@ def pose_rotmats(flame_params: dict) -> np.ndarray:
     return rodrigues(torch.from_numpy(aa)).reshape(T, 5, 3, 3).numpy()
 
 
+N_TEETH_COLS = 15      # vertices per teeth row (= vertices of a lip ring)
+N_TEETH_VERTS = 8 * N_TEETH_COLS     # 120: FLAME's 5023 + 120 = the 5143 of static_offset (flame_fitter.py:439-440)
+N_TEETH_FACES = 6 * 2 * (N_TEETH_COLS - 1)   # 168
+
+
+def add_teeth(v_template, shapedirs, posedirs, J_regressor, weights, faces, lip_upper, lip_lower, inset: float = 0.004) -> dict:
+    """Append upstream's procedural teeth to a FLAME rig: 120 vertices and 168 faces [NOT IN REFERENCE: the reference
+    only fixes the vertex count, `static_offset (1,5143,3)` at flame_fitter.py:439; the construction follows the
+    GaussianAvatars paper's description -- two arches derived from the lip rings, the upper one rigid with the head, the
+    lower one rigid with the jaw].
+
+    lip_upper / lip_lower: 15 vertex ids each, corresponding column by column.  With d = mean distance between the
+    rings, the arches start from the rings' midline (height levelled, pushed `inset` metres into the mouth):
+      rows 0..7 = upper root, lower root, upper edge, lower edge (front faces), then upper root, upper edge, lower root,
+      lower edge again 0.5 d further back -- edges 0.1 d above / below the midline, roots 2 d beyond the edges, the
+      lower arch another 0.1 d inside the upper one.
+    Rig arrays of the new vertices: the SHAPE blendshapes (first 300 directions) of the lip vertex above / below, no
+    expression and no pose-corrective displacement, no weight in the joint regressor, skinning weight 1 on the neck
+    joint (index 1: the head) for the upper arch and on the jaw joint (index 2) for the lower arch.
+    Faces: three quad strips per arch (front, biting edge, back), 14 quads each."""
+    v = np.asarray(v_template, np.float32)
+    V = v.shape[0]
+    up, low = np.asarray(lip_upper, np.int64).reshape(-1), np.asarray(lip_lower, np.int64).reshape(-1)
+    if up.shape != (N_TEETH_COLS,) or low.shape != (N_TEETH_COLS,):
+        raise ValueError(f"teeth need two lip rings of {N_TEETH_COLS} vertices")
+    vu, vl = v[up].astype(np.float64), v[low].astype(np.float64)
+    d = float(np.linalg.norm(vu - vl, axis=1).mean())
+    mid = 0.5 * (vu + vl)
+    mid[:, 1] = mid[:, 1].mean()
+    mid[:, 2] -= inset
+    ey, ez = np.array([0.0, 1.0, 0.0]), np.array([0.0, 0.0, 1.0])
+    u_edge = mid + 0.1 * d * ey
+    u_root = u_edge + 2.0 * d * ey
+    l_edge = mid - 0.1 * d * ey - 0.1 * d * ez
+    l_root = l_edge - 2.0 * d * ey
+    back = -0.5 * d * ez
+    rows = [u_root, l_root, u_edge, l_edge, u_root + back, u_edge + back, l_root + back, l_edge + back]
+    is_upper = [True, False, True, False, True, True, False, False]
+    n_new = N_TEETH_VERTS
+    sd, pd = np.asarray(shapedirs, np.float32), np.asarray(posedirs, np.float32)
+    sd_new = np.zeros((n_new,) + sd.shape[1:], np.float32)
+    w_new = np.zeros((n_new, 5), np.float32)
+    for r, upper in enumerate(is_upper):
+        sl = slice(r * N_TEETH_COLS, (r + 1) * N_TEETH_COLS)
+        sd_new[sl, :, :N_SHAPE_MAX] = sd[up if upper else low][:, :, :N_SHAPE_MAX]
+        w_new[sl, 1 if upper else 2] = 1.0
+    row0 = lambda r: V + r * N_TEETH_COLS
+    strips = [(0, 2), (2, 5), (5, 4),      # upper: front (root -> edge), biting edge (front -> back), back (edge -> root)
+              (3, 1), (7, 3), (6, 7)]      # lower: front (edge -> root), biting edge (back -> front), back (root -> edge)
+    f_new = []
+    for ra, rb in strips:
+        for c in range(N_TEETH_COLS - 1):
+            a, b, cc, dd = row0(ra) + c, row0(ra) + c + 1, row0(rb) + c, row0(rb) + c + 1
+            f_new += [(a, b, dd), (a, dd, cc)]
+    jr = np.asarray(J_regressor, np.float32)
+    return {
+        "v_template": np.concatenate([v, np.concatenate(rows, 0).astype(np.float32)], 0),
+        "shapedirs": np.concatenate([sd, sd_new], 0),
+        "posedirs": np.concatenate([pd, np.zeros((n_new,) + pd.shape[1:], np.float32)], 0),
+        "J_regressor": np.concatenate([jr, np.zeros((jr.shape[0], n_new), np.float32)], 1),
+        "weights": np.concatenate([np.asarray(weights, np.float32), w_new], 0),
+        "faces": np.concatenate([np.asarray(faces, np.int32), np.asarray(f_new, np.int32)], 0),
+    }
+
+
+def lip_rings_from_masks(masks_path: str, v_template: np.ndarray):
+    """Lip rings for the released FLAME topology from the `lips` region of FLAME_masks.pkl (the file upstream ships next
+    to the model): the region's vertices are split at the mouth's mean height, each half is ordered along x and cut into
+    15 equally populated columns, and the front-most (largest z) vertex of each column is taken.  Returns (upper, lower)
+    or None when a half holds fewer than 15 vertices.  [Could not be checked against the licensed asset in this build.]"""
+    with open(masks_path, "rb") as f:
+        masks = pickle.load(f, encoding="latin1")
+    lips = np.asarray(masks["lips"], np.int64).reshape(-1)
+    vv = np.asarray(v_template, np.float64)[lips]
+    y_mid = vv[:, 1].mean()
+    out = []
+    for half in (vv[:, 1] >= y_mid, vv[:, 1] < y_mid):
+        cand = np.nonzero(half)[0]
+        if cand.size < N_TEETH_COLS:
+            return None
+        cand = cand[np.argsort(-vv[cand, 0], kind="stable")]          # +x first, like the synthetic rings
+        out.append(np.asarray([int(lips[c[np.argmax(vv[c, 2])]]) for c in np.array_split(cand, N_TEETH_COLS)], np.int64))
+    return out[0], out[1]
+
+
 class FlameRig:
     """Static rig arrays (host, numpy) in FLAME-pickle conventions."""
 
@@ -85,17 +170,30 @@ class FlameRig:
         return cls(rig.v_template, rig.shapedirs, rig.posedirs, rig.J_regressor, rig.weights, rig.faces)
 
     @classmethod
-    def from_pickle(cls, path: str):
-        """Same keys `SimpleFLAME.__init__` reads (`flame_fitter.py:80-120`) plus `posedirs`."""
+    def from_pickle(cls, path: str, lip_rings=None, masks_path: str | None = None):
+        """Same keys `SimpleFLAME.__init__` reads (`flame_fitter.py:80-120`) plus `posedirs`.
+        The pickle holds FLAME's 5023 vertices; the 120 teeth vertices of upstream's head are appended (`add_teeth`)
+        when the lip rings are known: given as `lip_rings` (upper ids, lower ids), or derived from `masks_path` /
+        `FLAME_masks.pkl` next to the model.  Without them the rig keeps the pickle's vertex count (datasets carrying
+        5143-row offsets then use the leading rows, see DeviceFlame)."""
+        import os
         m = load_flame_pickle(path)
         jr = m["J_regressor"]
         jr = np.asarray(jr.todense() if hasattr(jr, "todense") else jr, np.float32)
         kt = np.asarray(m["kintree_table"], np.int64)
         parents = kt[0].copy()
         parents[0] = -1
-        return cls(np.asarray(m["v_template"], np.float32), np.asarray(m["shapedirs"], np.float32),
-                   np.asarray(m["posedirs"], np.float32), jr, np.asarray(m["weights"], np.float32),
-                   np.asarray(m["f"], np.int64).astype(np.int32), parents)
+        arrays = {"v_template": np.asarray(m["v_template"], np.float32), "shapedirs": np.asarray(m["shapedirs"], np.float32),
+                  "posedirs": np.asarray(m["posedirs"], np.float32), "J_regressor": jr, "weights": np.asarray(m["weights"], np.float32),
+                  "faces": np.asarray(m["f"], np.int64).astype(np.int32)}
+        if lip_rings is None:
+            cand = masks_path or os.path.join(os.path.dirname(os.path.abspath(path)), "FLAME_masks.pkl")
+            if os.path.exists(cand):
+                lip_rings = lip_rings_from_masks(cand, arrays["v_template"])
+        if lip_rings is not None:
+            arrays = add_teeth(**arrays, lip_upper=lip_rings[0], lip_lower=lip_rings[1])
+        return cls(arrays["v_template"], arrays["shapedirs"], arrays["posedirs"], arrays["J_regressor"], arrays["weights"],
+                   arrays["faces"], parents)
 
 
 class _ChumpyArray:

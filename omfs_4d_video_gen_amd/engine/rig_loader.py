@@ -21,7 +21,15 @@ def load_rig(n_verts_hint: int | None = None) -> FlameRig:
     explicit = os.environ.get("OMFS_FLAME_PKL")
     for cand in ([Path(explicit)] if explicit else []) + [FLAME_MODEL_PATH]:
         if cand.exists():
-            return FlameRig.from_pickle(str(cand))
+            # teeth: lip rings from $OMFS_FLAME_LIP_RINGS (npz with `upper`, `lower`: 15 vertex ids each), else from
+            # FLAME_masks.pkl next to the model (flame_rig.lip_rings_from_masks), else the rig keeps the pickle's 5023 vertices
+            rings = os.environ.get("OMFS_FLAME_LIP_RINGS")
+            lip = None
+            if rings:
+                import numpy as np
+                z = np.load(rings)
+                lip = (z["upper"], z["lower"])
+            return FlameRig.from_pickle(str(cand), lip_rings=lip)
     if os.environ.get("OMFS_SYNTHETIC_RIG") == "1":
         from . import synthetic
         return FlameRig.from_synthetic(synthetic.make_rig(int(os.environ.get("OMFS_SYNTHETIC_RIG_SEED", "0"))))

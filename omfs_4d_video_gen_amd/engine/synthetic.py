@@ -2,9 +2,10 @@
 
 The real FLAME weights are licensed and git-ignored by the reference
 (`/root/reference/.gitignore:28-29`), so every test / bench input is generated here,
-following SURVEY.md §8(d) "Synthetic inputs": an ellipsoid head with V = 5143 vertices
-(53 rings x 97 segments + 2 poles; the 5143 matches `static_offset (1,5143,3)` at
-`02_Visual_Engine/flame_fitter.py:439`), 400 blendshape directions (300 shape + 100
+following SURVEY.md §8(d) "Synthetic inputs": an ellipsoid head with FLAME's 5023 vertices (top pole + 54 rings x 93
+segments, open at the neck) to which the engine appends the 120 procedural teeth vertices of upstream's head
+(`flame_rig.add_teeth`), V = 5143 as `static_offset (1,5143,3)` at `02_Visual_Engine/flame_fitter.py:439` says;
+400 blendshape directions (300 shape + 100
 expression, `flame_fitter.py:89-92`), 36 pose-corrective directions, and 5 joints
 (root, neck, jaw, eye-L, eye-R; `flame_fitter.py:8-11`).
 
@@ -18,9 +19,11 @@ from dataclasses import dataclass
 
 import numpy as np
 
-V_FLAME = 5143
-N_RINGS = 53
-N_SEGS = 97
+V_BASE = 5023          # vertices of the FLAME pickle itself
+N_TEETH = 120          # procedural teeth vertices appended by flame_rig.add_teeth (upstream's head has 5023 + 120)
+V_FLAME = V_BASE + N_TEETH   # 5143: the vertex count of static_offset / dynamic_offset, flame_fitter.py:439-440
+N_RINGS = 54
+N_SEGS = 93
 N_SHAPE = 300
 N_EXPR = 100
 N_POSEDIRS = 36
@@ -30,7 +33,8 @@ HEAD_RADII = (0.09, 0.12, 0.10)
 
 
 def ellipsoid_mesh(radii=HEAD_RADII, rings=N_RINGS, segs=N_SEGS):
-    """UV ellipsoid: rings*segs + 2 vertices, 2*rings*segs faces (CCW seen from outside)."""
+    """UV ellipsoid, open at the bottom like FLAME's neck: top pole + rings*segs vertices (1 + 54*93 = 5023),
+    segs + 2*(rings-1)*segs faces (CCW seen from outside)."""
     rx, ry, rz = radii
     verts = [(0.0, ry, 0.0)]
     for r in range(rings):
@@ -38,15 +42,13 @@ def ellipsoid_mesh(radii=HEAD_RADII, rings=N_RINGS, segs=N_SEGS):
         for s in range(segs):
             ph = 2.0 * math.pi * s / segs
             verts.append((rx * math.sin(th) * math.cos(ph), ry * math.cos(th), rz * math.sin(th) * math.sin(ph)))
-    verts.append((0.0, -ry, 0.0))
     verts = np.asarray(verts, dtype=np.float64)
     faces = []
-    top, bot = 0, rings * segs + 1
+    top = 0
     ring0 = lambda r: 1 + r * segs
     for s in range(segs):
         s1 = (s + 1) % segs
         faces.append((top, ring0(0) + s1, ring0(0) + s))
-        faces.append((bot, ring0(rings - 1) + s, ring0(rings - 1) + s1))
     for r in range(rings - 1):
         for s in range(segs):
             s1 = (s + 1) % segs
@@ -55,6 +57,15 @@ def ellipsoid_mesh(radii=HEAD_RADII, rings=N_RINGS, segs=N_SEGS):
             faces.append((a, b, d))
             faces.append((a, d, c))
     return verts.astype(np.float32), np.asarray(faces, dtype=np.int32)
+
+
+def lip_rings(rings=N_RINGS, segs=N_SEGS):
+    """The two rows of 15 vertices the teeth are built from (upper lip, lower lip): adjacent rings a third of the way
+    below the equator, 15 consecutive segments centred on the front (+z) meridian."""
+    r_up = int(round(math.acos(-0.3) * (rings + 1) / math.pi)) - 1
+    s0 = int(round(segs / 4.0)) - 7
+    seg = np.arange(s0, s0 + 15)
+    return (1 + r_up * segs + seg).astype(np.int64), (1 + (r_up + 1) * segs + seg).astype(np.int64)
 
 
 @dataclass
@@ -69,6 +80,10 @@ class SyntheticRig:
     faces: np.ndarray           # (F,3) int32
     lmk_faces_idx: np.ndarray   # (68,) int64
     lmk_bary_coords: np.ndarray  # (68,3) f32
+    n_base_verts: int = V_BASE  # the leading vertices / faces are what the FLAME pickle holds; the rest are the teeth
+    n_base_faces: int = 0
+    lip_upper: np.ndarray | None = None   # (15,) vertex ids the teeth were derived from
+    lip_lower: np.ndarray | None = None
 
 
 def _smooth_fields(rng, v: np.ndarray, k: int, std: float) -> np.ndarray:
@@ -88,7 +103,7 @@ def make_rig(seed: int = 0, shape_std: float = 1e-3, pose_std: float = 1e-4) -> 
     rng = np.random.default_rng(seed)
     v, f = ellipsoid_mesh()
     V = v.shape[0]
-    assert V == V_FLAME
+    assert V == V_BASE
     shapedirs = _smooth_fields(rng, v, N_SHAPE + N_EXPR, shape_std)
     posedirs = _smooth_fields(rng, v, N_POSEDIRS, pose_std)
     rx, ry, rz = HEAD_RADII
@@ -115,7 +130,12 @@ def make_rig(seed: int = 0, shape_std: float = 1e-3, pose_std: float = 1e-4) -> 
     lmk_f = np.sort(rng.choice(front, size=68, replace=False)).astype(np.int64)
     bary = rng.random((68, 3)) + 0.2
     bary = (bary / bary.sum(1, keepdims=True)).astype(np.float32)
-    return SyntheticRig(v, shapedirs, posedirs, jr.astype(np.float32), w.astype(np.float32), kintree, f, lmk_f, bary)
+    # the head the engine works on: the pickle's 5023 vertices + the 120 procedural teeth vertices (flame_rig.add_teeth)
+    from .flame_rig import add_teeth
+    up, low = lip_rings()
+    t = add_teeth(v, shapedirs, posedirs, jr.astype(np.float32), w.astype(np.float32), f, up, low)
+    return SyntheticRig(t["v_template"], t["shapedirs"], t["posedirs"], t["J_regressor"], t["weights"], kintree, t["faces"],
+                        lmk_f, bary, V, f.shape[0], up, low)
 
 
 def write_flame_pickle(rig: SyntheticRig, pkl_path: str, lmk_npy_path: str | None = None) -> None:
@@ -124,14 +144,15 @@ def write_flame_pickle(rig: SyntheticRig, pkl_path: str, lmk_npy_path: str | Non
     `.todense()`), weights, kintree_table, f; landmark npy: dict with
     `full_lmk_faces_idx`, `full_lmk_bary_coords`."""
     import scipy.sparse as sp
+    nv, nf = rig.n_base_verts, rig.n_base_faces     # the pickle holds FLAME itself: no teeth
     model = {
-        "v_template": rig.v_template.astype(np.float64),
-        "shapedirs": rig.shapedirs.astype(np.float64),
-        "posedirs": rig.posedirs.astype(np.float64),
-        "J_regressor": sp.csc_matrix(rig.J_regressor.astype(np.float64)),
-        "weights": rig.weights.astype(np.float64),
+        "v_template": rig.v_template[:nv].astype(np.float64),
+        "shapedirs": rig.shapedirs[:nv].astype(np.float64),
+        "posedirs": rig.posedirs[:nv].astype(np.float64),
+        "J_regressor": sp.csc_matrix(rig.J_regressor[:, :nv].astype(np.float64)),
+        "weights": rig.weights[:nv].astype(np.float64),
         "kintree_table": rig.kintree_table,
-        "f": rig.faces.astype(np.uint32),
+        "f": rig.faces[:nf].astype(np.uint32),
     }
     with open(pkl_path, "wb") as fh:
         pickle.dump(model, fh, protocol=2)

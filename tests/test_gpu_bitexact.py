@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 
 # the last case is BASELINE.json's full size: the C oracle renders it in well under a minute on one host core
 @pytest.mark.parametrize("n,width,height,yaw,seed", [(4000, 160, 120, 0.3, 1), (20000, 320, 256, -0.7, 2), (2500, 100, 52, 0.0, 5),
-                                                     (300000, 1920, 1080, 0.35, 0)])
+                                                     (100000, 512, 512, 0.0, 3),          # BASELINE config 2
+                                                     (300000, 1920, 1080, 0.35, 0),       # configs 3 / 4
+                                                     (500000, 1920, 1080, -0.2, 7)])      # config 5
 def test_bitexact_vs_c_oracle(n, width, height, yaw, seed):
     from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig, DeviceFlame
     from omfs_4d_video_gen_amd.engine.gaussians import GaussianModel, pack_params
@@ -26,6 +28,10 @@ def test_bitexact_vs_c_oracle(n, width, height, yaw, seed):
         # ... and one stack of 400 coincident Gaussians: more equal depths than a sort bucket takes (radix fallback)
         g[k][200:600] = g[k][200]
     seq = synthetic.make_flame_sequence(4, seed)
+    # full-length per-timestep offsets (T,5143,3) as in the reference's npz contract (flame_fitter.py:440): the 120 teeth
+    # rows are used like every other vertex's
+    seq["dynamic_offset"] = (np.random.default_rng(seed + 77).standard_normal((4, 5143, 3)) * 2e-4).astype(np.float32)
+    assert rig.v_template.shape[0] == 5143 and seq["static_offset"].shape == (1, 5143, 3)
     cam = synthetic.make_camera(width, height, yaw=yaw)
     dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq)
     model = GaussianModel(g)
