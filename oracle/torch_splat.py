@@ -238,11 +238,22 @@ def tile_lists(proj: dict, width: int, height: int, cull: bool = True):
     return lists
 
 
-def composite(proj: dict, lists, width: int, height: int, bg, tiles=None):
+NEAR_TOL = 2e-5     # |255 alpha - 1| below which a (Gaussian, pixel) pair counts as "on the 1/255 threshold"
+
+
+def composite(proj: dict, lists, width: int, height: int, bg, tiles=None, decide=None, diag=None):
     """Front-to-back alpha compositing, exact order, vectorised per tile.
     Returns image (3,H,W), final_T (H,W), n_contrib (H,W) int32.
     tiles (optional set of tile indices): only these tiles are composited, every other tile shows the background
-    (full-size checks of a fixed tile subset: the autograd graph then holds those tiles only)."""
+    (full-size checks of a fixed tile subset: the autograd graph then holds those tiles only).
+    decide (optional dict of float32 arrays mean2d (N,2), conic (N,3), opac (N,), e.g. the C oracle's projection): the
+    DISCRETE decisions of the algorithm -- which (Gaussian, pixel) pairs reach alpha >= 1/255, where a pixel stops -- are
+    taken from these values instead of this module's own projection, whose fp32 geometry differs from the bit-level spec
+    by up to ~1e-3 pixel on thin triangles, enough to flip pairs that sit on a threshold.  The composited VALUES (and so
+    the autograd graph) still come from `proj`.  The image is a discontinuous function of the parameters at those
+    thresholds; a comparison of gradients is only meaningful on one side of them.
+    diag (optional dict): receives `near_gaussians` (set of ids) and `near_pixels` (H,W bool): pairs whose alpha lies
+    within NEAR_TOL (relative) of 1/255, where two correct fp32 evaluations may still decide differently."""
     gx, gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
     bg = torch.as_tensor(bg, dtype=torch.float32)
     img = torch.zeros(3, gy * TILE, gx * TILE)
@@ -250,6 +261,10 @@ def composite(proj: dict, lists, width: int, height: int, bg, tiles=None):
     ncon = torch.zeros(gy * TILE, gx * TILE, dtype=torch.int32)
     yy, xx = torch.meshgrid(torch.arange(TILE, dtype=torch.float32), torch.arange(TILE, dtype=torch.float32), indexing="ij")
     rows = []
+    if decide is not None:
+        d_m, d_con, d_op = (torch.as_tensor(decide[k], dtype=torch.float32) for k in ("mean2d", "conic", "opac"))
+    near_g = set()
+    near_px = torch.zeros(gy * TILE, gx * TILE, dtype=torch.bool)
     for ty in range(gy):
         cols = []
         for tx in range(gx):
@@ -272,12 +287,28 @@ def composite(proj: dict, lists, width: int, height: int, bg, tiles=None):
             a_raw = op[:, None] * torch.exp(power)
             # value clamped at 0.99, gradient passed straight through (as the upstream rasteriser does)
             alpha = a_raw + (torch.clamp(a_raw, max=0.99) - a_raw).detach()
-            keep = (power <= 0) & (alpha >= 1.0 / 255.0)
+            if decide is None:
+                power_d, alpha_d = power.detach(), alpha.detach()
+            else:
+                px32, py32 = (xx + tx * TILE).reshape(1, -1), (yy + ty * TILE).reshape(1, -1)
+                ddx, ddy = d_m[idt, 0:1] - px32, d_m[idt, 1:2] - py32
+                dc = d_con[idt]
+                power_d = -0.5 * (dc[:, 0:1] * ddx * ddx + dc[:, 2:3] * ddy * ddy) - dc[:, 1:2] * ddx * ddy
+                alpha_d = torch.clamp(d_op[idt][:, None] * torch.exp(power_d), max=0.99)
+            keep = (power_d <= 0) & (alpha_d >= 1.0 / 255.0)
             a = torch.where(keep, alpha, torch.zeros_like(alpha))
             Tinc = torch.cumprod(1 - a, dim=0)
             Texc = torch.cat([torch.ones_like(Tinc[:1]), Tinc[:-1]], 0)
-            stop = (Tinc < 1e-4) & keep
+            if decide is None:
+                stop = (Tinc < 1e-4) & keep
+            else:
+                stop = (torch.cumprod(1 - torch.where(keep, alpha_d, torch.zeros_like(alpha_d)), dim=0) < 1e-4) & keep
             done = torch.cumsum(stop.to(torch.int32), 0) > 0        # this splat and all later excluded
+            if diag is not None:
+                near = ((alpha_d * 255.0 - 1.0).abs() < NEAR_TOL) & (power_d <= 0) & ~done
+                if bool(near.any()):
+                    near_g.update(idt[near.any(1)].tolist())
+                    near_px[ty * TILE:(ty + 1) * TILE, tx * TILE:(tx + 1) * TILE] |= near.any(0).reshape(TILE, TILE)
             w = torch.where(done, torch.zeros_like(a), a * Texc)
             C = torch.einsum("np,nc->cp", w, col)
             alive = ~done
@@ -295,6 +326,8 @@ def composite(proj: dict, lists, width: int, height: int, bg, tiles=None):
     img = torch.cat([r[0] for r in rows], 1)[:, :height, :width]
     fT = torch.cat([r[1] for r in rows], 0)[:height, :width]
     ncon = torch.cat([r[2] for r in rows], 0)[:height, :width]
+    if diag is not None:
+        diag["near_gaussians"], diag["near_pixels"] = near_g, near_px[:height, :width]
     return img, fT, ncon
 
 
@@ -304,19 +337,20 @@ def lists_from_offsets(tile_start, ids):
     return [ids[ts[t]:ts[t + 1]].astype("int64") for t in range(len(ts) - 1)]
 
 
-def render(rig: dict, g: dict, frame: dict, cam: dict, bg=(0.0, 0.0, 0.0), sh_degree: int = 3, lists=None, tiles=None):
+def render(rig: dict, g: dict, frame: dict, cam: dict, bg=(0.0, 0.0, 0.0), sh_degree: int = 3, lists=None, tiles=None,
+           decide=None, diag=None):
     """One frame: FLAME -> face frames -> deform/project -> bin/sort -> composite.
     lists: per-tile id lists to composite instead of this module's own binning.  The order inside a tile is defined on
     the DEPTH BITS (DESIGN.md "Binning"); this module's fp32 depths differ from the bit-level spec (oracle/splat_oracle.c)
     in the last bit here and there, so two near-equal depths can swap -- handing over the C oracle's lists makes both
-    oracles composite in ONE order (the backward comparison then has no order noise).  tiles: see composite()."""
+    oracles composite in ONE order (the backward comparison then has no order noise).  tiles, decide, diag: see composite()."""
     verts = flame_lbs(rig, frame["shape"], frame["expr"][None], frame["rotmats"][None], frame["translation"][None],
                       frame.get("static_offset"), frame.get("dynamic_offset"))[0]
     R_f, c_f, s_f = face_frames(verts, rig["faces"].long())
     proj = deform_project(g, R_f, c_f, s_f, cam, sh_degree)
     if lists is None:
         lists = tile_lists(proj, cam["width"], cam["height"])
-    img, fT, ncon = composite(proj, lists, cam["width"], cam["height"], bg, tiles)
+    img, fT, ncon = composite(proj, lists, cam["width"], cam["height"], bg, tiles, decide, diag)
     return {"image": img, "final_T": fT, "n_contrib": ncon, "proj": proj, "lists": lists, "verts": verts,
             "frames": (R_f, c_f, s_f)}
 

@@ -69,9 +69,14 @@ def check_backward_on_tile_subset(N, W, H, yaw, seed, t=2, n_heavy=16, n_other=4
     torch.cuda.synchronize()
 
     torch.set_num_threads(8)
+    from omfs_4d_video_gen_amd.engine.gaussians import pack_params
+    from oracle import c_oracle as CO
+    verts_c, _ = CO.flame_frame(dflame, t)
+    proj_c = CO.project(pack_params(g), g["binding"], CO.face_frames(verts_c, dflame.rig.faces), CO.camera(ccam), N)
     og = oracle_gaussians(g, requires_grad=True)
+    diag = {}
     ref = O.render(oracle_rig(rig), og, oracle_frame(seq, t), cam, bg=bg, sh_degree=3,
-                   lists=O.lists_from_offsets(ts, ids), tiles=set(tiles))
+                   lists=O.lists_from_offsets(ts, ids), tiles=set(tiles), decide=proj_c, diag=diag)
     img = rast.image.cpu()
     on = mask.bool()
     assert float((img[:, on] - ref["image"][:, on]).abs().mean()) < 1e-4
@@ -82,12 +87,30 @@ def check_backward_on_tile_subset(N, W, H, yaw, seed, t=2, n_heavy=16, n_other=4
     touched = np.unique(np.concatenate([ids[ts[tl]:ts[tl + 1]] for tl in tiles]))
     untouched = np.ones(N, bool)
     untouched[touched] = False
-    for name, gt in got.items():
-        r = og[name].grad.numpy()
-        scale = np.abs(r).max()
-        d = np.abs(gt - r)
-        assert d.max() <= 2e-3 * scale + 1e-7, f"{name}: max diff {d.max()} vs max ref {scale}"
-        assert d.sum() <= 2e-4 * np.abs(r).sum() + 1e-6, name
-        # Gaussians outside the chosen tiles receive the regularisers' gradient only
-        assert np.abs(gt[untouched] - r[untouched]).max() <= 1e-6 * max(scale, 1.0), name
+    want = {k: og[k].grad.numpy() for k in got}
+    assert_grads_close(got, want, diag["near_gaussians"], N)
+    for name, gt in got.items():       # Gaussians outside the chosen tiles receive the regularisers' gradient only
+        assert np.abs(gt[untouched] - want[name][untouched]).max() <= 1e-6 * max(np.abs(want[name]).max(), 1.0), name
     return rast, tiles
+
+
+def assert_grads_close(got: dict, want: dict, near_gaussians, n: int):
+    """Per parameter group: every element within 2e-3 of the group's largest reference gradient, the sum of the differences
+    within 2e-4 of the sum of the reference magnitudes.  The rendered image is DISCONTINUOUS in the parameters where a
+    (Gaussian, pixel) pair crosses alpha = 1/255 (the pair appears or vanishes with a weight of 0.4 %); one such pair
+    moves a Gaussian's gradient by about the per-element bound.  The oracle takes its decisions from the bit-level spec's
+    projection (torch_splat.composite `decide`), which removes every flip that geometry rounding could cause; what is left
+    are pairs within 2e-5 of the threshold (torch_splat.NEAR_TOL, 20x the difference between the engine's exp2-domain
+    alpha and the spec's expf) -- the Gaussians that own one are listed by the oracle, must be few, and get 2e-2."""
+    near = np.zeros(n, bool)
+    near[np.fromiter(near_gaussians, dtype=np.int64, count=len(near_gaussians))] = True
+    assert near.sum() <= max(4, n // 100), f"{int(near.sum())} of {n} Gaussians sit on the alpha threshold"
+    for name, gt in got.items():
+        r = want[name]
+        scale = np.abs(r).max()
+        d = np.abs(gt - r).reshape(n, -1).max(1)
+        worst = int(np.argmax(np.where(near, 0, d)))
+        assert d[~near].max() <= 2e-3 * scale + 1e-7, f"{name}: max diff {d[~near].max()} (Gaussian {worst}) vs max ref {scale}"
+        if near.any():
+            assert d[near].max() <= 2e-2 * scale + 1e-7, f"{name}: near-threshold max diff {d[near].max()} vs max ref {scale}"
+        assert np.abs(gt - r).sum() <= 2e-4 * np.abs(r).sum() + 1e-6, name
