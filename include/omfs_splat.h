@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMFS_ABI_VERSION 4
+#define OMFS_ABI_VERSION 5
 #define OMFS_TILE 16
 #define OMFS_SEG 128     /* list entries per backward segment                                          */
 #define OMFS_NPLANES 59
@@ -74,6 +74,11 @@ typedef struct omfs_flame_rig {
  * dynamic_offset in omfs_flame_lbs) instead of row b -- an arbitrary set of timesteps in one launch. */
 int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, const float* rotmats,
                       int n_frames, float* joint_xf, float* coef, const int32_t* frame_index, void* stream);
+/* The same from axis-angle poses: pose [*][15] (global, neck, jaw, eye-L, eye-R; rows as expr).  The rotation matrices of
+ * the posed rows are computed in the same launch (omfs_flame_rodrigues's formula) and stored to rotmats [*][45]:
+ * FLAME fine-tuning poses from the current parameters without a separate Rodrigues launch. */
+int omfs_flame_joints_pose(const omfs_flame_rig* rig, const float* expr, const float* pose, float* rotmats,
+                           int n_frames, float* joint_xf, float* coef, const int32_t* frame_index, void* stream);
 
 /* verts [n_frames][v_pad][4] = LBS(v_static + basis . coef) (+ dynamic_offset) + translation.
  * dynamic_offset may be NULL; layout [n_frames][V][3]. translation [n_frames][3].
@@ -164,7 +169,8 @@ typedef struct omfs_raster_buffers {
   uint32_t dup_capacity;
   uint32_t sort_lds_pairs; /* longest tile list whose bucket-ordered copy is kept in LDS (0 = default 7936 pairs = 78 KB,
                               two workgroups per CU; 8 B of LDS each); longer lists keep it in keys_tmp        */
-  uint32_t* status;       /* [1] OMFS_STATUS_* bits, OR-ed by kernels (caller zeroes)            */
+  uint32_t* status;       /* [2] word 0: OMFS_STATUS_* bits, OR-ed by kernels (caller zeroes); word 1: stamp of the
+                             (Gaussians, camera) whose tile-test ballots keys_tmp holds (library-owned, zero initially) */
   /* forward checkpoints for the depth-parallel backward pass: per pixel (T, C.rgb) on entering list segment k
    * (k >= 1) of tile t, stored at slot tile_start[t]/OMFS_SEG + t + k; seg_capacity >= n_tiles + dup_capacity/OMFS_SEG */
   float* seg_ckpt;        /* [seg_capacity][256][4]                                               */
@@ -191,8 +197,9 @@ int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_c
  *  scan    : tile_count -> tile_start (exclusive scan), tile_order, zeroed tile_cursor; tile_count is consumed (left
  *            zeroed for the next view: it must be zero before the first omfs_bin_count)
  *  scatter : (depth bits, id) pairs into their tile's segment of keys; REPLAYS the tile-test outcomes that the
- *            omfs_bin_count of the same view recorded in keys_tmp (one 64-bit ballot per walk step), so the four
- *            steps must run in this order on the same g / cam / rb
+ *            omfs_bin_count of the same view recorded in keys_tmp (one 64-bit ballot per walk step) when status[1]
+ *            still carries that call's stamp (same g->n, g->params and camera, no omfs_tile_sort in between); in any
+ *            other call order the test is re-evaluated (slower, same result)
  *  sort    : per-tile sort by (depth bits, id) -> sorted_ids (keys_tmp is scratch again from here on)       */
 int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
@@ -235,17 +242,23 @@ int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, co
  *   omfs_face_frames_bwd : per-Gaussian records dface [n][16] (from omfs_project_bwd), summed per triangle through the
  *                          CSR (face_start [F+1], face_gauss [n]: Gaussians sorted by parent triangle) -> dverts
  *                          [v_pad][4] += (atomics; caller zeroes)
- *   omfs_flame_skin_bwd  : dverts -> dv_shaped [V][3] (gradient of the blend-shaped vertices, overwritten) and
+ *   omfs_flame_skin_bwd  : dverts (CONSUMED: every row read is left zeroed, so the next frame's omfs_face_frames_bwd
+ *                          needs no clearing pass) -> dv_shaped [V][3] (gradient of the blend-shaped vertices, overwritten) and
  *                          sums [omfs_flame_skin_rows(rig)][64]: one row of partial sums per wave,
  *                          { d joint_xf [5][12], d translation [3], pad } (overwritten, no atomics); v_shaped
  *                          [v_pad][4] is the optional second output of omfs_flame_lbs, joint_xf [60] that of
  *                          omfs_flame_joints for the frame
  *   omfs_flame_param_bwd : dv_shaped, sums (the rows above) -> d expr [n_expr], d pose [5][3] (axis-angle: global,
- *                          neck, jaw, eyes), d translation [3]; dcoef [n_coef] is scratch.
- *   omfs_adam_flat       : torch.optim.Adam step on a flat buffer (the FLAME parameter tensors) */
+ *                          neck, jaw, eyes), d translation [3]; dcoef [n_coef + 1] is scratch whose LAST word is a
+ *                          block ticket that must be zero before the first call (the call leaves it zero): the basis^T
+ *                          product and the serial front run in ONE launch, the block that finishes last does the front.
+ *   omfs_adam_flat       : torch.optim.Adam step on a flat buffer (the FLAME parameter tensors)
+ *   omfs_adam_flat_multi : the same step on up to 4 flat tensors in one launch (host arrays of n_tensors device pointers,
+ *                          sizes and learning rates); the gradients are CONSUMED (zeroed once read), so dense gradient
+ *                          tensors of which one row is written per step never need clearing */
 int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t* faces, int n_faces, const float* dface,
                          const int32_t* face_start, const int32_t* face_gauss, float* dverts, void* stream);
-int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, const float* dverts,
+int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, float* dverts,
                         float* dv_shaped, float* sums, void* stream);
 int omfs_flame_rodrigues(const float* axis_angle, int n, float* rotmats, void* stream);
 int omfs_flame_skin_rows(const omfs_flame_rig* rig);
@@ -254,6 +267,10 @@ int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basis_dense, in
                          float* dtrans, void* stream);
 int omfs_adam_flat(float* params, const float* grads, float* m, float* v, int n, float lr, float beta1, float beta2,
                    float eps, int step, float grad_scale, void* stream);
+struct omfs_step_state;
+int omfs_adam_flat_multi(int n_tensors, float* const* params_host, float* const* grads_host, float* const* m_host,
+                         float* const* v_host, const int* n_host, const float* lr_host, float beta1, float beta2, float eps,
+                         int step, float grad_scale, const struct omfs_step_state* state_dev, void* stream);
 
 typedef struct omfs_reg_params {
   float lambda_xyz, thr_xyz, lambda_scale, thr_scale;
@@ -302,6 +319,30 @@ int omfs_adam_step(float* params, const float* grads, float* m, float* v, int n,
  * data-parallel trainer update the planes whose gradients are complete while the others are still being reduced */
 int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v, int n, int n_pad,
                           const omfs_adam_params* ap, int plane0, int n_planes, void* stream);
+
+/* ---- device-resident per-iteration scalars.  With them nothing about a training iteration is a kernel ARGUMENT any more
+ * (the learning-rate schedule and Adam's bias corrections were the last ones), so a whole iteration can be captured in a
+ * hipGraph once per view and replayed.  omfs_step_advance (one thread) increments both step counters and derives, in double
+ * precision like the host-side entry points: the position learning rate lr_xyz = exp(log(lr_init)(1-t) + log(lr_final) t),
+ * t = min(iterations completed / max_steps, 1) (3DGS' log-linear schedule), and Adam's bias corrections for the
+ * Gaussian and the FLAME parameters.  omfs_adam_step_dev / omfs_adam_flat_multi(state_dev != NULL) read them: planes 0..2
+ * take lr_xyz, every other plane ap->lr[plane]; ap->step / step are ignored.                                            */
+typedef struct omfs_step_state {          /* 16 words of DEVICE memory; the caller initialises step / flame_step        */
+  int32_t step;                           /* Adam step of the Gaussian parameters (1-based after omfs_step_advance)      */
+  int32_t flame_step;                     /* Adam step of the FLAME parameters                                           */
+  float lr_xyz;                           /* position learning rate of this iteration                                    */
+  float inv_bc1, inv_sqrt_bc2;            /* 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)                              */
+  float flame_inv_bc1, flame_inv_sqrt_bc2;
+  float reserved[9];
+} omfs_step_state;
+typedef struct omfs_lr_schedule {
+  float lr_init, lr_final;
+  int max_steps;
+  float beta1, beta2;
+} omfs_lr_schedule;
+int omfs_step_advance(omfs_step_state* state_dev, const omfs_lr_schedule* sch, void* stream);
+int omfs_adam_step_dev(float* params, const float* grads, float* m, float* v, int n, int n_pad, const omfs_adam_params* ap,
+                       const omfs_step_state* state_dev, int plane0, int n_planes, void* stream);
 
 /* ---- adaptive density control (clone / split / prune), SURVEY.md Appendix A item 10: what the absent upstream train.py does
  * between iterations (call site 02_Visual_Engine/train_ghost.py:227-271).  Three steps, the caller allocates:

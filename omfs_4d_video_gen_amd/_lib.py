@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see module d
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 RB_FORWARD_ONLY = 1
 NPLANES = 59
 TILE = 16
@@ -80,6 +80,13 @@ class AdamParamsC(C.Structure):
                 ("step", C.c_int), ("grad_scale", C.c_float)]
 
 
+class LrScheduleC(C.Structure):
+    _fields_ = [("lr_init", C.c_float), ("lr_final", C.c_float), ("max_steps", C.c_int), ("beta1", C.c_float), ("beta2", C.c_float)]
+
+
+STEP_STATE_WORDS = 16     # omfs_step_state: device memory (int32 step, int32 flame_step, 5 floats, padding)
+
+
 class FlameFitC(C.Structure):
     _fields_ = [("n_frames", C.c_int), ("n_use", C.c_int), ("target", c_void_p), ("valid", c_void_p), ("inv_denom", C.c_float),
                 ("lr", C.c_float * 5), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step", C.c_int),
@@ -97,6 +104,13 @@ SIGNATURES = {
     "omfs_abi_version": (C.c_int, []),
     "omfs_last_error": (C.c_char_p, []),
     "omfs_flame_joints": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "omfs_flame_joints_pose": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "omfs_adam_flat_multi": (C.c_int, [C.c_int, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_int, C.c_float,
+                                       c_void_p, c_void_p]),
+    "omfs_step_advance": (C.c_int, [c_void_p, C.POINTER(LrScheduleC), c_void_p]),
+    "omfs_adam_step_dev": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), c_void_p,
+                                     C.c_int, C.c_int, c_void_p]),
     "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
     "omfs_extract_drgb": (C.c_int, [C.POINTER(RasterBuffersC), c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),

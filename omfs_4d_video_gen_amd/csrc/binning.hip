@@ -16,14 +16,74 @@ namespace omfs {
 // ------------------------------------------------------------------ scan + launch order
 // One workgroup.  Thread t owns the SCAN_PER consecutive tiles starting at t * per; their counts are loaded once
 // (independent loads, one round trip) and stay in registers for all phases:
-//   1. exclusive scan of the counts -> tile_start, tile_cursor = 0, overflow flag;
-//   2. launch order: tiles sorted by descending log2 bucket of their count (heavy tiles first).  One 64-bit LDS
-//      atomic per tile hands out the position inside the bucket (low word) together with the number of
-//      OMFS_SEG-entry list segments of the tiles in front of it (high word), so
-//   3. order_seg0[p] = segments owned by the tiles before position p of the launch order (order_seg0[n_tiles] =
-//      total) needs no further pass.  The backward pass launches one wave per (segment, quadrant) and finds its
-//      tile by bisection in this array.
+//   0. exclusive scan of the counts -> tile_start, tile_cursor = 0, overflow flag;
+//   1. launch order: tiles by descending log2 bucket of their count (heavy tiles first) and, with it,
+//      order_seg0[p] = OMFS_SEG-entry list segments owned by the tiles before position p (order_seg0[n_tiles] = total):
+//      the backward pass launches one wave per (segment, quadrant) and finds its tile by bisection in this array.
+// A tile's position is bucket base + its rank inside the bucket.  8160 tiles fall into a dozen buckets, so one LDS atomic
+// per tile (what this kernel did first: 2 x 8192 returning atomics on a dozen addresses, serialised by the LDS, most of
+// its 23 us) is replaced by WAVE-AGGREGATED counting: per item the wave loops over the distinct buckets among its 64
+// tiles (ballot match), a DPP scan gives every member its rank / segment prefix inside the group, and the group's leader
+// alone touches the wave's PRIVATE cursor of that bucket -- ~50 uncontended LDS operations per wave instead of 1024.
+// Two sweeps: totals per (wave, bucket) first, then -- the cursors turned into absolute positions (bucket-major,
+// wave-minor) -- the assignment.
 constexpr int SCAN_PER = 8;   // tiles per thread held in registers (n_tiles <= 8192; larger images loop)
+constexpr int SCAN_BUCKETS = 33;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+// inclusive prefix sum over the 64 lanes, DPP only (no LDS round trips)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32_dpp(uint32_t v) {
+  v += dpp_u32<0x111, 0xF>(v);   // row_shr:1
+  v += dpp_u32<0x112, 0xF>(v);   // row_shr:2
+  v += dpp_u32<0x114, 0xF>(v);   // row_shr:4
+  v += dpp_u32<0x118, 0xF>(v);   // row_shr:8   -> inclusive inside each row of 16
+  v += dpp_u32<0x142, 0xA>(v);   // row_bcast:15 -> rows 1, 3
+  v += dpp_u32<0x143, 0xC>(v);   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// One sweep over the SCAN_PER items of every lane.  ASSIGN = false: wb[bucket] += (tiles, segments) of the wave's groups.
+// ASSIGN = true: wb[bucket] is the wave's absolute cursor (position | segments in front << 32); members get their
+// launch position and segment prefix.
+template <bool ASSIGN>
+__device__ __forceinline__ void scan_bucket_sweep(const uint32_t (&cnt)[SCAN_PER], int beg, int n_tiles, unsigned long long* wb,
+                                                  uint32_t* __restrict__ tile_order, uint32_t* __restrict__ order_seg0) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 0; k < SCAN_PER; ++k) {
+    const bool valid = beg + k < n_tiles;
+    const uint32_t c = cnt[k];
+    const int slot = valid ? (c ? __clz(c) : 32) : 64;          // 32 - bucket: heavy tiles first; 64 = no tile
+    const uint32_t sg = (c + OMFS_SEG - 1) / OMFS_SEG;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int ld = __builtin_ctzll(todo);
+      const int s0 = __builtin_amdgcn_readlane(slot, ld);
+      const bool in = slot == s0;
+      const unsigned long long m = __ballot(in);
+      const uint32_t incl = wave_incl_scan_u32_dpp(in ? sg : 0u);
+      const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      const unsigned long long add = (unsigned long long)__popcll(m) | ((unsigned long long)tot << 32);
+      if (ASSIGN) {
+        unsigned long long old = 0ull;
+        if (lane == ld) { old = wb[s0]; wb[s0] = old + add; }     // the wave's private cursor: no atomic needed
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)old, ld);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(old >> 32), ld);
+        if (in) {
+          const uint32_t pos = lo + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          tile_order[pos] = (uint32_t)(beg + k);
+          order_seg0[pos] = hi + incl - sg;
+        }
+      } else if (lane == ld) {
+        wb[s0] += add;
+      }
+      todo &= ~m;
+    }
+  }
+}
 
 __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* __restrict__ tile_count,
                                                          uint32_t* __restrict__ tile_start,
@@ -31,24 +91,26 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
                                                          uint32_t* __restrict__ tile_order, uint32_t dup_capacity,
                                                          uint32_t* __restrict__ status, uint32_t* __restrict__ order_seg0) {
   __shared__ uint32_t wave_tot[16];
-  __shared__ unsigned long long bucket_acc[33];   // low: tiles in the bucket, high: their segments; then running bases
-  __shared__ uint32_t carry;                      // tiles / pairs of the chunks before (images with > 8192 tiles)
+  __shared__ unsigned long long wb[16][SCAN_BUCKETS];   // per wave and bucket: totals, then cursors
+  __shared__ uint32_t carry;                            // pairs of the chunks before (images with > 8192 tiles)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < 33) bucket_acc[tid] = 0ull;
+  for (int k = tid; k < 16 * SCAN_BUCKETS; k += 1024) (&wb[0][0])[k] = 0ull;
   if (tid == 0) carry = 0;
   __syncthreads();
-  // ---- pass A over chunks of 8192 tiles: scan + bucket totals
-  uint32_t total = 0;
   uint32_t cnt[SCAN_PER];
-  const bool single = n_tiles <= 1024 * SCAN_PER;   // then cnt[] still holds this thread's counts in pass B
+  const bool single = n_tiles <= 1024 * SCAN_PER;   // then cnt[] still holds this thread's counts in the later sweeps
+  auto load_counts = [&](int beg) {
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) cnt[k] = beg + k < n_tiles ? tile_count[beg + k] : 0u;
+  };
+  // ---- phase 0 over chunks of 8192 tiles: exclusive scan -> tile_start; totals per (wave, bucket)
   for (int c0 = 0; c0 < n_tiles; c0 += 1024 * SCAN_PER) {
     const int beg = c0 + tid * SCAN_PER;
+    load_counts(beg);
     uint32_t sum = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) { cnt[k] = beg + k < n_tiles ? tile_count[beg + k] : 0u; }
-#pragma unroll
     for (int k = 0; k < SCAN_PER; ++k) sum += cnt[k];
-    const uint32_t incl = wave_incl_scan_u32(sum, lane);
+    const uint32_t incl = wave_incl_scan_u32_dpp(sum);
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     uint32_t base = carry, chunk_total = 0;
@@ -63,46 +125,42 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
       if (beg + k < n_tiles) {
         tile_start[beg + k] = run;       // rewritten as 0 below if the capacity overflows
         tile_cursor[beg + k] = 0;
-        const uint32_t c = cnt[k];
-        const int bucket = c ? (32 - __clz(c)) : 0;  // 0..32, larger = more work
-        atomicAdd(&bucket_acc[32 - bucket], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
-        run += c;
+        run += cnt[k];
       }
     }
+    scan_bucket_sweep<false>(cnt, beg, n_tiles, wb[wave], tile_order, order_seg0);
     __syncthreads();
     if (tid == 0) carry += chunk_total;
     __syncthreads();
   }
-  total = carry;
-  const bool overflow = total > dup_capacity;
-  if (tid == 0) {
-    tile_start[n_tiles] = overflow ? 0u : total;
-    if (overflow) atomicOr(status, OMFS_STATUS_DUP_OVERFLOW);
-    unsigned long long r = 0ull;   // exclusive scan over the buckets, both words at once
-    for (int b = 0; b < 33; ++b) {
-      const unsigned long long v = overflow ? 0ull : bucket_acc[b];   // on overflow every list is emptied: one bucket
-      bucket_acc[b] = r;
-      r += v;
-    }
-    order_seg0[n_tiles] = overflow ? 0u : (uint32_t)(r >> 32);
+  const uint32_t total = carry;
+  if (total > dup_capacity) {
+    // every list is emptied (the frame shows the background, the flag tells the host): identity order, no segments
+    if (tid == 0) { tile_start[n_tiles] = 0u; order_seg0[n_tiles] = 0u; atomicOr(status, OMFS_STATUS_DUP_OVERFLOW); }
+    for (int t = tid; t < n_tiles; t += 1024) { tile_start[t] = 0u; tile_count[t] = 0u; tile_order[t] = (uint32_t)t; order_seg0[t] = 0u; }
+    return;
+  }
+  // ---- totals -> absolute cursors: bucket-major, wave-minor exclusive scan (33 x 16 entries; lane b of wave 0 owns bucket b)
+  if (wave == 0) {
+    unsigned long long tot = 0ull;
+    if (lane < SCAN_BUCKETS)
+      for (int w = 0; w < 16; ++w) { const unsigned long long v = wb[w][lane]; wb[w][lane] = tot; tot += v; }
+    // exclusive scan of the bucket totals over the lanes, both words (tiles < 2^16, segments < 2^32: no carry between them)
+    const uint32_t lo = wave_incl_scan_u32_dpp((uint32_t)tot), hi = wave_incl_scan_u32_dpp((uint32_t)(tot >> 32));
+    const unsigned long long base = ((unsigned long long)(hi - (uint32_t)(tot >> 32)) << 32) | (unsigned long long)(lo - (uint32_t)tot);
+    if (lane < SCAN_BUCKETS)
+      for (int w = 0; w < 16; ++w) wb[w][lane] += base;
+    if (lane == 63) { tile_start[n_tiles] = total; order_seg0[n_tiles] = hi; }
   }
   __syncthreads();
-  // ---- pass B: positions in the launch order (+ segment prefix); counts are re-read only for images with > 8192 tiles
+  // ---- phase 1: positions in the launch order (+ segment prefix); counts are re-read only for images with > 8192 tiles
   for (int c0 = 0; c0 < n_tiles; c0 += 1024 * SCAN_PER) {
     const int beg = c0 + tid * SCAN_PER;
+    if (!single) load_counts(beg);
+    scan_bucket_sweep<true>(cnt, beg, n_tiles, wb[wave], tile_order, order_seg0);
 #pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) {
-      if (beg + k < n_tiles) {
-        uint32_t c = single ? cnt[k] : tile_count[beg + k];
-        tile_count[beg + k] = 0;                       // consumed: the next frame's omfs_bin_count accumulates from zero
-        if (overflow) { c = 0; tile_start[beg + k] = 0; }
-        const int bucket = c ? (32 - __clz(c)) : 0;
-        const unsigned long long old = atomicAdd(&bucket_acc[32 - bucket], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
-        const uint32_t pos = (uint32_t)old;
-        tile_order[pos] = (uint32_t)(beg + k);
-        order_seg0[pos] = (uint32_t)(old >> 32);
-      }
-    }
+    for (int k = 0; k < SCAN_PER; ++k)
+      if (beg + k < n_tiles) tile_count[beg + k] = 0;      // consumed: the next frame's omfs_bin_count accumulates from zero
   }
 }
 
@@ -219,9 +277,11 @@ __device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSource ps, int gx, int n_tiles,
                                                                 uint32_t* __restrict__ tile_count,
                                                                 unsigned long long* __restrict__ hits_all,
-                                                                uint32_t* __restrict__ n_visible) {
+                                                                uint32_t* __restrict__ n_visible, uint32_t* __restrict__ status,
+                                                                uint32_t stamp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ uint32_t s_vis;
+  if (blockIdx.x == 0 && threadIdx.x == 0) status[1] = hits_all ? stamp : 0u;   // whose tile-test ballots keys_tmp now holds
   WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
@@ -248,10 +308,14 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSou
                                                                   const uint32_t* __restrict__ tile_start,
                                                                   uint32_t* __restrict__ tile_cursor,
                                                                   uint2* __restrict__ keys,
-                                                                  unsigned long long* __restrict__ hits_all) {
+                                                                  unsigned long long* __restrict__ hits_all,
+                                                                  const uint32_t* __restrict__ status, uint32_t stamp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);  // count, then this block's next slot in the tile
+  // the recorded ballots are replayed only if they are the ones omfs_bin_count left for THESE Gaussians and THIS camera
+  // (stamp in status[1]; omfs_tile_sort, which reuses keys_tmp, clears it): any other call order recomputes the test
+  if (status[1] != stamp) hits_all = nullptr;
   unsigned long long* hits = hits_all ? hits_all + ((size_t)blockIdx.x * BIN_WAVES + (threadIdx.x >> 6)) * HITS_PER_WAVE : nullptr;
   if (tile_start[n_tiles] == 0u) return;                // nothing visible, or capacity overflow (flagged by the scan)
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
@@ -506,7 +570,8 @@ template <int NT>
 __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
                                                        const uint32_t* __restrict__ tile_start,
                                                        uint2* __restrict__ keys, uint2* __restrict__ keys_tmp,
-                                                       uint32_t* __restrict__ sorted_ids, int lds_cap, int n_lo, int n_hi) {
+                                                       uint32_t* __restrict__ sorted_ids, int lds_cap, int n_lo, int n_hi,
+                                                       uint32_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / 64;
   uint2* bufB = reinterpret_cast<uint2*>(smem);
@@ -515,6 +580,7 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
   const uint32_t tile = tile_order[blockIdx.x];
   const uint32_t s = tile_start[tile];
   const int n = (int)(tile_start[tile + 1] - s);
+  if (status && blockIdx.x == 0 && threadIdx.x == 0) status[1] = 0u;   // keys_tmp is scratch from here on: no ballots to replay
   if (n <= n_lo || n > n_hi) return;
   OMFS_DBG_SORT_BEGIN();
   const int tid = threadIdx.x;
@@ -566,6 +632,30 @@ static unsigned long long* hits_buffer(int n, const omfs_raster_buffers* rb) {
   return need <= (size_t)rb->dup_capacity ? reinterpret_cast<unsigned long long*>(rb->keys_tmp) : nullptr;
 }
 
+// identifies (Gaussian set, camera) of a bin_count / bin_scatter pair: FNV-1a over the words both calls are given; never 0
+static uint32_t hits_stamp(const omfs_gaussians* g, const omfs_camera* cam) {
+  uint32_t h = 2166136261u;
+  auto mix = [&](const void* p, size_t bytes) {
+    const unsigned char* b = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < bytes; ++i) h = (h ^ b[i]) * 16777619u;
+  };
+  mix(&g->n, sizeof(g->n)); mix(&g->params, sizeof(g->params)); mix(cam, sizeof(*cam));
+  return h ? h : 1u;
+}
+
+// dynamic LDS above 64 KB needs the attribute once per device and function
+#include <atomic>
+static int ensure_max_lds(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  OMFS_CHECK_HIP(hipGetDevice(&dev));
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    OMFS_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return OMFS_OK;
+}
+
 extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
   if (int rc = check_bin_args(cam, rb)) return rc;
   OMFS_REQUIRE(g && g->n > 0 && rb->g0 && rb->g1, "gaussians");
@@ -574,13 +664,10 @@ extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, c
   PairSource ps{(const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2};
   const size_t lds = (size_t)n_tiles * 4 + BIN_SCRATCH_BYTES;
   if (lds <= BIN_LDS_LIMIT) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)bin_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));   // + a static word
-      attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = ensure_max_lds((const void*)bin_count_kernel, 159 * 1024, attr_done)) return rc;   // + a static word
     hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles, rb->tile_count,
-                       hits_buffer(g->n, rb), rb->n_visible);
+                       hits_buffer(g->n, rb), rb->n_visible, rb->status, hits_stamp(g, cam));
   } else {
     hipLaunchKernelGGL(bin_count_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, rb->tile_count, rb->n_visible);
   }
@@ -607,13 +694,10 @@ extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam,
   PairSource ps{(const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2};
   const size_t lds = (size_t)n_tiles * 4 + BIN_SCRATCH_BYTES;
   if (lds <= BIN_LDS_LIMIT) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)bin_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+    static std::atomic<unsigned long long> attr_done{0};
+    if (int rc = ensure_max_lds((const void*)bin_scatter_kernel, 160 * 1024, attr_done)) return rc;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles,
-                       rb->tile_start, rb->tile_cursor, (uint2*)rb->keys, hits_buffer(g->n, rb));
+                       rb->tile_start, rb->tile_cursor, (uint2*)rb->keys, hits_buffer(g->n, rb), rb->status, hits_stamp(g, cam));
   } else {
     hipLaunchKernelGGL(bin_scatter_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, n_tiles,
                        rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
@@ -630,19 +714,16 @@ extern "C" int omfs_tile_sort(const omfs_camera* cam, const omfs_raster_buffers*
   const int cap_large = rb->sort_lds_pairs ? (int)rb->sort_lds_pairs : SORT_LARGE_CAP_DEFAULT;
   OMFS_REQUIRE(cap_large >= 256 && sort_lds_bytes(cap_large, SORT_LARGE_NT) <= 160 * 1024, "sort_lds_pairs");
   const int cap_small = cap_large < SORT_SMALL_CAP ? cap_large : SORT_SMALL_CAP;
-  static bool attr_set = false;  // one process per GPU: set once
-  if (!attr_set) {
-    OMFS_CHECK_HIP(hipFuncSetAttribute((const void*)tile_sort_kernel<SORT_LARGE_NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> attr_done{0};
+  if (int rc = ensure_max_lds((const void*)tile_sort_kernel<SORT_LARGE_NT>, 160 * 1024, attr_done)) return rc;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(tile_sort_kernel<SORT_LARGE_NT>, dim3(n_tiles), dim3(SORT_LARGE_NT), sort_lds_bytes(cap_large, SORT_LARGE_NT), s,
                      rb->tile_order, rb->tile_start, (uint2*)rb->keys, (uint2*)rb->keys_tmp, rb->sorted_ids, cap_large,
-                     cap_small, 0x7fffffff);
+                     cap_small, 0x7fffffff, rb->status);
   OMFS_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(tile_sort_kernel<SORT_SMALL_NT>, dim3(n_tiles), dim3(SORT_SMALL_NT), sort_lds_bytes(cap_small, SORT_SMALL_NT), s,
                      rb->tile_order, rb->tile_start, (uint2*)rb->keys, (uint2*)rb->keys_tmp, rb->sorted_ids, cap_small,
-                     0, cap_small);
+                     0, cap_small, (uint32_t*)nullptr);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

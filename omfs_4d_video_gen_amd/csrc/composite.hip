@@ -115,16 +115,23 @@ constexpr int DEEP_WAVES = OMFS_DEEP_WAVES;       // segments evaluated in paral
 // masks, publishes the records in its private LDS page and turns the mask bits into four 64-bit ballots
 // held in scalar registers; it then walks ONLY the set bits (scalar bit scans) of the sub-blocks that
 // still hold an unsaturated pixel.
-__global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
+#ifdef OMFS_FWD_WAVES
+#define OMFS_FWD_ATTR __attribute__((amdgpu_waves_per_eu(OMFS_FWD_WAVES, 8)))
+#else
+#define OMFS_FWD_ATTR
+#endif
+__global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam cam, const uint32_t* __restrict__ tile_order,
                                                            const uint32_t* __restrict__ tile_start,
                                                            const uint32_t* __restrict__ sorted_ids,
                                                            const float4* __restrict__ g0, const float4* __restrict__ g1,
                                                            const float4* __restrict__ g2, float* __restrict__ image,
                                                            float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                            float4* __restrict__ seg_ckpt, int keep_ckpt) {
-  __shared__ float4 s0[WB];
-  __shared__ float4 s1[WB];
-  __shared__ float s2[WB];
+  // staged records live at index 1 .. 64; index 0 is a record that no pixel can hit (log2 opacity -1e30): the visit
+  // loop takes FOUR list entries per iteration and pads an incomplete batch with it (ffs of an empty bit mask is 0)
+  __shared__ float4 s0[WB + 1];
+  __shared__ float4 s1[WB + 1];
+  __shared__ float4 s2[WB + 1];   // .x = blue (one address register serves the three reads of an entry)
   OMFS_DBG_SPAN(0);
   const uint32_t tile = tile_order[blockIdx.x >> 2];
   const int quad = blockIdx.x & 3, lane = threadIdx.x;
@@ -147,6 +154,11 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
     const uint32_t id = sorted_ids[beg + lane];
     r0 = g0[id]; r1 = g1[id]; r2 = g2[id].x;
   }
+  if (lane == 0) {
+    s0[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    s1[0] = make_float4(0.f, -1e30f, 0.f, 0.f);
+    s2[0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   unsigned long long live = __ballot(!done);
   // lists longer than FWD_SEQ_SEGS segments are finished by composite_fwd_deep_kernel (segment-parallel)
   const bool deep = end - beg > (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG);
@@ -162,9 +174,9 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
     if (k < end) {
       const float A = r0.z, B = r0.w, C = r1.x;
       const float lo = __log2f(fmaxf(r1.y, 1e-30f));
-      s0[lane] = make_float4(r0.x, r0.y, -0.5f * LOG2E * A, -LOG2E * B);
-      s1[lane] = make_float4(-0.5f * LOG2E * C, lo, r1.z, r1.w);
-      s2[lane] = r2;
+      s0[lane + 1] = make_float4(r0.x, r0.y, -0.5f * LOG2E * A, -LOG2E * B);
+      s1[lane + 1] = make_float4(-0.5f * LOG2E * C, lo, r1.z, r1.w);
+      s2[lane + 1].x = r2;
       mask = quadrant_mask(r0.x, r0.y, A, B, C, lo, qx0, qy0);
     }
     unsigned long long ms[4];
@@ -185,62 +197,53 @@ __global__ __launch_bounds__(64) void composite_fwd_kernel(CompCam cam, const ui
       return r;
     };
     unsigned long long m = combine(live);
-    if (m == 0ull) continue;
     const uint32_t base = b - beg;
-    // LDS reads of the next splat are issued before the current one is evaluated; two register sets alternate
-    // (the body is written once and instantiated twice), so the prefetch needs no copies
-    int jn = __builtin_ctzll(m);
-    float4 recA0 = s0[jn], recA1 = s1[jn], recB0 = recA0, recB1 = recA1;
-    float recA2 = s2[jn], recB2 = recA2;
-    auto visit = [&](const float4& a, const float4& c, const float& cb, float4& nx0, float4& nx1, float& nx2, bool check) {
-      const int j = jn;
-      OMFS_DBG_WORK();
-      m &= m - 1ull;
-      jn = __builtin_ctzll(m | (1ull << 63));    // m == 0: any staged entry will do, it is not used
-      nx0 = s0[jn]; nx1 = s1[jn]; nx2 = s2[jn];
-#ifdef OMFS_DEBUG_COUNTERS
-      {
-        const float dx_ = a.x - fx, dy_ = a.y - fy;
-        const float p2_ = fma_(a.z * dx_, dx_, fma_(c.x * dy_, dy_, a.w * dx_ * dy_));
-        const unsigned long long hb = __ballot(!done && p2_ <= 0.f && p2_ + c.y >= LOG2_INV255);
-        OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb));
+    // Four entries per iteration, no branch inside: the bit scans are scalar, the twelve LDS reads of a batch are issued
+    // together, and the four alpha evaluations are independent of each other -- only the short T / stop chain is serial.
+    // A wave that runs alone on its SIMD (the silhouette quadrants every launch ends on) is bound by dependent-issue
+    // latency, not by throughput: the batch gives it four-fold instruction-level parallelism.  A pixel that is done, or
+    // not hit, takes a no-op step (weight 0, T and last unchanged).
+    while (m) {
+      int jx[4];
+      float4 ra[4], rc[4];
+      float rb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        jx[u] = __builtin_ffsll((long long)m);      // 1-based staged index, 0 (the inert record) when the mask is empty
+        m &= m - 1ull;
+        OMFS_DBG_WORK();
       }
-#endif
-      if (!done) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { ra[u] = s0[jx[u]]; rc[u] = s1[jx[u]]; rb[u] = s2[jx[u]].x; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float4 a = ra[u], c = rc[u];
         const float dx = a.x - fx, dy = a.y - fy;
         const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
         const float e = p2 + c.y;
-        if (p2 <= 0.f && e >= LOG2_INV255) {
-          const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
-          const float Tn = T * (1.f - alpha);
-          const bool stop = Tn < 1e-4f;
-          // the splat that would take T below the threshold is not composited: weight 0, T and last stay
-          const float w = stop ? 0.f : alpha * T;
-          C0 = fma_(c.z, w, C0);
-          C1 = fma_(c.w, w, C1);
-          C2 = fma_(cb, w, C2);
-          T = stop ? T : Tn;
-          last = stop ? last : base + (uint32_t)j + 1u;
-          done = stop;
-        }
+        const bool hit = !done && p2 <= 0.f && e >= LOG2_INV255;
+#ifdef OMFS_DEBUG_COUNTERS
+        { const unsigned long long hb = __ballot(hit); OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb)); }
+#endif
+        const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
+        const float Tn = T * (1.f - alpha);
+        // the splat that would take T below the threshold is not composited: weight 0, T and last stay
+        const bool stop = hit && Tn < 1e-4f;
+        const bool upd = hit && !stop;
+        const float w = upd ? alpha * T : 0.f;
+        C0 = fma_(c.z, w, C0);
+        C1 = fma_(c.w, w, C1);
+        C2 = fma_(rb[u], w, C2);
+        T = upd ? Tn : T;
+        last = upd ? base + (uint32_t)jx[u] : last;
+        done = done || stop;
       }
-      if (!check) return;     // saturation is looked at after every fourth splat
+      // saturation is looked at once per batch
       const unsigned long long nl = __ballot(!done);
       if (nl != live) {
         live = nl;
         m &= combine(live);
-        jn = m ? __builtin_ctzll(m) : 0;   // the prefetched splat may have been dropped
-        nx0 = s0[jn]; nx1 = s1[jn]; nx2 = s2[jn];
       }
-    };
-    while (m) {
-      visit(recA0, recA1, recA2, recB0, recB1, recB2, false);
-      if (!m) break;
-      visit(recB0, recB1, recB2, recA0, recA1, recA2, false);
-      if (!m) break;
-      visit(recA0, recA1, recA2, recB0, recB1, recB2, false);
-      if (!m) break;
-      visit(recB0, recB1, recB2, recA0, recA1, recA2, true);
     }
     live = __ballot(!done);
   }
@@ -288,9 +291,9 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
     const uint32_t* __restrict__ sorted_ids, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ g2, float* __restrict__ image, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float4* __restrict__ seg_ckpt, int keep_ckpt) {
-  __shared__ float4 pg0[DEEP_WAVES][WB];
-  __shared__ float4 pg1[DEEP_WAVES][WB];
-  __shared__ float pg2[DEEP_WAVES][WB];
+  __shared__ float4 pg0[DEEP_WAVES][WB + 1];  // index 0 of every wave's page: the record no pixel can hit (see composite_fwd_kernel)
+  __shared__ float4 pg1[DEEP_WAVES][WB + 1];
+  __shared__ float4 pg2[DEEP_WAVES][WB + 1];  // .x = blue
   __shared__ float4 comp[DEEP_WAVES][64];     // per segment and pixel: (P, A.rgb)
   __shared__ uint32_t comp_last[DEEP_WAVES][64];
   __shared__ float4 res[64];                  // exactly resolved pixels: (T, C.rgb)
@@ -300,6 +303,11 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
   const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
   if (tend - tbeg <= (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG)) return;
   const int quad = blockIdx.x & 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    pg0[wave][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    pg1[wave][0] = make_float4(0.f, -1e30f, 0.f, 0.f);
+    pg2[wave][0] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const size_t slot0 = (size_t)(tbeg / OMFS_SEG) + tile;
   const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
@@ -355,9 +363,9 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
         if (k < se) {
           const float A = q0[h].z, B = q0[h].w, C = q1[h].x;
           const float lo = __log2f(fmaxf(q1[h].y, 1e-30f));
-          pg0[wave][lane] = make_float4(q0[h].x, q0[h].y, -0.5f * LOG2E * A, -LOG2E * B);
-          pg1[wave][lane] = make_float4(-0.5f * LOG2E * C, lo, q1[h].z, q1[h].w);
-          pg2[wave][lane] = q2[h];
+          pg0[wave][lane + 1] = make_float4(q0[h].x, q0[h].y, -0.5f * LOG2E * A, -LOG2E * B);
+          pg1[wave][lane + 1] = make_float4(-0.5f * LOG2E * C, lo, q1[h].z, q1[h].w);
+          pg2[wave][lane + 1].x = q2[h];
           mask = quadrant_mask(q0[h].x, q0[h].y, A, B, C, lo, qx0, qy0);
         }
         unsigned long long m = 0ull;
@@ -369,15 +377,17 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t base = b - tbeg;
-        int jn = m ? __builtin_ctzll(m) : 0;
+        // branch-free: alpha is masked to 0 for pixels that are done or not hit (P and A then stay as they are).  One entry
+        // per iteration with two alternating register sets for the LDS prefetch: the four-entry batches of
+        // composite_fwd_kernel cost this kernel registers and padded slots (measured: 122 -> 144 us)
+        int jn = m ? __builtin_ffsll((long long)m) : 0;
         float4 recA0 = pg0[wave][jn], recA1 = pg1[wave][jn], recB0 = recA0, recB1 = recA1;
-        float recA2 = pg2[wave][jn], recB2 = recA2;
-        // branch-free: alpha is masked to 0 for pixels that are done or not hit (P and A then stay as they are)
+        float recA2 = pg2[wave][jn].x, recB2 = recA2;
         auto visit = [&](const float4& a, const float4& c, const float& cb, float4& nx0, float4& nx1, float& nx2) {
           const int j = jn;
           m &= m - 1ull;
-          jn = __builtin_ctzll(m | (1ull << 63));
-          nx0 = pg0[wave][jn]; nx1 = pg1[wave][jn]; nx2 = pg2[wave][jn];
+          jn = __builtin_ffsll((long long)m);          // 0 (the inert record) when nothing is left: it is not used
+          nx0 = pg0[wave][jn]; nx1 = pg1[wave][jn]; nx2 = pg2[wave][jn].x;
           const float dx = a.x - fx, dy = a.y - fy;
           const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
           const float e = p2 + c.y;
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
           A1 = fma_(c.w, w, A1);
           A2 = fma_(cb, w, A2);
           P = P * (1.f - alpha);
-          lw = hit ? base + (uint32_t)j + 1u : lw;
+          lw = hit ? base + (uint32_t)j : lw;
         };
         while (m) {
           visit(recA0, recA1, recA2, recB0, recB1, recB2);

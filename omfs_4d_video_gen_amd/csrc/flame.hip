@@ -19,12 +19,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // One 64-thread block per frame column: 15 lanes run the joint-regression chains (ascending-k fma, as
 // the oracle), all lanes write the coefficient column, lane 0 walks the 5-joint kinematic chain.
+__device__ __forceinline__ void rodrigues_fwd(const float* aa, float* R, float* K, float& th);
+
+// pose (may be NULL): axis-angle [*][15]; when given, the frame's five rotation matrices are computed here (the formula of
+// rodrigues_kernel, bit for bit) and stored to rotmats -- FLAME fine-tuning poses from the current parameters without a
+// separate launch.
 __global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
-                                                          const float* __restrict__ expr, const float* __restrict__ rotmats,
+                                                          const float* __restrict__ expr, float* __restrict__ rotmats,
+                                                          const float* __restrict__ pose,
                                                           int n_frames, int n_expr, int k_pad, int b_pad,
                                                           float* __restrict__ joint_xf, float* __restrict__ coef,
                                                           const int32_t* __restrict__ frame_index) {
   __shared__ float sJ[15];
+  __shared__ float sR[45];
   const int b = blockIdx.x, lane = threadIdx.x;
   if (b >= n_frames) {  // padded frame columns: zero coefficients
     for (int k = lane; k < k_pad; k += 64) coef[(size_t)k * b_pad + b] = 0.f;
@@ -32,7 +39,17 @@ __global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restric
   }
   const int src = frame_index ? frame_index[b] : b;     // row of the sequence arrays this batch column shows
   const float* e = expr + (size_t)src * n_expr;
-  const float* R = rotmats + (size_t)src * 45;
+  if (pose) {
+    if (lane < 5) {
+      float Rj[9], Kj[9], th;
+      rodrigues_fwd(pose + (size_t)src * 15 + lane * 3, Rj, Kj, th);
+      for (int i = 0; i < 9; ++i) { sR[lane * 9 + i] = Rj[i]; rotmats[(size_t)src * 45 + lane * 9 + i] = Rj[i]; }
+    }
+  } else if (lane < 45) {
+    sR[lane] = rotmats[(size_t)src * 45 + lane];
+  }
+  __syncthreads();
+  const float* R = sR;
   if (lane < 15) {  // J[j][c] = j_static + sum_k j_expr[j*3+c][k] * e[k]
     float acc = j_static[lane];
     const float* row = j_expr + (size_t)lane * n_expr;
@@ -270,7 +287,7 @@ __global__ void face_frames_bwd_kernel(const float* __restrict__ verts, const in
 // flame_lbs.  Writes dv_shaped = M_v(3x3)^T dv and the per-wave partial sums of d X_j = w_vj dv (x) [v_shaped; 1] and
 // d translation = dv (63 values, DPP wave reduction) into sums[wave][64].
 __global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __restrict__ lbs_weights, const float* __restrict__ v_shaped,
-                                                             const float* __restrict__ joint_xf, const float* __restrict__ dverts,
+                                                             const float* __restrict__ joint_xf, float* __restrict__ dverts,
                                                              int n_verts, float* __restrict__ dv_shaped, float* __restrict__ sums) {
   __shared__ float X[60];
   if (threadIdx.x < 60) X[threadIdx.x] = joint_xf[threadIdx.x];
@@ -281,6 +298,7 @@ __global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __rest
   if (on) {
     for (int j = 0; j < 5; ++j) w[j] = lbs_weights[(size_t)v * 8 + j];
     const float4 d = reinterpret_cast<const float4*>(dverts)[v], a = reinterpret_cast<const float4*>(v_shaped)[v];
+    reinterpret_cast<float4*>(dverts)[v] = make_float4(0.f, 0.f, 0.f, 0.f);   // consumed: the next frame's atomics start from zero
     dv[0] = d.x; dv[1] = d.y; dv[2] = d.z;
     vs[0] = a.x; vs[1] = a.y; vs[2] = a.z;
     float out[3] = {0.f, 0.f, 0.f};
@@ -308,9 +326,18 @@ __global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __rest
 }
 
 // dcoef[k] = sum_i basis_dense[k][i] dv_shaped[i]   (one block per coefficient)
+struct FrontArgs {
+  const float* j_static; const float* j_expr; const float* expr; const float* pose; int n_expr; const float* partial; int n_rows;
+  float* dexpr; float* dpose; float* dtrans;
+};
+__device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef);
+
+// The block that finishes last (ticket in dcoef[gridDim.x], reset for the next call) goes on with flame_front_bwd: the
+// basis^T product and the small serial front share one launch.
 __global__ __launch_bounds__(256) void basis_t_gemv_kernel(const float* __restrict__ basis_dense, const float* __restrict__ dv_shaped,
-                                                           int row, float* __restrict__ dcoef) {
+                                                           int row, float* __restrict__ dcoef, FrontArgs fa) {
   __shared__ float ws[4];
+  __shared__ uint32_t s_ticket;
   const float* b = basis_dense + (size_t)blockIdx.x * row;
   float a = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int i = threadIdx.x;
@@ -322,7 +349,16 @@ __global__ __launch_bounds__(256) void basis_t_gemv_kernel(const float* __restri
   a = wave_sum_all((a + a1) + (a2 + a3));
   if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) dcoef[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+  if (threadIdx.x == 0) {
+    dcoef[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    __threadfence();
+    s_ticket = atomicAdd(reinterpret_cast<uint32_t*>(dcoef + gridDim.x), 1u);
+  }
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;        // uniform over the block
+  __threadfence();
+  if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(dcoef + gridDim.x) = 0u;
+  flame_front_bwd(fa, dcoef);
 }
 
 // axis-angle -> rotation matrix, the formula of flame_fitter.py:133-152: a = aa / (|aa| + 1e-8), R = I + sin K + (1 - cos) K^2
@@ -351,25 +387,34 @@ __global__ void rodrigues_kernel(const float* __restrict__ aa, int n, float* __r
 
 // Gradient of the small FLAME front: (d joint_xf [5][12], d coef [K], d translation) -> (d expr [E], d pose [5][3]).
 // One wave; lane 0 walks the 5-joint chain and the axis-angle maps backwards, all lanes finish d expr.
-__global__ __launch_bounds__(64) void flame_front_bwd_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
-                                                             const float* __restrict__ expr, const float* __restrict__ pose,
-                                                             int n_expr, const float* __restrict__ partial, int n_rows,
-                                                             const float* __restrict__ dcoef, float* __restrict__ dexpr,
-                                                             float* __restrict__ dpose, float* __restrict__ dtrans) {
+// Called by all 256 threads of one block (barriers inside); dcoef was written by other blocks: read through volatile.
+__device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
+  const volatile float* dcoef = dcoef_;
+  const float* j_static = fa.j_static; const float* j_expr = fa.j_expr; const float* expr = fa.expr; const float* pose = fa.pose;
+  const int n_expr = fa.n_expr, n_rows = fa.n_rows;
+  const float* partial = fa.partial;
+  float* dexpr = fa.dexpr; float* dpose = fa.dpose; float* dtrans = fa.dtrans;
   __shared__ float sJ[15], sdJ[15];
   __shared__ float sums[64];
+  __shared__ float part4[4][64];
   const int lane = threadIdx.x;
-  {   // add up the per-wave rows of flame_skin_bwd: lane q owns value q
+  {   // add up the per-wave rows of flame_skin_bwd: thread (w, q) sums value q over the rows r = w (mod 4), in row order
+    const int w = lane >> 6, q = lane & 63;
     float t = 0.f;
-    for (int r = 0; r < n_rows; ++r) t += partial[(size_t)r * 64 + lane];
-    sums[lane] = t;
-    if (lane >= 60 && lane < 63) dtrans[lane - 60] = t;
+    for (int r = w; r < n_rows; r += 4) t += partial[(size_t)r * 64 + q];
+    part4[w][q] = t;
   }
   if (lane < 15) {
     float a = j_static[lane];
     const float* row = j_expr + (size_t)lane * n_expr;
     for (int k = 0; k < n_expr; ++k) a = fma_(row[k], expr[k], a);
     sJ[lane] = a;
+  }
+  __syncthreads();
+  if (lane < 64) {
+    const float t = (part4[0][lane] + part4[1][lane]) + (part4[2][lane] + part4[3][lane]);
+    sums[lane] = t;
+    if (lane >= 60 && lane < 63) dtrans[lane - 60] = t;
   }
   __syncthreads();
   if (lane == 0) {
@@ -460,7 +505,7 @@ __global__ __launch_bounds__(64) void flame_front_bwd_kernel(const float* __rest
     for (int i = 0; i < 15; ++i) sdJ[i] = dJ[i / 3][i % 3];
   }
   __syncthreads();
-  for (int e = lane; e < n_expr; e += 64) {
+  for (int e = lane; e < n_expr; e += 256) {
     float a = dcoef[e];
     for (int i = 0; i < 15; ++i) a = fma_(j_expr[(size_t)i * n_expr + e], sdJ[i], a);
     dexpr[e] = a;
@@ -479,9 +524,52 @@ __global__ void adam_flat_kernel(float* __restrict__ p, const float* __restrict_
   p[i] = p[i] - lr_step * (me / fma_(sqrtf(ve), inv_sqrt_bc2, eps));
 }
 
+// Up to four flat tensors in one launch; the gradient is CONSUMED (zeroed after it is read), so dense gradient tensors of
+// which one row is written per step need no clearing pass.
+struct AdamSeg { float* p; float* g; float* m; float* v; int n; float lr_step; };
+struct AdamSegs { AdamSeg s[4]; int n_seg; };
+__global__ void adam_flat_multi_kernel(AdamSegs segs, float b1, float b2, float eps, float inv_sqrt_bc2, float grad_scale,
+                                       const omfs_step_state* __restrict__ st) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float lr_mul = 1.f;
+  if (st) { lr_mul = st->flame_inv_bc1; inv_sqrt_bc2 = st->flame_inv_sqrt_bc2; }   // device-resident step (graph replay)
+  for (int k = 0; k < segs.n_seg; ++k) {
+    const AdamSeg& sg = segs.s[k];
+    if (i < sg.n) {
+      const float ge = sg.g[i] * grad_scale;
+      sg.g[i] = 0.f;
+      const float me = fma_(b1, sg.m[i], (1.f - b1) * ge);
+      const float ve = fma_(b2, sg.v[i], (1.f - b2) * ge * ge);
+      sg.m[i] = me; sg.v[i] = ve;
+      sg.p[i] = sg.p[i] - (sg.lr_step * lr_mul) * (me / fma_(sqrtf(ve), inv_sqrt_bc2, eps));
+      return;
+    }
+    i -= (sg.n + 255) / 256 * 256;       // segments start on block boundaries
+  }
+}
+
 }  // namespace omfs
 
 using namespace omfs;
+
+extern "C" int omfs_adam_flat_multi(int n_tensors, float* const* params, float* const* grads, float* const* m, float* const* v,
+                                    const int* n, const float* lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                                    const omfs_step_state* state_dev, void* stream) {
+  OMFS_REQUIRE(n_tensors >= 1 && n_tensors <= 4 && params && grads && m && v && n && lr && (state_dev || step >= 1), "args");
+  const double bc1 = state_dev ? 1.0 : 1.0 - pow((double)beta1, step), bc2 = state_dev ? 1.0 : 1.0 - pow((double)beta2, step);
+  AdamSegs segs;
+  segs.n_seg = n_tensors;
+  int blocks = 0;
+  for (int k = 0; k < n_tensors; ++k) {
+    OMFS_REQUIRE(params[k] && grads[k] && m[k] && v[k] && n[k] > 0, "tensor");
+    segs.s[k] = AdamSeg{params[k], grads[k], m[k], v[k], n[k], (float)(lr[k] / bc1)};
+    blocks += cdiv(n[k], 256);
+  }
+  hipLaunchKernelGGL(adam_flat_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, segs, beta1, beta2, eps,
+                     (float)(1.0 / sqrt(bc2)), grad_scale, state_dev);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
 
 extern "C" int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, const float* rotmats, int n_frames,
                                  float* joint_xf, float* coef, const int32_t* frame_index, void* stream) {
@@ -489,7 +577,19 @@ extern "C" int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, c
   OMFS_REQUIRE(n_frames > 0 && rig->n_expr > 0 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36, "shape");
   int b_pad = cdiv(n_frames, 16) * 16;
   hipLaunchKernelGGL(flame_joints_kernel, dim3(b_pad), dim3(64), 0, (hipStream_t)stream, rig->j_static,
-                     rig->j_expr, expr, rotmats, n_frames, rig->n_expr, rig->k_pad, b_pad, joint_xf, coef, frame_index);
+                     rig->j_expr, expr, const_cast<float*>(rotmats), (const float*)nullptr, n_frames, rig->n_expr, rig->k_pad, b_pad,
+                     joint_xf, coef, frame_index);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_flame_joints_pose(const omfs_flame_rig* rig, const float* expr, const float* pose, float* rotmats, int n_frames,
+                                      float* joint_xf, float* coef, const int32_t* frame_index, void* stream) {
+  OMFS_REQUIRE(rig && expr && pose && rotmats && joint_xf && coef, "null pointer");
+  OMFS_REQUIRE(n_frames > 0 && rig->n_expr > 0 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36, "shape");
+  int b_pad = cdiv(n_frames, 16) * 16;
+  hipLaunchKernelGGL(flame_joints_kernel, dim3(b_pad), dim3(64), 0, (hipStream_t)stream, rig->j_static,
+                     rig->j_expr, expr, rotmats, pose, n_frames, rig->n_expr, rig->k_pad, b_pad, joint_xf, coef, frame_index);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
@@ -529,7 +629,7 @@ extern "C" int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t
 
 extern "C" int omfs_flame_skin_rows(const omfs_flame_rig* rig) { return rig ? cdiv(rig->n_verts, 256) * 4 : 0; }
 
-extern "C" int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, const float* dverts,
+extern "C" int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, float* dverts,
                                    float* dv_shaped, float* sums, void* stream) {
   OMFS_REQUIRE(rig && v_shaped && joint_xf && dverts && dv_shaped && sums, "null pointer");
   OMFS_REQUIRE(rig->n_verts > 0 && rig->lbs_weights, "rig");
@@ -552,10 +652,8 @@ extern "C" int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basi
   OMFS_REQUIRE(rig && basis_dense && dv_shaped && expr && pose && sums && dcoef && dexpr && dpose && dtrans, "null pointer");
   OMFS_REQUIRE(n_coef == rig->n_expr + 36 && rig->j_static && rig->j_expr, "shape");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(basis_t_gemv_kernel, dim3(n_coef), dim3(256), 0, s, basis_dense, dv_shaped, 3 * rig->n_verts, dcoef);
-  OMFS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(flame_front_bwd_kernel, dim3(1), dim3(64), 0, s, rig->j_static, rig->j_expr, expr, pose, rig->n_expr, sums,
-                     cdiv(rig->n_verts, 256) * 4, dcoef, dexpr, dpose, dtrans);
+  FrontArgs fa{rig->j_static, rig->j_expr, expr, pose, rig->n_expr, sums, cdiv(rig->n_verts, 256) * 4, dexpr, dpose, dtrans};
+  hipLaunchKernelGGL(basis_t_gemv_kernel, dim3(n_coef), dim3(256), 0, s, basis_dense, dv_shaped, 3 * rig->n_verts, dcoef, fa);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

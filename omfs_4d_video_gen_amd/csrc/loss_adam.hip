@@ -187,19 +187,41 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
 }
 
 struct AdamK {
-  float lr_step[OMFS_NPLANES];  // lr / (1 - b1^t)
+  float lr_step[OMFS_NPLANES];  // lr / (1 - b1^t); with a device-resident step state: the plain lr
   float b1, b2, eps, inv_sqrt_bc2, grad_scale;
 };
+
+// One thread: the per-iteration scalars of a training step, on the device (see omfs_step_state in the header).
+__global__ void step_advance_kernel(omfs_step_state* st, omfs_lr_schedule sch) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int done = st->step;                    // iterations completed before this one
+  const int step = done + 1, fstep = st->flame_step + 1;
+  st->step = step; st->flame_step = fstep;
+  double lr = (double)sch.lr_init;
+  if (sch.lr_init != sch.lr_final && sch.max_steps > 0) {
+    const double t = fmin(fmax((double)done / (double)sch.max_steps, 0.0), 1.0);
+    lr = exp(log((double)sch.lr_init) * (1.0 - t) + log((double)sch.lr_final) * t);
+  }
+  st->lr_xyz = (float)lr;
+  st->inv_bc1 = (float)(1.0 / (1.0 - pow((double)sch.beta1, (double)step)));
+  st->inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)sch.beta2, (double)step)));
+  st->flame_inv_bc1 = (float)(1.0 / (1.0 - pow((double)sch.beta1, (double)fstep)));
+  st->flame_inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow((double)sch.beta2, (double)fstep)));
+}
 
 // grid = (n_pad/1024 [float4 x 256], 59)
 __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g,
                                                    float4* __restrict__ m, float4* __restrict__ v, int n4_per_plane,
-                                                   AdamK k, int plane0) {
+                                                   AdamK k, int plane0, const omfs_step_state* __restrict__ st) {
   const int plane = plane0 + blockIdx.y;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4_per_plane) return;
   const size_t o = (size_t)plane * n4_per_plane + i;
-  const float lr = k.lr_step[plane];
+  float lr = k.lr_step[plane];
+  if (st) {      // device-resident schedule (graph replay): position planes take this iteration's rate, all take its bias corrections
+    lr = (plane < OMFS_P_SCALE ? st->lr_xyz : lr) * st->inv_bc1;
+    k.inv_sqrt_bc2 = st->inv_sqrt_bc2;
+  }
   float4 pp = p[o], gg = g[o], mm = m[o], vv = v[o];
   auto upd = [&](float& pe, float ge, float& me, float& ve) {
     ge *= k.grad_scale;
@@ -248,28 +270,48 @@ extern "C" int omfs_loss_l1_ssim(const float* image, const float* target, int wi
 }
 
 static int adam_launch(float* params, const float* grads, float* m, float* v, int n, int n_pad, const omfs_adam_params* ap,
-                       int plane0, int n_planes, void* stream) {
+                       int plane0, int n_planes, const omfs_step_state* state_dev, void* stream) {
   OMFS_REQUIRE(params && grads && m && v && ap, "null pointer");
-  OMFS_REQUIRE(n > 0 && n_pad >= n && n_pad % 256 == 0 && ap->step >= 1, "shape");
+  OMFS_REQUIRE(n > 0 && n_pad >= n && n_pad % 256 == 0 && (state_dev || ap->step >= 1), "shape");
   OMFS_REQUIRE(plane0 >= 0 && n_planes >= 1 && plane0 + n_planes <= OMFS_NPLANES, "plane range");
   AdamK k;
-  const double bc1 = 1.0 - pow((double)ap->beta1, ap->step), bc2 = 1.0 - pow((double)ap->beta2, ap->step);
-  for (int i = 0; i < OMFS_NPLANES; ++i) k.lr_step[i] = (float)(ap->lr[i] / bc1);
-  k.b1 = ap->beta1; k.b2 = ap->beta2; k.eps = ap->eps; k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  if (state_dev) {
+    for (int i = 0; i < OMFS_NPLANES; ++i) k.lr_step[i] = ap->lr[i];
+    k.inv_sqrt_bc2 = 1.f;
+  } else {
+    const double bc1 = 1.0 - pow((double)ap->beta1, ap->step), bc2 = 1.0 - pow((double)ap->beta2, ap->step);
+    for (int i = 0; i < OMFS_NPLANES; ++i) k.lr_step[i] = (float)(ap->lr[i] / bc1);
+    k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  }
+  k.b1 = ap->beta1; k.b2 = ap->beta2; k.eps = ap->eps;
   k.grad_scale = ap->grad_scale;
   const int n4 = n_pad / 4;
   hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n4, 256), n_planes), dim3(256), 0, (hipStream_t)stream, (float4*)params,
-                     (const float4*)grads, (float4*)m, (float4*)v, n4, k, plane0);
+                     (const float4*)grads, (float4*)m, (float4*)v, n4, k, plane0, state_dev);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
 
+extern "C" int omfs_step_advance(omfs_step_state* state_dev, const omfs_lr_schedule* sch, void* stream) {
+  OMFS_REQUIRE(state_dev && sch && sch->beta1 > 0.f && sch->beta1 < 1.f && sch->beta2 > 0.f && sch->beta2 < 1.f, "args");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, *sch);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_adam_step_dev(float* params, const float* grads, float* m, float* v, int n, int n_pad,
+                                  const omfs_adam_params* ap, const omfs_step_state* state_dev, int plane0, int n_planes,
+                                  void* stream) {
+  OMFS_REQUIRE(state_dev, "state_dev");
+  return adam_launch(params, grads, m, v, n, n_pad, ap, plane0, n_planes, state_dev, stream);
+}
+
 extern "C" int omfs_adam_step(float* params, const float* grads, float* m, float* v, int n, int n_pad,
                               const omfs_adam_params* ap, void* stream) {
-  return adam_launch(params, grads, m, v, n, n_pad, ap, 0, OMFS_NPLANES, stream);
+  return adam_launch(params, grads, m, v, n, n_pad, ap, 0, OMFS_NPLANES, nullptr, stream);
 }
 
 extern "C" int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v, int n, int n_pad,
                                      const omfs_adam_params* ap, int plane0, int n_planes, void* stream) {
-  return adam_launch(params, grads, m, v, n, n_pad, ap, plane0, n_planes, stream);
+  return adam_launch(params, grads, m, v, n, n_pad, ap, plane0, n_planes, nullptr, stream);
 }

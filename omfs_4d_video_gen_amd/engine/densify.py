@@ -116,6 +116,7 @@ class DensityController:
         t.opt.m, t.opt.v = adam_m, adam_v
         t.grads = torch.zeros(NPLANES, n_pad, device=params.device)
         t.densify_stats = torch.zeros(2, n_pad, device=params.device)
+        t.invalidate_graphs()          # captured iterations refer to the buffers just replaced
         # stale projections beyond the new count must not look visible
         t.rast.g2[n:].zero_()
 

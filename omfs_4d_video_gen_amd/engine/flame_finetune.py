@@ -7,9 +7,15 @@ Gradient path, all HIP (include/omfs_splat.h): composite_bwd -> project_bwd (dL/
 vertices, dL/d joint transforms, dL/d translation) -> `omfs_flame_param_bwd` (basis^T product, 5-joint kinematic chain,
 axis-angle map of `flame_fitter.py:122-152`) -> `omfs_adam_flat`.  The parameters ARE the device arrays the FLAME
 forward kernels read (`DeviceFlame.expr / .translation`, rotation matrices refreshed from the axis-angle poses by
-`omfs_flame_rodrigues`), so nothing is copied per step; seven small launches, no host math.
+the joints launch, `omfs_flame_joints_pose`), so nothing is copied per step.  Per step: three forward launches (joints +
+Rodrigues, LBS, triangle frames), three backward launches (`dverts` and the gradient tensors are consumed = left zeroed
+by their readers, the basis^T product and the serial front share a launch) and ONE Adam launch for the three parameter
+tensors; no host math.  The trainer runs this chain on a second stream underneath the Gaussians' Adam pass.
 """
+
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 import torch
@@ -49,16 +55,22 @@ class FlameFineTuner:
         # dense basis [K][3V] (column 3v+c): blend-shape recompute per vertex and the transpose product
         self.basis = up(dflame.h_basis.transpose(0, 2, 1).reshape(self.n_coef, 3 * V))
         dflame.keep_v_shaped = True
+        dflame.pose = self.pose                              # the joints launch refreshes rotmats from these
         dflame._scratch.clear()
         self.dface = None                                    # [n_capacity][16] per-Gaussian frame-gradient records
         self._csr_key, self.face_start, self.face_gauss = None, None, None
         self.dverts = torch.zeros(dflame.v_pad, 4, device=dev)
         self.dv_shaped = torch.empty(V, 3, device=dev)
         self.sums = torch.zeros(int(L.load().omfs_flame_skin_rows(dflame.c_rig)), 64, device=dev)   # one row per wave
-        self.dcoef = torch.empty(self.n_coef, device=dev)
+        self.dcoef = torch.zeros(self.n_coef + 1, device=dev)     # + the last-block ticket of omfs_flame_param_bwd (kept zero)
         self._t = None
-        self._last_t = None
         self.refresh_rotmats()
+        # host-side argument arrays of the one Adam launch (device pointers of the three tensors, sizes, learning rates)
+        keys = ("expr", "pose", "translation")
+        arr = lambda seq: (C.c_void_p * 3)(*[L.ptr(t) for t in seq])
+        self._adam_args = (arr([self.params[k] for k in keys]), arr([self.grad[k] for k in keys]), arr([self.m[k] for k in keys]),
+                           arr([self.v[k] for k in keys]), (C.c_int * 3)(*[self.params[k].numel() for k in keys]),
+                           (C.c_float * 3)(*[float(self.lr[k]) for k in keys]))
 
     def refresh_rotmats(self):
         """All timesteps: axis-angle poses -> the rotation matrices the forward kernels read."""
@@ -80,13 +92,9 @@ class FlameFineTuner:
         self._csr_key = key
 
     def begin(self, t: int, binding: torch.Tensor, all_timesteps: bool = False):
-        """Before the FLAME forward of timestep t: its rotation matrices from the current poses (all timesteps when the
-        forward poses other ranks' views as well)."""
+        """Before the FLAME forward of timestep t (the forward itself turns the current poses of the rows it shows into
+        rotation matrices: `DeviceFlame.pose`)."""
         self.bind(binding)
-        if all_timesteps:
-            self.refresh_rotmats()
-        else:
-            L.check(L.load().omfs_flame_rodrigues(L.ptr(self.pose[t]), 5, L.ptr(self.df.rotmats[t]), L.stream_ptr()), "omfs_flame_rodrigues")
         self._t = t
 
     def backward(self, verts: torch.Tensor, nb: int = 1, col: int = 0):
@@ -98,10 +106,7 @@ class FlameFineTuner:
         lib, s = L.load(), L.stream_ptr()
         joint_all, _, _, _, vs_all = df._buffers(nb)        # written by the FLAME forward kernels
         joint_xf, v_shaped = joint_all[col], vs_all[col]
-        self.dverts.zero_()
-        if self._last_t is not None and self._last_t != t:
-            for g in self.grad.values():
-                g[self._last_t].zero_()
+        # dverts was left zeroed by the last omfs_flame_skin_bwd, the gradient rows by the last Adam launch
         L.check(lib.omfs_face_frames_bwd(L.ptr(verts), df.v_pad, L.ptr(df.faces), df.rig.n_faces, L.ptr(self.dface),
                                          L.ptr(self.face_start), L.ptr(self.face_gauss), L.ptr(self.dverts), s), "omfs_face_frames_bwd")
         L.check(lib.omfs_flame_skin_bwd(df.c_rig, L.ptr(v_shaped), L.ptr(joint_xf), L.ptr(self.dverts), L.ptr(self.dv_shaped),
@@ -109,23 +114,24 @@ class FlameFineTuner:
         L.check(lib.omfs_flame_param_bwd(df.c_rig, L.ptr(self.basis), self.n_coef, L.ptr(self.dv_shaped), L.ptr(self.expr[t]),
                                          L.ptr(self.pose[t]), L.ptr(self.sums), L.ptr(self.dcoef), L.ptr(self.grad["expr"][t]),
                                          L.ptr(self.grad["pose"][t]), L.ptr(self.grad["translation"][t]), s), "omfs_flame_param_bwd")
-        self._last_t = t
         self._t = None
 
     def grads(self):
         return [self.grad["expr"], self.grad["pose"], self.grad["translation"]]
 
-    def step(self, grad_scale: float = 1.0):
-        """Dense Adam over all timesteps (torch.optim.Adam semantics, as upstream)."""
-        self.step_count += 1
-        lib, s = L.load(), L.stream_ptr()
-        for k, p in self.params.items():
-            L.check(lib.omfs_adam_flat(L.ptr(p), L.ptr(self.grad[k]), L.ptr(self.m[k]), L.ptr(self.v[k]), p.numel(),
-                                       float(self.lr[k]), self.betas[0], self.betas[1], self.eps, self.step_count,
-                                       float(grad_scale), s), "omfs_adam_flat")
+    def step(self, grad_scale: float = 1.0, state_dev: int = 0):
+        """Dense Adam over all timesteps (torch.optim.Adam semantics, as upstream).  state_dev: device pointer of an
+        omfs_step_state whose flame_step / bias corrections replace the host-side step count (graph replay; the caller keeps
+        `step_count` in step with it)."""
+        if not state_dev:
+            self.step_count += 1
+        a = self._adam_args
+        L.check(L.load().omfs_adam_flat_multi(3, a[0], a[1], a[2], a[3], a[4], a[5], self.betas[0], self.betas[1], self.eps,
+                                              max(self.step_count, 1), float(grad_scale), state_dev, L.stream_ptr()), "omfs_adam_flat_multi")
 
     # ---- checkpoint / egress
     def state_dict(self) -> dict:
+        torch.cuda.synchronize(self.df.device)      # the parameters are updated on the trainer's side stream
         cpu = lambda d: {k: v.detach().cpu() for k, v in d.items()}
         return {"params": cpu(self.params), "m": cpu(self.m), "v": cpu(self.v), "step": self.step_count}
 
@@ -137,6 +143,7 @@ class FlameFineTuner:
 
     def to_flame_params(self, base: dict) -> dict:
         """The tuned sequence in the dataset schema of flame_fitter.py:431-441."""
+        torch.cuda.synchronize(self.df.device)      # the parameters are updated on the trainer's side stream
         out = {k: np.array(v) for k, v in base.items()}
         pose = self.pose.detach().cpu().numpy().reshape(-1, 5, 3)
         T = pose.shape[0]

@@ -312,6 +312,7 @@ class DeviceFlame:
                                  L.ptr(self.lbs_weights), L.ptr(self.j_static), L.ptr(self.j_expr))
         self._scratch = {}
         self.keep_v_shaped = False     # FLAME fine-tuning: flame_lbs also stores the blend-shaped vertices
+        self.pose = None               # FLAME fine-tuning: axis-angle poses [T][15]; rotmats are then refreshed by the joints launch
         self.slot = 0                  # output buffer set (the trainer poses the next step's frames on a side stream)
 
     def _buffers(self, nb: int):
@@ -331,7 +332,8 @@ class DeviceFlame:
         if not (0 <= t0 and t0 + nb <= self.n_frames):
             raise IndexError(f"frames [{t0},{t0 + nb}) outside sequence of {self.n_frames}")
         return self._run(L.ptr(self.expr[t0]), L.ptr(self.rotmats[t0]), L.ptr(self.translation[t0]),
-                         L.ptr(self.dynamic[t0]) if self.dynamic is not None else 0, nb, 0, out)
+                         L.ptr(self.dynamic[t0]) if self.dynamic is not None else 0, nb, 0, out,
+                         L.ptr(self.pose[t0]) if self.pose is not None else 0)
 
     def face_frames_indexed(self, frame_index: torch.Tensor):
         """Arbitrary timesteps in one batch: frame_index is a device int32 tensor [nb] of sequence rows.
@@ -339,15 +341,20 @@ class DeviceFlame:
         if frame_index.dtype != torch.int32 or not frame_index.is_cuda or frame_index.dim() != 1:
             raise ValueError("frame_index must be a 1-D int32 device tensor")
         return self._run(L.ptr(self.expr), L.ptr(self.rotmats), L.ptr(self.translation),
-                         L.ptr(self.dynamic) if self.dynamic is not None else 0, int(frame_index.shape[0]), L.ptr(frame_index), None)
+                         L.ptr(self.dynamic) if self.dynamic is not None else 0, int(frame_index.shape[0]), L.ptr(frame_index), None,
+                         L.ptr(self.pose))
 
-    def _run(self, expr_p, rot_p, trans_p, dyn_p, nb, index_p, out):
+    def _run(self, expr_p, rot_p, trans_p, dyn_p, nb, index_p, out, pose_p=0):
         lib = L.load()
         s = L.stream_ptr()
         joint_xf, coef, verts, face_xf, v_shaped = self._buffers(nb)
         if out is not None:
             face_xf = out
-        L.check(lib.omfs_flame_joints(self.c_rig, expr_p, rot_p, nb, L.ptr(joint_xf), L.ptr(coef), index_p, s), "omfs_flame_joints")
+        if pose_p:     # rotation matrices from the current axis-angle poses, in the same launch
+            L.check(lib.omfs_flame_joints_pose(self.c_rig, expr_p, pose_p, rot_p, nb, L.ptr(joint_xf), L.ptr(coef), index_p, s),
+                    "omfs_flame_joints_pose")
+        else:
+            L.check(lib.omfs_flame_joints(self.c_rig, expr_p, rot_p, nb, L.ptr(joint_xf), L.ptr(coef), index_p, s), "omfs_flame_joints")
         L.check(lib.omfs_flame_lbs(self.c_rig, L.ptr(coef), L.ptr(joint_xf), trans_p, dyn_p, nb, L.ptr(verts), L.ptr(v_shaped),
                                    index_p, s), "omfs_flame_lbs")
         L.check(lib.omfs_face_frames(L.ptr(verts), self.v_pad, L.ptr(self.faces), self.rig.n_faces, nb, L.ptr(face_xf), s),

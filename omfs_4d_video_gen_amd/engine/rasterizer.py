@@ -57,7 +57,7 @@ class Rasterizer:
         self.keys = z(self.dup_capacity, 2, dt=torch.int32)
         self.keys_tmp = z(self.dup_capacity, 2, dt=torch.int32)
         self.sorted_ids = z(self.dup_capacity, dt=torch.int32)
-        self.status = z(1, dt=torch.int32)
+        self.status = z(2, dt=torch.int32)      # word 0: overflow flag; word 1: the library's tile-test replay stamp
         self.seg_capacity = self.n_tiles + self.dup_capacity // L.SEG + 1
         self.seg_ckpt = z(self.seg_capacity, 256, 4)
         self.order_seg0 = z(self.n_tiles + 1, dt=torch.int32)
@@ -123,7 +123,7 @@ class Rasterizer:
 
     def overflowed(self) -> bool:
         """Host sync: did the device flag a tile-list capacity overflow since the flag was last cleared?"""
-        return bool(int(self.status.item()) & 1)
+        return bool(int(self.status[0].item()) & 1)
 
     def check_status(self):
         """Host sync: raise if the device flagged a capacity overflow."""

@@ -113,6 +113,13 @@ class Trainer:
             cp = np.stack([np.asarray(make_camera_struct(v.camera).cam_pos, np.float32) for v in views])
             self.cam_pos_table = torch.from_numpy(cp).to(self.device)
         self._side_stream = torch.cuda.Stream(device=self.device)
+        # whole iterations as hipGraphs (one per view and buffer parity; single GPU): the step-dependent scalars -- position
+        # learning rate, Adam bias corrections -- live in an omfs_step_state on the device, advanced by the graph's first node
+        self.use_graph = world_size == 1 and os.environ.get("OMFS_STEP_GRAPH", "1") != "0"
+        self._graphs, self._graph_seen = {}, set()
+        self._state = torch.zeros(L.STEP_STATE_WORDS, dtype=torch.int32, device=self.device)
+        self._state_step, self._frames_ready = -1, None
+        self._sched = L.LrScheduleC(float(position_lr_init), float(position_lr_final), int(iterations), 0.9, 0.999)
         self._events = [(torch.cuda.Event(), torch.cuda.Event()), (torch.cuda.Event(), torch.cuda.Event())]
         self._prefetch = None
         self._target_f32 = None
@@ -175,19 +182,147 @@ class Trainer:
         from .distributed import view_index
         return self.views[view_index(step, self.rank, self.world, len(self.views))]
 
+    # ------------------------------------------------------------------ hipGraph replay of whole iterations
+    def _graph_key(self, it: int):
+        from .distributed import view_index
+        vi = view_index(it, self.rank, self.world, len(self.views))
+        return (vi, it & 1, self.sh_degree, self.model.n, self.model.params.data_ptr(), L.ptr(self.densify_stats),
+                self.views[vi].target.data_ptr(), self.rast.keys.data_ptr())
+
+    def invalidate_graphs(self) -> None:
+        """Buffers a captured iteration refers to were replaced (densification): forget every graph."""
+        self._graphs.clear()
+        self._graph_seen.clear()
+
+    def _graph_eligible(self) -> bool:
+        return (self.use_graph and not self.dp and not self.timer.enabled
+                and (self.flame_ft is not None or self._frames_all is not None))
+
+    def _capture_step(self, it: int):
+        """Capture iteration `it` (its view, camera, buffers; the step-dependent scalars live in self._state on the device).
+        With FLAME fine-tuning the graph expects the frames of this view in buffer set it&1 and leaves the next view's in the
+        other one: FLAME backward + FLAME Adam + next FLAME forward fork onto the side stream under the Gaussians' Adam."""
+        view = self.view_for_step(it)
+        cam = self._cam(view, self.sh_degree)
+        r, ft, lib = self.rast, self.flame_ft, L.load()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            s = L.stream_ptr()
+            L.check(lib.omfs_step_advance(L.ptr(self._state), self._sched, s), "omfs_step_advance")
+            if ft is not None:
+                self.dflame.slot = it & 1
+                _, _, verts_all, face_all, _ = self.dflame._buffers(1)
+                fxf, verts = face_all[0], verts_all[0]
+            else:
+                fxf, verts = self._frames_all[view.timestep], None
+            g = r._gauss(self.model)
+            r.project(self.model, fxf, cam)
+            L.check(lib.omfs_bin_count(g, cam, r.rb, s), "omfs_bin_count")
+            L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan")
+            L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter")
+            L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort")
+            r.composite(cam)
+            target = view.target
+            if target.dtype == torch.uint8:
+                if self._target_f32 is None:
+                    raise RuntimeError("8-bit targets: run one eager step first")
+                L.check(lib.omfs_rgb8_to_image(L.ptr(target), r.width, r.height, L.ptr(self._target_f32), s), "omfs_rgb8_to_image")
+                target = self._target_f32
+            r.loss_l1_ssim(target, self.lambda_dssim)
+            gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
+                                L.ptr(ft.dface) if ft is not None else 0, 0)
+            L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd")
+            rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
+            L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd")
+            join = None
+            if ft is not None:
+                fork, join = torch.cuda.Event(), torch.cuda.Event()
+                fork.record()
+                with torch.cuda.stream(self._side_stream):
+                    self._side_stream.wait_event(fork)
+                    ft._t = view.timestep
+                    ft.backward(verts, 1, 0)
+                    ft.step(1.0, state_dev=L.ptr(self._state))
+                    self.dflame.slot = (it + 1) & 1
+                    self._pose_frames(it + 1)
+                    join.record(self._side_stream)
+                self.dflame.slot = it & 1
+            m = self.model
+            self.opt.ap.grad_scale = 1.0
+            L.check(lib.omfs_adam_step_dev(L.ptr(m.params), L.ptr(self.grads), L.ptr(self.opt.m), L.ptr(self.opt.v), m.n, m.n_pad,
+                                           self.opt.ap, L.ptr(self._state), 0, NPLANES, s), "omfs_adam_step_dev")
+            if join is not None:
+                torch.cuda.current_stream().wait_event(join)
+        return graph
+
+    def _step_graph(self, it: int) -> bool:
+        """Replay (capturing it on the second visit of its key) the graph of iteration `it`; False: the caller steps eagerly."""
+        key = self._graph_key(it)
+        graph = self._graphs.get(key)
+        if graph is None:
+            if key not in self._graph_seen:      # first visit: eager (one-off work such as function attributes happens there)
+                self._graph_seen.add(key)
+                return False
+            if len(self._graphs) > 4 * max(len(self.views), 1):
+                self._graphs.clear()
+        view = self.view_for_step(it)
+        ft = self.flame_ft
+        if self._state_step != it:               # eager iterations ran in between: hand the step counts to the device
+            self._state[:2].copy_(torch.tensor([self.opt.step_count, ft.step_count if ft is not None else 0], dtype=torch.int32))
+        if ft is not None:
+            ft.bind(self.model.binding)
+            for slot in (0, 1):                  # both buffer sets exist before anything is captured (no allocation inside)
+                self.dflame.slot = slot
+                self.dflame._buffers(1)
+            if self._frames_ready != (it, view.timestep):      # the previous iteration was not a replay: pose this view now
+                torch.cuda.current_stream().wait_stream(self._side_stream)
+                self.dflame.slot = it & 1
+                self._pose_frames(it)
+        if graph is None:
+            self.opt.set_lr(self.lr_planes)
+            graph = self._graphs[key] = self._capture_step(it)
+        graph.replay()
+        self.opt.step_count += 1
+        if ft is not None:
+            ft.step_count += 1
+            self._frames_ready = (it + 1, self.view_for_step(it + 1).timestep)
+        self._state_step = it + 1
+        return True
+
     def step(self) -> None:
         """One training iteration of this rank (enqueue only)."""
         it = self.step_idx
         view = self.view_for_step(it)
         if it > 0 and it % self.sh_every == 0 and self.sh_degree < self.sh_degree_max:
             self.sh_degree += 1
+        if self._graph_eligible():
+            try:
+                if self._step_graph(it):
+                    self.step_idx += 1
+                    return
+            except Exception as e:      # a failed capture must not cost the run: say so, go on eagerly
+                print(f"[engine] hipGraph capture of the training iteration failed ({type(e).__name__}: {e}); continuing without graphs")
+                self.use_graph = False
+                self._graphs.clear()
+                torch.cuda.synchronize()
         cam = self._cam(view, self.sh_degree)
         r, tm = self.rast, self.timer
         tm.begin()
         ft = self.flame_ft
-        if ft is not None:             # rotation matrices from the current poses
+        # FLAME fine-tuning on one GPU: the FLAME backward chain, the FLAME parameters' Adam and the NEXT step's FLAME forward
+        # run on the side stream underneath the Gaussians' Adam pass (nothing of it touches the Gaussian parameters); the
+        # posed buffers alternate between two sets
+        ft_pipe = ft is not None and not self.dp
+        if ft is not None:
             ft.begin(view.timestep, self.model.binding, all_timesteps=self.compact_dp)
-            verts, face_xf, nb, col, pat = self._pose_frames(it)
+            if ft_pipe and self._prefetch is not None and self._prefetch[0] == (it, view.timestep):
+                torch.cuda.current_stream().wait_event(self._prefetch[1])
+                self.dflame.slot = it & 1
+                verts, face_xf, nb, col, pat = self._prefetch[2]
+            else:
+                if ft_pipe:
+                    self.dflame.slot = it & 1
+                verts, face_xf, nb, col, pat = self._pose_frames(it)
         elif self._frames_all is not None:
             # the sequence is fixed and its frames are resident: nothing to pose
             if self.compact_dp:            # the frames of ALL ranks' views of this step, one row per rank
@@ -248,7 +383,21 @@ class Trainer:
             gather = allgather_into_(self.drgb_all, self.drgb_local, self.pg, async_op=True)
         rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
         L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
-        if ft is not None:
+        if ft_pipe:
+            ev_main, ev_side = self._events[it & 1]
+            ev_main.record()                                    # dface of this step is complete
+            with torch.cuda.stream(self._side_stream):
+                self._side_stream.wait_event(ev_main)
+                ft.backward(verts[col], nb, col)
+                ft.step(1.0)
+                nview = self.view_for_step(it + 1)
+                self.dflame.slot = (it + 1) & 1
+                nxt = self._pose_frames(it + 1)
+                ev_side.record(self._side_stream)
+            self._prefetch = ((it + 1, nview.timestep), ev_side, nxt)
+            self.dflame.slot = it & 1
+            tm.mark("flame_bwd")
+        elif ft is not None:
             ft.backward(verts[col], nb, col); tm.mark("flame_bwd")
         if self.dp:
             from .distributed import allgather_into_, allreduce_sum_
@@ -278,7 +427,7 @@ class Trainer:
             self.opt.apply_planes(self.grads, 0, P_SH + 3)
         else:
             self.opt.step(self.grads, 1.0 / self.world)
-        if ft is not None:
+        if ft is not None and not ft_pipe:
             ft.step(1.0 / self.world)
         tm.mark("adam")
         self.step_idx += 1

@@ -191,3 +191,11 @@ def test_render_uses_tuned_flame_plus_dataset_edits(tmp_path):
     assert np.allclose(out["expr"], tuned["expr"]) and np.array_equal(out["shape"], src["shape"])
     other = {k: (v[:3] if k != "shape" else v) for k, v in src.items()}           # a different sequence: dataset wins
     assert tuned_flame(tmp_path, other) is other
+
+
+def test_every_engine_module_imports_without_a_gpu():
+    """Import errors in modules that only GPU tests exercise must not wait for the GPU box."""
+    import importlib
+    for name in ("densify", "distributed", "flame_finetune", "flame_rig", "gaussians", "io_formats", "rasterizer", "render", "rig_loader",
+                 "synthetic", "train", "trainer"):
+        importlib.import_module(f"omfs_4d_video_gen_amd.engine.{name}")

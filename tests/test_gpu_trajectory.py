@@ -113,3 +113,56 @@ def test_posing_per_step_on_the_side_stream_equals_the_resident_frame_table(monk
     noise = np.abs(pa - pc).mean(axis=1) + 1e-8          # what two runs of the same mode differ by
     assert (np.abs(pa - pb).mean(axis=1) <= 10.0 * noise + 1e-6).all()
     assert np.allclose(la, lb, rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("finetune", [False, True])
+def test_graph_replay_of_whole_iterations_matches_eager_steps(finetune):
+    """Single GPU: from the second visit of a view on, an iteration is ONE hipGraph replay -- position learning rate and Adam
+    bias corrections come from the device-resident omfs_step_state the graph's first node advances.  Same losses and (up to
+    the order of float atomics, which Adam's sign-like first steps amplify) the same parameters as the eager iterations."""
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, Trainer, View
+    n, Wd, Hd, steps = 6000, 160, 120, 48
+    srig = synthetic.make_rig(0)
+    rig = FlameRig.from_synthetic(srig)
+    seq = synthetic.make_flame_sequence(4, 0)
+    cams = synthetic.make_camera_arc(Wd, Hd, 4)
+    g0, g1 = synthetic.make_gaussians(n, rig.n_faces, 0), synthetic.make_gaussians(n, rig.n_faces, 1)
+    rr = Renderer(rig, seq, g1, Wd, Hd)
+    views = []
+    for i, c in enumerate(cams):
+        v = View(c, timestep=i)
+        v.target = rr.render(v).clone()
+        views.append(v)
+    runs = {}
+    for mode in ("eager", "graph"):
+        tr = Trainer(rig, {k: np.array(v) for k, v in seq.items()}, g0, views, Wd, Hd, iterations=300, start_sh_degree=3,
+                     finetune_flame=finetune, position_lr_init=5e-3, position_lr_final=5e-5)
+        tr.use_graph = mode == "graph"
+        losses = []
+        for _ in range(steps):
+            tr.step()
+            losses.append(tr.loss_value())
+        torch.cuda.synchronize()
+        tr.rast.check_status()
+        runs[mode] = (tr, np.array(losses))
+    te, le = runs["eager"]
+    tg, lg = runs["graph"]
+    assert len(te._graphs) == 0 and len(tg._graphs) == 4            # one graph per view (4 views: parity follows the view)
+    assert tg.opt.step_count == te.opt.step_count == steps and tg.step_idx == steps
+    st = tg._state.cpu()
+    assert int(st[0]) == steps and (not finetune or int(st[1]) == steps)
+    assert np.abs(lg - le).max() < 2e-3 * le.max(), (lg[-4:], le[-4:])
+    assert lg[-4:].mean() < 0.9 * lg[:4].mean()
+    for lo, hi in ((0, 3), (3, 6), (6, 10), (10, 11), (11, 59)):
+        a, b = tg.model.params[lo:hi, :n].cpu().numpy(), te.model.params[lo:hi, :n].cpu().numpy()
+        d = np.abs(a - b)
+        assert d.mean() <= 2e-4 * max(1.0, np.abs(b).max()) and d.max() <= 5e-2, (lo, d.mean(), d.max())
+    if finetune:
+        for k in ("expr", "pose", "translation"):
+            a, b = tg.flame_ft.params[k].cpu().numpy(), te.flame_ft.params[k].cpu().numpy()
+            d, sc = np.abs(a - b), np.abs(b).max()
+            assert d.mean() <= 1e-3 * sc + 1e-6 and d.max() <= 0.05 * sc + 1e-4, (k, d.mean(), d.max(), sc)
+    # the position learning rate the graph used at the last iteration is the eager schedule's
+    from omfs_4d_video_gen_amd.engine.trainer import expon_lr
+    assert abs(float(st.view(torch.float32)[2]) - expon_lr(steps - 1, 5e-3, 5e-5, 300)) < 1e-9 + 1e-6 * 5e-3
