@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--no_aux", action="store_true")
     ap.add_argument("--profile_steps", type=int, default=40)
     ap.add_argument("--frozen_flame", action="store_true", help="headline step with a fixed FLAME sequence (--not_finetune_flame_params)")
+    ap.add_argument("--input_order", action="store_true", help="keep the cloud in its input order (binding i mod F) instead of the surface-coherent storage order")
     return ap.parse_args()
 
 
@@ -216,7 +217,8 @@ def main():
     # upstream's default for --bind_to_mesh (the reference's argv passes no opt-out, train_ghost.py:227-237): the per-timestep
     # FLAME parameters are optimised with the Gaussians, so FLAME LBS + triangle frames are posed INSIDE the timed step
     trainer = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3,
-                      rank=rank, world_size=world, process_group=pg, finetune_flame=not args.frozen_flame)
+                      rank=rank, world_size=world, process_group=pg, finetune_flame=not args.frozen_flame,
+                      coherent_order=not args.input_order)
 
     def barrier():
         if world > 1:
@@ -325,7 +327,7 @@ def main():
 
     # ---- aux: render_surgery fps on the same scene (frames shard across ranks, no collective)
     if not args.no_aux:
-        rr = Renderer(rig, seq, g_init, W, H)
+        rr = Renderer(rig, seq, g_init, W, H, coherent_order=not args.input_order)
         frames = [View(cams[i % len(cams)], timestep=i % T) for i in range(rank, args.render_frames, world)]
         for v in frames[:5]:
             rr.render(v, rgb8=True)
@@ -382,7 +384,8 @@ def main():
             # the same training step with the other setting of the FLAME switch (--not_finetune_flame_params: fixed sequence,
             # triangle frames resident) -- not the headline
             del rr
-            tf = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3, finetune_flame=args.frozen_flame)
+            tf = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3, finetune_flame=args.frozen_flame,
+                         coherent_order=not args.input_order)
             for _ in range(20):
                 tf.step()
             torch.cuda.synchronize()

@@ -320,6 +320,12 @@ int omfs_adam_step(float* params, const float* grads, float* m, float* v, int n,
 int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v, int n, int n_pad,
                           const omfs_adam_params* ap, int plane0, int n_planes, void* stream);
 
+/* The same step on the flat range [offset, offset + count) of the [59][n_pad] buffers (both multiples of 4): the shard a
+ * data-parallel rank owns after a reduce-scatter of the gradient ("sharded" exchange: reduce-scatter, Adam on 1/W of the
+ * elements, all-gather of the updated parameters).  params / grads / m / v point at the START of the range. */
+int omfs_adam_step_range(float* params, const float* grads, float* m, float* v, int n_pad, long long offset, long long count,
+                         const omfs_adam_params* ap, void* stream);
+
 /* ---- device-resident per-iteration scalars.  With them nothing about a training iteration is a kernel ARGUMENT any more
  * (the learning-rate schedule and Adam's bias corrections were the last ones), so a whole iteration can be captured in a
  * hipGraph once per view and replayed.  omfs_step_advance (one thread) increments both step counters and derives, in double

@@ -108,6 +108,8 @@ SIGNATURES = {
     "omfs_adam_flat_multi": (C.c_int, [C.c_int, C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p), C.POINTER(c_void_p),
                                        C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.c_int, C.c_float,
                                        c_void_p, c_void_p]),
+    "omfs_adam_step_range": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_longlong, C.c_longlong,
+                                       C.POINTER(AdamParamsC), c_void_p]),
     "omfs_step_advance": (C.c_int, [c_void_p, C.POINTER(LrScheduleC), c_void_p]),
     "omfs_adam_step_dev": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), c_void_p,
                                      C.c_int, C.c_int, c_void_p]),

@@ -237,6 +237,31 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
   p[o] = pp; m[o] = mm; v[o] = vv;
 }
 
+// The same update on a flat range [offset, offset + count) of the [59][n_pad] buffers (count, offset multiples of 4):
+// a data-parallel rank that owns one contiguous shard of the reduce-scattered gradient.  p / g / m / v point at the
+// START of the range; the plane of element offset + i selects the learning rate.
+__global__ __launch_bounds__(256) void adam_range_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                         float4* __restrict__ v, long long offset4, long long count4, int n4_per_plane,
+                                                         AdamK k) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count4) return;
+  const int plane = (int)((offset4 + i) / n4_per_plane);
+  const float lr = k.lr_step[plane];
+  float4 pp = p[i], gg = g[i], mm = m[i], vv = v[i];
+  auto upd = [&](float& pe, float ge, float& me, float& ve) {
+    ge *= k.grad_scale;
+    me = fma_(k.b1, me, (1.f - k.b1) * ge);
+    ve = fma_(k.b2, ve, (1.f - k.b2) * ge * ge);
+    const float denom = fma_(sqrtf(ve), k.inv_sqrt_bc2, k.eps);
+    pe = pe - lr * (me / denom);
+  };
+  upd(pp.x, gg.x, mm.x, vv.x);
+  upd(pp.y, gg.y, mm.y, vv.y);
+  upd(pp.z, gg.z, mm.z, vv.z);
+  upd(pp.w, gg.w, mm.w, vv.w);
+  p[i] = pp; m[i] = mm; v[i] = vv;
+}
+
 }  // namespace omfs
 
 using namespace omfs;
@@ -288,6 +313,23 @@ static int adam_launch(float* params, const float* grads, float* m, float* v, in
   const int n4 = n_pad / 4;
   hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n4, 256), n_planes), dim3(256), 0, (hipStream_t)stream, (float4*)params,
                      (const float4*)grads, (float4*)m, (float4*)v, n4, k, plane0, state_dev);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_adam_step_range(float* params, const float* grads, float* m, float* v, int n_pad, long long offset,
+                                    long long count, const omfs_adam_params* ap, void* stream) {
+  OMFS_REQUIRE(params && grads && m && v && ap, "null pointer");
+  OMFS_REQUIRE(n_pad > 0 && n_pad % 256 == 0 && ap->step >= 1, "shape");
+  OMFS_REQUIRE(offset >= 0 && count > 0 && offset % 4 == 0 && count % 4 == 0 && offset + count <= (long long)OMFS_NPLANES * n_pad, "range");
+  AdamK k;
+  const double bc1 = 1.0 - pow((double)ap->beta1, ap->step), bc2 = 1.0 - pow((double)ap->beta2, ap->step);
+  for (int i = 0; i < OMFS_NPLANES; ++i) k.lr_step[i] = (float)(ap->lr[i] / bc1);
+  k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  k.b1 = ap->beta1; k.b2 = ap->beta2; k.eps = ap->eps; k.grad_scale = ap->grad_scale;
+  const long long count4 = count / 4;
+  hipLaunchKernelGGL(adam_range_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4*)params,
+                     (const float4*)grads, (float4*)m, (float4*)v, offset / 4, count4, n_pad / 4, k);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -113,6 +113,7 @@ class DensityController:
         t, m = self.t, self.t.model
         n_pad = int(params.shape[1])
         m.params, m.binding, m.n, m.n_pad = params, binding, n, n_pad
+        m.order = None                 # the compaction re-indexed the cloud: the storage order is the order from here on
         t.opt.m, t.opt.v = adam_m, adam_v
         t.grads = torch.zeros(NPLANES, n_pad, device=params.device)
         t.densify_stats = torch.zeros(2, n_pad, device=params.device)

@@ -5,20 +5,42 @@ holds a full [59][n_pad] gradient buffer; the exchange is either ONE all-reduce 
 by default, the compact form (trainer.py): all-reduce of the 14 planes that are not rank-1 (geometry, opacity, SH
 degree 0) + all-gather of each rank's dL/dcolour (3 planes), from which every rank rebuilds the summed gradient of the
 45 higher SH planes itself (omfs_sh_rest_grads) -- 2.3x fewer bytes per rank on the xGMI links at 8 ranks.  Then every
-rank applies the same Adam step with grad_scale = 1/W, so replicas stay bit-identical.
+rank applies the same Adam step with grad_scale = 1/W, so replicas stay bit-identical.  A third form ("sharded",
+SURVEY.md section 8e): reduce-scatter of the whole buffer, Adam on the rank's 1/W of the elements (omfs_adam_step_range), all-gather
+of the updated parameters -- the bytes of "full" on the links, Adam traffic divided by W.
 render_surgery: frame f belongs to rank f mod W; no collective.
 `torch.distributed` backend "nccl" is RCCL on ROCm; tests run the same code over gloo on CPU tensors.
 """
 from __future__ import annotations
 
+import functools
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 
-def view_index(step: int, rank: int, world: int, n_views: int) -> int:
-    return (step * world + rank) % n_views
+@functools.lru_cache(maxsize=64)
+def _epoch_order(seed: int, epoch: int, n_views: int):
+    return tuple(int(i) for i in np.random.default_rng([int(seed), int(epoch)]).permutation(n_views))
+
+
+def view_index(step: int, rank: int, world: int, n_views: int, seed: int | None = None) -> int:
+    """View of rank `rank` at iteration `step`.  seed None: global slot step*world + rank walks the views in index order.
+    Otherwise rank r walks ITS views (`views_of_rank`) epoch by epoch, every epoch in its own seeded random order (without
+    replacement, as upstream pops its viewpoint stack) -- a function of (seed, rank, step) alone, so every rank can compute
+    every other rank's view (the compact exchange poses them all) without talking."""
+    if seed is None:
+        return (step * world + rank) % n_views
+    own = views_of_rank(n_views, rank, world)
+    epoch, k = divmod(step, len(own))
+    return own[_epoch_order(seed * 1000003 + rank, epoch, len(own))[k]]
+
+
+def views_of_rank(n_views: int, rank: int, world: int) -> range:
+    """The views rank `rank` ever trains on: index = rank (mod world).  A rank keeps only their images in HBM."""
+    return range(rank % max(n_views, 1), n_views, world) if world <= n_views else range(rank % n_views, rank % n_views + 1)
 
 
 def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
@@ -46,6 +68,38 @@ def allgather_into_(out: torch.Tensor, inp: torch.Tensor, group=None, async_op: 
     except (RuntimeError, NotImplementedError):
         work = dist.all_gather(list(out.unbind(0)), inp, group=group, async_op=async_op)
     return work if async_op else out
+
+
+def reduce_scatter_sum_(out: torch.Tensor, full: torch.Tensor, group=None):
+    """out [S] <- this rank's contiguous shard of the sum over ranks of full [W*S] (rank r owns [r*S, (r+1)*S)).
+    RCCL: ONE reduce-scatter.  gloo has no reduce-scatter: the CPU rehearsal all-reduces and slices -- the same numbers
+    (a ring reduce-scatter and a ring all-reduce add in the same order on every shard only by luck, so bit-equality between
+    the backends is not claimed; between the RANKS of one run the result is bit-identical by construction, each element
+    being updated by exactly one rank)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if full.numel() != world * out.numel():
+        raise ValueError("full must hold world_size shards of out's size")
+    if dist.get_backend(group) == "nccl":
+        dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=group)
+    else:
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(full[rank * out.numel():(rank + 1) * out.numel()])
+    return out
+
+
+def allgather_shards_(full: torch.Tensor, group=None):
+    """full [W*S]: every rank's own shard [r*S, (r+1)*S) is broadcast to all (in place on RCCL)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    S = full.numel() // world
+    mine = full[rank * S:(rank + 1) * S]
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(full, mine, group=group)
+    else:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine.clone(), group=group)
+        for r, p in enumerate(parts):
+            full[r * S:(r + 1) * S].copy_(p)
+    return full
 
 
 def replicas_in_sync(params: torch.Tensor, group=None) -> bool:

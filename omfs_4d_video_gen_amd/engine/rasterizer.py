@@ -218,6 +218,14 @@ class Adam:
         L.check(L.load().omfs_adam_step_planes(L.ptr(m.params), L.ptr(grads), L.ptr(self.m), L.ptr(self.v), m.n, m.n_pad,
                                                C.byref(self.ap), int(plane0), int(n_planes), L.stream_ptr()), "omfs_adam_step_planes")
 
+    def apply_range(self, grad_shard: torch.Tensor, offset: int, count: int):
+        """The update on the flat range [offset, offset + count) of the [59][n_pad] buffers; grad_shard holds that range's
+        (summed) gradient.  Data-parallel "sharded" exchange: moments outside the rank's range are not touched."""
+        mdl = self.model
+        p, m, v = mdl.params.view(-1), self.m.view(-1), self.v.view(-1)
+        L.check(L.load().omfs_adam_step_range(L.ptr(p[offset:]), L.ptr(grad_shard), L.ptr(m[offset:]), L.ptr(v[offset:]), mdl.n_pad,
+                                              int(offset), int(count), C.byref(self.ap), L.stream_ptr()), "omfs_adam_step_range")
+
     def step(self, grads: torch.Tensor, grad_scale: float = 1.0):
         self.step_count += 1
         self.ap.step = self.step_count

@@ -60,6 +60,7 @@ def parse(argv=None):
     p.add_argument("--flame_pose_lr", type=float, default=1e-5)
     p.add_argument("--flame_trans_lr", type=float, default=1e-6)
     p.add_argument("--start_checkpoint", type=str, default=None)
+    p.add_argument("--no_shuffle", action="store_true", help="visit the views in index order instead of a seeded random order per epoch")
     p.add_argument("--target_storage", choices=("auto", "f32", "u8"), default="auto",
                    help="how training images are kept in HBM: fp32 planes, 8-bit RGB expanded per step, or by dataset size")
     args, unknown = p.parse_known_args(argv)
@@ -119,12 +120,17 @@ def main(argv=None):
     bg = (1.0, 1.0, 1.0) if args.white_background else (0.0, 0.0, 0.0)
     views, size = [], None
     from concurrent.futures import ThreadPoolExecutor
+    # a rank trains on the views with index = rank (mod world) only (distributed.views_of_rank): it decodes and keeps just
+    # those images; the other views contribute their cameras and timesteps (the compact exchange poses every rank's view)
+    from omfs_4d_video_gen_amd.engine.distributed import views_of_rank
+    mine = set(views_of_rank(len(split["frames"]), rank, world)) if not args.no_shuffle else set(range(len(split["frames"])))
     with ThreadPoolExecutor(max_workers=8) as pool:          # PNG decode releases the interpreter lock
-        loaded = list(pool.map(lambda fr: IO.load_image_rgba(os.path.join(args.source_path, fr["file_path"])), split["frames"]))
+        loaded = list(pool.map(lambda ifr: IO.load_image_rgba(os.path.join(args.source_path, ifr[1]["file_path"])) if ifr[0] in mine else (None, None),
+                               enumerate(split["frames"])))
     images, alphas = [im for im, _ in loaded], [a for _, a in loaded]
     del loaded
     # fp32 targets are 4x the bytes of the images: kept while they fit comfortably beside the model, 8-bit otherwise
-    n_px = sum(int(im.shape[0]) * int(im.shape[1]) for im in images)
+    n_px = sum(int(im.shape[0]) * int(im.shape[1]) for im in images if im is not None)
     store_u8 = args.target_storage == "u8" or (args.target_storage == "auto" and n_px * 12 > 64 << 30)
     for fr, trow, img, alpha in zip(split["frames"], split["timestep_of_frame"], images, alphas):
         cam = IO.camera_from_frame(fr, split["top"])
@@ -137,12 +143,15 @@ def main(argv=None):
         if (w, h) != (cam["width"], cam["height"]):
             s = w / cam["width"]
             cam = {**cam, "width": w, "height": h, "fl_x": cam["fl_x"] * s, "fl_y": cam["fl_y"] * s}
-        if img.shape[:2] != (h, w):
-            img = resize_nearest(img, w, h)
         if size is None:
             size = (w, h)
         elif size != (w, h):
             raise SystemExit("[engine] all training views must share one resolution")
+        if img is None:                         # another rank's view: camera and timestep only
+            views.append(View(cam, int(trow), target=None, name=os.path.basename(fr["file_path"])))
+            continue
+        if img.shape[:2] != (h, w):
+            img = resize_nearest(img, w, h)
         mask_rel = fr.get("fg_mask_path")
         mask = None
         if mask_rel and os.path.exists(os.path.join(args.source_path, mask_rel)):
@@ -178,14 +187,17 @@ def main(argv=None):
     cap = (args.max_gaussians if args.max_gaussians > 0 else 4 * n) if densify else n
     trainer = Trainer(rig, split["flame"], g0, views, size[0], size[1], bg=bg, iterations=args.iterations,
                       sh_degree_max=args.sh_degree, start_sh_degree=0, rank=rank, world_size=world, process_group=pg,
-                      n_capacity=cap, finetune_flame=args.finetune_flame_params,
+                      n_capacity=cap, finetune_flame=args.finetune_flame_params, coherent_order=True,
+                      shuffle_views=None if args.no_shuffle else args.seed,
                       flame_lr={"expr": args.flame_expr_lr, "pose": args.flame_pose_lr, "translation": args.flame_trans_lr})
     it0 = 0
     if ckpt is not None:
         it0 = int(ckpt["iteration"])
-        wcols = min(trainer.opt.m.shape[1], ckpt["adam_m"].shape[1])
-        trainer.opt.m[:, :wcols].copy_(ckpt["adam_m"][:, :wcols])
-        trainer.opt.v[:, :wcols].copy_(ckpt["adam_v"][:, :wcols])
+        # the checkpoint's columns are in ITS storage order; this trainer's cloud is g0[order]
+        order = trainer.model.order if trainer.model.order is not None else np.arange(n)
+        idx = torch.from_numpy(np.ascontiguousarray(order))
+        trainer.opt.m[:, :n].copy_(ckpt["adam_m"][:, :n][:, idx])
+        trainer.opt.v[:, :n].copy_(ckpt["adam_v"][:, :n][:, idx])
         trainer.opt.step_count = it0
         trainer.sh_degree = int(ckpt["sh_degree"])
         trainer.step_idx = it0
@@ -199,6 +211,9 @@ def main(argv=None):
         controller = DensityController(trainer, scene_extent(views), args.densify_from_iter, args.densify_until_iter,
                                        args.densification_interval, args.densify_grad_threshold,
                                        opacity_reset_interval=args.opacity_reset_interval, max_gaussians=cap, seed=args.seed)
+        if ckpt is not None and "densify_stats" in ckpt:     # the statistics gathered since the last densification go on
+            order = trainer.model.order if trainer.model.order is not None else np.arange(n)
+            trainer.densify_stats[:, :n].copy_(ckpt["densify_stats"][:, :n][:, torch.from_numpy(np.ascontiguousarray(order))])
 
     out = Path(args.model_path)
     if rank == 0:
@@ -239,6 +254,7 @@ def main(argv=None):
             print(f"\n[ITER {it}] Saving Checkpoint", flush=True)
             torch.save({"iteration": it, "params": trainer.model.params.cpu(), "binding": trainer.model.binding.cpu(),
                         "adam_m": trainer.opt.m.cpu(), "adam_v": trainer.opt.v.cpu(), "sh_degree": trainer.sh_degree,
+                        **({"densify_stats": trainer.densify_stats.cpu()} if trainer.densify_stats is not None else {}),
                         **({"flame": trainer.flame_ft.state_dict()} if trainer.flame_ft is not None else {})},
                        out / f"chkpnt{it}.pth")
     torch.cuda.synchronize()

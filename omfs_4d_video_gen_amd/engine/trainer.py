@@ -78,12 +78,21 @@ class Trainer:
                  reg=(0.01, 1.0, 1.0, 0.6), position_lr_init=5e-3, position_lr_final=5e-5,
                  sh_degree_max: int = 3, sh_increase_every: int = 1000, start_sh_degree: int = 0,
                  dup_capacity: int | None = None, rank: int = 0, world_size: int = 1, process_group=None,
-                 n_capacity: int | None = None, finetune_flame: bool = False, flame_lr: dict | None = None):
+                 n_capacity: int | None = None, finetune_flame: bool = False, flame_lr: dict | None = None,
+                 coherent_order: bool = False, shuffle_views: int | None = None):
+        """shuffle_views: seed of the per-epoch random view order (None: the views in index order, epoch after epoch).
+        coherent_order: store the cloud along a Morton curve over the parent triangles (gaussians.coherent_order); the
+        engine CLIs and the benchmark do, `model.to_dict()` returns the caller's order either way."""
         self.device = torch.device(device)
         self.rank, self.world = rank, world_size
         self.pg = process_group
+        self.view_seed = None if shuffle_views is None else int(shuffle_views)
         self.dflame = DeviceFlame(rig, flame_params, device=device)
-        self.model = GaussianModel(gaussians, device=device)
+        order = None
+        if coherent_order:
+            from .gaussians import coherent_order as _order
+            order = _order(gaussians["binding"], rig.v_template[rig.faces].mean(1))
+        self.model = GaussianModel(gaussians, device=device, order=order)
         self.rast = Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity, n_capacity=n_capacity)
         self.rast._ensure_bwd()
         self.rast.rb.n_visible = L.ptr(self.rast.n_visible)   # counted by omfs_bin_count (no omfs_count_visible dispatches)
@@ -106,8 +115,15 @@ class Trainer:
         # OMFS_DP_FORCE=1 takes the exchange path with a single rank too: the RCCL calls and their stream ordering can then
         # be exercised on a one-GPU box (tests/test_gpu_distributed.py); the result is the plain single-GPU step's
         self.dp = self.world > 1 or (os.environ.get("OMFS_DP_FORCE") == "1" and process_group is not None)
-        self.compact_dp = self.dp and self.world <= 16 and os.environ.get("OMFS_DP_EXCHANGE", "compact") != "full"
+        mode = os.environ.get("OMFS_DP_EXCHANGE", "compact")
+        if mode not in ("compact", "full", "sharded"):
+            raise ValueError(f"OMFS_DP_EXCHANGE={mode!r}: expected compact, full or sharded")
+        self.compact_dp = self.dp and self.world <= 16 and mode == "compact"
+        # "sharded": reduce-scatter of the gradient buffer, Adam on this rank's contiguous 1/W of the [59][n_pad] elements,
+        # all-gather of the updated parameters (the Adam moments of the other shards are not maintained on this rank)
+        self.sharded_dp = self.dp and mode == "sharded"
         self._dp_patterns = {}
+        self._gshard = None
         self.drgb_local = self.drgb_scratch = self.drgb_all = self.cam_pos_table = None
         if self.compact_dp:
             cp = np.stack([np.asarray(make_camera_struct(v.camera).cam_pos, np.float32) for v in views])
@@ -150,7 +166,7 @@ class Trainer:
     def _frame_key(self, step: int):
         from .distributed import view_index
         if self.compact_dp:
-            return (step & 1,) + tuple(self.views[view_index(step, r, self.world, len(self.views))].timestep for r in range(self.world))
+            return (step & 1,) + tuple(self.views[view_index(step, r, self.world, len(self.views), self.view_seed)].timestep for r in range(self.world))
         return (step & 1, self.view_for_step(step).timestep)
 
     def _pose_frames(self, step: int):
@@ -166,7 +182,7 @@ class Trainer:
         """(device int32 timesteps [W], omfs_view_set) of ALL ranks' views at this step; the schedule is periodic,
         so the few distinct patterns are built once (no per-step host-to-device copy)."""
         from .distributed import view_index
-        ids = tuple(view_index(step, r, self.world, len(self.views)) for r in range(self.world))
+        ids = tuple(view_index(step, r, self.world, len(self.views), self.view_seed) for r in range(self.world))
         pat = self._dp_patterns.get(ids)
         if pat is None:
             ts = torch.tensor([self.views[i].timestep for i in ids], dtype=torch.int32, device=self.device)
@@ -180,12 +196,12 @@ class Trainer:
 
     def view_for_step(self, step: int) -> View:
         from .distributed import view_index
-        return self.views[view_index(step, self.rank, self.world, len(self.views))]
+        return self.views[view_index(step, self.rank, self.world, len(self.views), self.view_seed)]
 
     # ------------------------------------------------------------------ hipGraph replay of whole iterations
     def _graph_key(self, it: int):
         from .distributed import view_index
-        vi = view_index(it, self.rank, self.world, len(self.views))
+        vi = view_index(it, self.rank, self.world, len(self.views), self.view_seed)
         return (vi, it & 1, self.sh_degree, self.model.n, self.model.params.data_ptr(), L.ptr(self.densify_stats),
                 self.views[vi].target.data_ptr(), self.rast.keys.data_ptr())
 
@@ -407,6 +423,15 @@ class Trainer:
                 gather.wait()
                 L.check(lib.omfs_sh_rest_grads(g, L.ptr(face_xf), self.dflame.rig.n_faces, L.ptr(self.cam_pos_table), pat[1],
                                                L.ptr(self.drgb_all), self.sh_degree, L.ptr(self.grads), s), "omfs_sh_rest_grads")
+            elif self.sharded_dp:
+                from .distributed import reduce_scatter_sum_
+                flat = self.grads.view(-1)
+                S = flat.numel() // self.world            # n_pad is a multiple of 256: every world size up to 64 divides 59*n_pad/4
+                if self._gshard is None or self._gshard.numel() != S:
+                    if flat.numel() % (4 * self.world):
+                        raise ValueError("sharded exchange needs 59 * n_pad divisible by 4 * world_size")
+                    self._gshard = torch.empty(S, device=self.device)
+                reduce_scatter_sum_(self._gshard, flat, self.pg)
             else:
                 allreduce_sum_(self.grads, self.pg)
             if ft is not None and not self.compact_dp:   # every rank touched a different timestep: dense (tiny) tensors, summed
@@ -425,6 +450,12 @@ class Trainer:
                     allreduce_sum_(gr, self.pg)
             reduce14.wait()
             self.opt.apply_planes(self.grads, 0, P_SH + 3)
+        elif self.sharded_dp:
+            from .distributed import allgather_shards_
+            S = self._gshard.numel()
+            self.opt.begin_step(1.0 / self.world)
+            self.opt.apply_range(self._gshard, self.rank * S, S)
+            allgather_shards_(self.model.params.view(-1), self.pg)
         else:
             self.opt.step(self.grads, 1.0 / self.world)
         if ft is not None and not ft_pipe:
@@ -442,10 +473,14 @@ class Renderer:
 
     def __init__(self, rig: FlameRig, flame_params: dict, gaussians: dict, width: int, height: int,
                  bg=(0.0, 0.0, 0.0), device="cuda", sh_degree: int = 3, dup_capacity: int | None = None,
-                 flame_batch: int = 16):
+                 flame_batch: int = 16, coherent_order: bool = False):
         self.device = torch.device(device)
         self.dflame = DeviceFlame(rig, flame_params, device=device)
-        self.model = GaussianModel(gaussians, device=device)
+        order = None
+        if coherent_order:
+            from .gaussians import coherent_order as _order
+            order = _order(gaussians["binding"], rig.v_template[rig.faces].mean(1))
+        self.model = GaussianModel(gaussians, device=device, order=order)
         self.rast = Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity)
         self.rast.rb.flags = L.RB_FORWARD_ONLY     # no backward pass follows: the forward skips the segment checkpoints
         self.bg, self.sh_degree = tuple(bg), sh_degree

@@ -44,6 +44,20 @@ def _worker(rank, world, port, q):
     out = torch.zeros(world, 3, n_pad)
     allgather_into_(out, drgb)
     assert all(torch.equal(out[r], torch.full((3, n_pad), float(r + 1))) for r in range(world))
+    # sharded exchange: reduce-scatter of the flat buffer (rank r owns elements [r*S, (r+1)*S)), update of the own shard,
+    # all-gather of the updated shards
+    from omfs_4d_video_gen_amd.engine.distributed import allgather_shards_, reduce_scatter_sum_
+    grads = torch.randn(59, n_pad, generator=g)
+    both = [torch.zeros_like(grads) for _ in range(world)]
+    dist.all_gather(both, grads.clone())
+    S = grads.numel() // world
+    shard = torch.empty(S)
+    reduce_scatter_sum_(shard, grads.view(-1), None)
+    assert torch.equal(shard, (both[0] + both[1]).view(-1)[rank * S:(rank + 1) * S])
+    p2 = params.clone().view(-1)
+    p2[rank * S:(rank + 1) * S] -= 0.01 * shard / world          # only the own shard is updated ...
+    allgather_shards_(p2, None)                                    # ... and every rank receives all of them
+    assert replicas_in_sync(p2) and torch.equal(p2, (params - 0.01 * (both[0] + both[1]) / world).view(-1))
     bad = params + (rank * 1e-3)
     assert not replicas_in_sync(bad)
     q.put((rank, views, list(frames_of_rank(11, rank, world)), params.double().sum().item()))
