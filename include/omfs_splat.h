@@ -185,7 +185,11 @@ typedef struct omfs_raster_buffers {
   uint32_t* n_visible;    /* optional [1]: number of Gaussians with radius > 0 in this view; omfs_project_fwd clears it,
                              omfs_bin_count accumulates it (what omfs_count_visible computes, without its two
                              dispatches); may be NULL                                                              */
+  uint32_t* scan_scratch; /* optional [OMFS_SCAN_SCRATCH_WORDS], zero before the first use and left zero by every call: with it
+                             omfs_bin_scan runs as several workgroups that exchange their totals through these words (same
+                             result, a quarter of the time); NULL: one workgroup                                    */
 } omfs_raster_buffers;
+#define OMFS_SCAN_SCRATCH_WORDS 1040
 #define OMFS_RB_FORWARD_ONLY 1u
 
 /* deform + project + colour for one view -> g0,g1,g2. face_xf [n_faces][16]. */
@@ -339,14 +343,20 @@ typedef struct omfs_step_state {          /* 16 words of DEVICE memory; the call
   float lr_xyz;                           /* position learning rate of this iteration                                    */
   float inv_bc1, inv_sqrt_bc2;            /* 1 / (1 - beta1^step), 1 / sqrt(1 - beta2^step)                              */
   float flame_inv_bc1, flame_inv_sqrt_bc2;
-  float reserved[9];
+  int32_t table_base;                     /* iteration (0-based) that entry 0 of omfs_step_advance's next_table belongs to  */
+  float reserved[8];
 } omfs_step_state;
 typedef struct omfs_lr_schedule {
   float lr_init, lr_final;
   int max_steps;
   float beta1, beta2;
 } omfs_lr_schedule;
-int omfs_step_advance(omfs_step_state* state_dev, const omfs_lr_schedule* sch, void* stream);
+/* next_table (device, may be NULL): entry j holds a per-iteration word of iteration table_base + j (the trainer stores the
+ * FLAME timestep of that iteration's view); the entry of the iteration AFTER the one being advanced to is copied to
+ * next_out[0] -- a captured iteration poses the next view's FLAME frame from it, so a replay needs no host-side update
+ * at all (index clamped to the table). */
+int omfs_step_advance(omfs_step_state* state_dev, const omfs_lr_schedule* sch, const int32_t* next_table, int table_len,
+                      int32_t* next_out, void* stream);
 int omfs_adam_step_dev(float* params, const float* grads, float* m, float* v, int n, int n_pad, const omfs_adam_params* ap,
                        const omfs_step_state* state_dev, int plane0, int n_planes, void* stream);
 

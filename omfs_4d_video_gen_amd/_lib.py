@@ -19,6 +19,7 @@ RB_FORWARD_ONLY = 1
 NPLANES = 59
 TILE = 16
 SEG = 128
+SCAN_SCRATCH_WORDS = 1040
 
 c_float_p = C.POINTER(C.c_float)
 c_u32_p = C.POINTER(C.c_uint32)
@@ -58,7 +59,7 @@ class RasterBuffersC(C.Structure):
                 ("dup_capacity", C.c_uint32), ("sort_lds_pairs", C.c_uint32), ("status", c_void_p),
                 ("seg_ckpt", c_void_p), ("order_seg0", c_void_p), ("seg_capacity", C.c_uint32),
                 ("image", c_void_p), ("final_T", c_void_p), ("n_contrib", c_void_p), ("flags", C.c_uint32),
-                ("n_visible", c_void_p)]
+                ("n_visible", c_void_p), ("scan_scratch", c_void_p)]
 
 
 class GradBuffersC(C.Structure):
@@ -84,7 +85,8 @@ class LrScheduleC(C.Structure):
     _fields_ = [("lr_init", C.c_float), ("lr_final", C.c_float), ("max_steps", C.c_int), ("beta1", C.c_float), ("beta2", C.c_float)]
 
 
-STEP_STATE_WORDS = 16     # omfs_step_state: device memory (int32 step, int32 flame_step, 5 floats, padding)
+STEP_STATE_WORDS = 16     # omfs_step_state: device memory (int32 step, int32 flame_step, 5 floats, int32 table_base, padding)
+STEP_STATE_TABLE_BASE = 7
 
 
 class FlameFitC(C.Structure):
@@ -110,7 +112,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p]),
     "omfs_adam_step_range": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_longlong, C.c_longlong,
                                        C.POINTER(AdamParamsC), c_void_p]),
-    "omfs_step_advance": (C.c_int, [c_void_p, C.POINTER(LrScheduleC), c_void_p]),
+    "omfs_step_advance": (C.c_int, [c_void_p, C.POINTER(LrScheduleC), c_void_p, C.c_int, c_void_p, c_void_p]),
     "omfs_adam_step_dev": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), c_void_p,
                                      C.c_int, C.c_int, c_void_p]),
     "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p,

@@ -48,12 +48,19 @@ __global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restric
   } else if (lane < 45) {
     sR[lane] = rotmats[(size_t)src * 45 + lane];
   }
+  // the joint regressor's expression part (15 x n_expr) and the coefficients go through LDS: all 64 lanes fetch them with
+  // independent coalesced loads (one memory round trip), the 15 ascending-k fma chains then run from LDS -- straight from
+  // global memory every chain step was its own round trip (14 us alone, 58-81 us beside the Adam pass)
+  __shared__ float s_je[15 * 128];
+  __shared__ float s_e[128];
+  for (int k = lane; k < 15 * n_expr; k += 64) s_je[k] = j_expr[k];
+  for (int k = lane; k < n_expr; k += 64) s_e[k] = e[k];
   __syncthreads();
   const float* R = sR;
   if (lane < 15) {  // J[j][c] = j_static + sum_k j_expr[j*3+c][k] * e[k]
     float acc = j_static[lane];
-    const float* row = j_expr + (size_t)lane * n_expr;
-    for (int k = 0; k < n_expr; ++k) acc = fma_(row[k], e[k], acc);
+    const float* row = s_je + lane * n_expr;
+    for (int k = 0; k < n_expr; ++k) acc = fma_(row[k], s_e[k], acc);
     sJ[lane] = acc;
   }
   // coefficient column: expr, then pose features (R_j - I), j = 1..4, row-major, then zero padding
@@ -199,37 +206,41 @@ __global__ void face_frames_kernel(const float* __restrict__ verts, int v_pad, c
   o[3] = make_float4(scale, 0.f, 0.f, 0.f);
 }
 
-// ---- backward (FLAME fine-tuning), one frame.  One thread per face: sums the per-Gaussian records project_bwd
-// wrote (no atomics there), then the gradient of the frame record
-// (R columns a0, n, a2; centre; scale) w.r.t. the three vertices, added into dverts with float atomics
-// (a vertex belongs to ~6 faces).  The clamps of safe_normalize3 are not differentiated.
-__global__ void face_frames_bwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int n_faces,
-                                       const float* __restrict__ dface, const int32_t* __restrict__ face_start,
-                                       const int32_t* __restrict__ face_gauss, float* __restrict__ dverts) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= n_faces) return;
-  // sum of the frame-gradient records of the Gaussians bound to this triangle (CSR by triangle)
-  float g[16];
-  for (int k = 0; k < 16; ++k) g[k] = 0.f;
-  const int lo = face_start[f], hi = face_start[f + 1];
-  auto add = [&](const float4& a, const float4& b, const float4& c, const float4& d) {
-    g[0] += a.x; g[1] += a.y; g[2] += a.z; g[3] += a.w; g[4] += b.x; g[5] += b.y; g[6] += b.z; g[7] += b.w;
-    g[8] += c.x; g[9] += c.y; g[10] += c.z; g[11] += c.w; g[12] += d.x;
-  };
-  int e = lo;
-  for (; e + 4 <= hi; e += 4) {            // four records per memory round trip
-    const float4* r0 = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e] * 4;
-    const float4* r1 = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e + 1] * 4;
-    const float4* r2 = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e + 2] * 4;
-    const float4* r3 = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e + 3] * 4;
-    const float4 a0 = r0[0], b0 = r0[1], c0 = r0[2], d0 = r0[3], a1 = r1[0], b1 = r1[1], c1 = r1[2], d1 = r1[3];
-    const float4 a2 = r2[0], b2 = r2[1], c2 = r2[2], d2 = r2[3], a3 = r3[0], b3 = r3[1], c3 = r3[2], d3 = r3[3];
-    add(a0, b0, c0, d0); add(a1, b1, c1, d1); add(a2, b2, c2, d2); add(a3, b3, c3, d3);
+// ---- backward (FLAME fine-tuning), one frame.  SIXTEEN lanes per face (one DPP row; four faces per wave): lane q sums word q
+// of the frame-gradient records project_bwd wrote for the Gaussians bound to this triangle (CSR by triangle; no atomics
+// there) -- a record is one 64-byte line across the row, the sixteen Gaussian indices of a batch are fetched in one
+// coalesced load and handed round by lane permutes, sixteen record loads are then in flight at once: two memory round
+// trips per sixteen Gaussians instead of two per four (the chain runs beside the Adam pass, where a round trip is slow).
+// Every lane then holds all thirteen sums (row permutes) and evaluates the small gradient of the frame record
+// (R columns a0, n, a2; centre; scale) w.r.t. the three vertices; lanes 0..8 add one component each into dverts with a
+// float atomic (a vertex belongs to ~6 faces).  The clamps of safe_normalize3 are not differentiated.
+__global__ __launch_bounds__(256) void face_frames_bwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int n_faces,
+                                                              const float* __restrict__ dface, const int32_t* __restrict__ face_start,
+                                                              const int32_t* __restrict__ face_gauss, float* __restrict__ dverts) {
+  const int f = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+  const int q = threadIdx.x & 15, lane = threadIdx.x & 63, row0 = lane & 48;
+  const bool live = f < n_faces;
+  const int lo = live ? face_start[f] : 0, hi = live ? face_start[f + 1] : 0;
+  float acc = 0.f;
+  // every row of the wave runs the same number of batches (lane permutes are wave-wide instructions)
+  int nb = (hi - lo + 15) >> 4;
+#pragma unroll
+  for (int d = 16; d < 64; d <<= 1) nb = max(nb, __shfl_xor(nb, d, 64));
+  for (int b = 0; b < nb; ++b) {
+    const int e = lo + b * 16 + q;
+    const int mine = e < hi ? face_gauss[e] : -1;
+    float part[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int id = __shfl(mine, row0 + k, 64);
+      part[k] = id >= 0 ? dface[(size_t)id * 16 + q] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += part[k];
   }
-  for (; e < hi; ++e) {
-    const float4* rec = reinterpret_cast<const float4*>(dface) + (size_t)face_gauss[e] * 4;
-    add(rec[0], rec[1], rec[2], rec[3]);
-  }
+  float g[13];
+#pragma unroll
+  for (int k = 0; k < 13; ++k) g[k] = __shfl(acc, row0 + k, 64);
   if (lo == hi) return;
   const float4* vb = reinterpret_cast<const float4*>(verts);
   const int i0 = faces[f * 3 + 0], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
@@ -275,11 +286,12 @@ __global__ void face_frames_bwd_kernel(const float* __restrict__ verts, const in
   float de1[3];
   for (int k = 0; k < 3; ++k) de1[k] = (da0[k] - a0[k] * t0) / L1 + dL1 * a0[k];
   const float third = 1.0f / 3.0f;
-  for (int k = 0; k < 3; ++k) {
+  if (q < 9) {                      // lane q of the row: vertex q / 3, component q % 3
+    const int k = q % 3, vtx = q / 3;
     const float c3 = dc[k] * third;
-    atomicAdd(&dverts[(size_t)i0 * 4 + k], c3 - de1[k] - de2[k]);
-    atomicAdd(&dverts[(size_t)i1 * 4 + k], c3 + de1[k]);
-    atomicAdd(&dverts[(size_t)i2 * 4 + k], c3 + de2[k]);
+    const float val = vtx == 0 ? c3 - de1[k] - de2[k] : (vtx == 1 ? c3 + de1[k] : c3 + de2[k]);
+    const int iv = vtx == 0 ? i0 : (vtx == 1 ? i1 : i2);
+    atomicAdd(&dverts[(size_t)iv * 4 + k], val);
   }
 }
 
@@ -334,23 +346,31 @@ __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef);
 
 // The block that finishes last (ticket in dcoef[gridDim.x], reset for the next call) goes on with flame_front_bwd: the
 // basis^T product and the small serial front share one launch.
-__global__ __launch_bounds__(256) void basis_t_gemv_kernel(const float* __restrict__ basis_dense, const float* __restrict__ dv_shaped,
-                                                           int row, float* __restrict__ dcoef, FrontArgs fa) {
-  __shared__ float ws[4];
+constexpr int GEMV_NT = 1024, GEMV_PER = 16;     // rows of up to 16384 elements (3 V = 15 429) in ONE memory round trip
+__global__ __launch_bounds__(GEMV_NT) void basis_t_gemv_kernel(const float* __restrict__ basis_dense, const float* __restrict__ dv_shaped,
+                                                               int row, float* __restrict__ dcoef, FrontArgs fa) {
+  __shared__ float ws[GEMV_NT / 64];
   __shared__ uint32_t s_ticket;
   const float* b = basis_dense + (size_t)blockIdx.x * row;
-  float a = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int i = threadIdx.x;
-  for (; i + 768 < row; i += 1024) {       // four independent loads per round trip
-    a = fma_(b[i], dv_shaped[i], a); a1 = fma_(b[i + 256], dv_shaped[i + 256], a1);
-    a2 = fma_(b[i + 512], dv_shaped[i + 512], a2); a3 = fma_(b[i + 768], dv_shaped[i + 768], a3);
+  float acc = 0.f;
+  for (int i0 = 0; i0 < row; i0 += GEMV_NT * GEMV_PER) {
+    float bv[GEMV_PER], dv[GEMV_PER];
+#pragma unroll
+    for (int u = 0; u < GEMV_PER; ++u) {             // all loads of the pass are issued before the first use
+      const int i = i0 + u * GEMV_NT + threadIdx.x;
+      bv[u] = i < row ? b[i] : 0.f;
+      dv[u] = i < row ? dv_shaped[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < GEMV_PER; ++u) acc = fma_(bv[u], dv[u], acc);
   }
-  for (; i < row; i += 256) a = fma_(b[i], dv_shaped[i], a);
-  a = wave_sum_all((a + a1) + (a2 + a3));
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = a;
+  acc = wave_sum_all(acc);
+  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    dcoef[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+    float t = 0.f;
+    for (int w = 0; w < GEMV_NT / 64; ++w) t += ws[w];
+    dcoef[blockIdx.x] = t;
     __threadfence();
     s_ticket = atomicAdd(reinterpret_cast<uint32_t*>(dcoef + gridDim.x), 1u);
   }
@@ -387,7 +407,8 @@ __global__ void rodrigues_kernel(const float* __restrict__ aa, int n, float* __r
 
 // Gradient of the small FLAME front: (d joint_xf [5][12], d coef [K], d translation) -> (d expr [E], d pose [5][3]).
 // One wave; lane 0 walks the 5-joint chain and the axis-angle maps backwards, all lanes finish d expr.
-// Called by all 256 threads of one block (barriers inside); dcoef was written by other blocks: read through volatile.
+// Called by all threads of one block (barriers inside); dcoef was written by other blocks: read through volatile,
+// once, into LDS (n_expr + 36 <= 256).
 __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
   const volatile float* dcoef = dcoef_;
   const float* j_static = fa.j_static; const float* j_expr = fa.j_expr; const float* expr = fa.expr; const float* pose = fa.pose;
@@ -397,18 +418,34 @@ __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
   __shared__ float sJ[15], sdJ[15];
   __shared__ float sums[64];
   __shared__ float part4[4][64];
+  __shared__ float s_dcoef[256];     // dcoef was written by the other blocks: fetched once, by all threads in parallel
+  __shared__ float s_pose[15];
   const int lane = threadIdx.x;
-  {   // add up the per-wave rows of flame_skin_bwd: thread (w, q) sums value q over the rows r = w (mod 4), in row order
+  if (lane < n_expr + 36 && lane < 256) s_dcoef[lane] = dcoef[lane];
+  if (lane < 15) s_pose[lane] = pose[lane];
+  if (lane < 256) {   // add up the per-wave rows of flame_skin_bwd: thread (w, q) sums value q over the rows r = w (mod 4), in row order
     const int w = lane >> 6, q = lane & 63;
     float t = 0.f;
     for (int r = w; r < n_rows; r += 4) t += partial[(size_t)r * 64 + q];
     part4[w][q] = t;
   }
+  __shared__ float s_je[15 * 128];   // joint regressor's expression part and the coefficients: one coalesced round trip
+  __shared__ float s_e[128];
+  __shared__ float sR[5][9], sK[5][9], sth[5];
+  for (int k = lane; k < 15 * n_expr; k += (int)blockDim.x) s_je[k] = j_expr[k];
+  for (int k = lane; k < n_expr; k += (int)blockDim.x) s_e[k] = expr[k];
+  __syncthreads();
   if (lane < 15) {
     float a = j_static[lane];
-    const float* row = j_expr + (size_t)lane * n_expr;
-    for (int k = 0; k < n_expr; ++k) a = fma_(row[k], expr[k], a);
+    const float* row = s_je + lane * n_expr;
+    for (int k = 0; k < n_expr; ++k) a = fma_(row[k], s_e[k], a);
     sJ[lane] = a;
+  }
+  if (lane >= 64 && lane < 69) {       // the five joint rotations (and their generators), one lane each
+    float Rj[9], Kj[9], t;
+    rodrigues_fwd(s_pose + (lane - 64) * 3, Rj, Kj, t);
+    for (int i = 0; i < 9; ++i) { sR[lane - 64][i] = Rj[i]; sK[lane - 64][i] = Kj[i]; }
+    sth[lane - 64] = t;
   }
   __syncthreads();
   if (lane < 64) {
@@ -420,7 +457,8 @@ __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
   if (lane == 0) {
     float R[5][9], K[5][9], th[5], J[5][3];
     for (int j = 0; j < 5; ++j) {
-      rodrigues_fwd(pose + j * 3, R[j], K[j], th[j]);
+      for (int i = 0; i < 9; ++i) { R[j][i] = sR[j][i]; K[j][i] = sK[j][i]; }
+      th[j] = sth[j];
       for (int c = 0; c < 3; ++c) J[j][c] = sJ[j * 3 + c];
     }
     const int par[5] = {-1, 0, 1, 1, 1};
@@ -475,11 +513,18 @@ __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
     for (int c = 0; c < 3; ++c) dJ[0][c] += dtw[0][c];
     // pose features (R_j - I), j = 1..4, are coefficients n_expr .. n_expr+35
     for (int j = 1; j < 5; ++j)
-      for (int i = 0; i < 9; ++i) dR[j][i] += dcoef[n_expr + (j - 1) * 9 + i];
-    for (int j = 0; j < 5; ++j) {
-      const float* G = dR[j];
-      const float* Kj = K[j];
-      const float t = th[j], sn = sinf(t), cs = cosf(t);
+      for (int i = 0; i < 9; ++i) dR[j][i] += s_dcoef[n_expr + (j - 1) * 9 + i];
+    for (int j = 0; j < 5; ++j)
+      for (int i = 0; i < 9; ++i) sR[j][i] = dR[j][i];        // sR now carries dL/dR_j to the five lanes below
+    for (int i = 0; i < 15; ++i) sdJ[i] = dJ[i / 3][i % 3];
+  }
+  __syncthreads();
+  if (lane < 5) {          // axis-angle maps backwards, one joint per lane
+    const int j = lane;
+    {
+      const float* G = sR[j];
+      const float* Kj = sK[j];
+      const float t = sth[j], sn = sinf(t), cs = cosf(t);
       float K2[9], dK[9];
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 3; ++c) {
@@ -497,17 +542,15 @@ __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
         }
       float dth = cs * dsn + sn * dom;
       const float da[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
-      const float* aa = pose + j * 3;
+      const float* aa = s_pose + j * 3;
       const float inv = 1.f / (t + 1e-8f);
       dth -= (da[0] * aa[0] + da[1] * aa[1] + da[2] * aa[2]) * inv * inv;
       for (int c = 0; c < 3; ++c) dpose[j * 3 + c] = da[c] * inv + (t > 0.f ? dth * aa[c] / t : 0.f);
     }
-    for (int i = 0; i < 15; ++i) sdJ[i] = dJ[i / 3][i % 3];
   }
-  __syncthreads();
-  for (int e = lane; e < n_expr; e += 256) {
-    float a = dcoef[e];
-    for (int i = 0; i < 15; ++i) a = fma_(j_expr[(size_t)i * n_expr + e], sdJ[i], a);
+  for (int e = lane; e < n_expr; e += (int)blockDim.x) {
+    float a = s_dcoef[e];
+    for (int i = 0; i < 15; ++i) a = fma_(s_je[i * n_expr + e], sdJ[i], a);
     dexpr[e] = a;
   }
 }
@@ -535,6 +578,8 @@ __global__ void adam_flat_multi_kernel(AdamSegs segs, float b1, float b2, float 
   if (st) { lr_mul = st->flame_inv_bc1; inv_sqrt_bc2 = st->flame_inv_sqrt_bc2; }   // device-resident step (graph replay)
   for (int k = 0; k < segs.n_seg; ++k) {
     const AdamSeg& sg = segs.s[k];
+    const int padded = (sg.n + 255) / 256 * 256;       // segments start on block boundaries
+    if (i >= padded) { i -= padded; continue; }
     if (i < sg.n) {
       const float ge = sg.g[i] * grad_scale;
       sg.g[i] = 0.f;
@@ -542,9 +587,8 @@ __global__ void adam_flat_multi_kernel(AdamSegs segs, float b1, float b2, float 
       const float ve = fma_(b2, sg.v[i], (1.f - b2) * ge * ge);
       sg.m[i] = me; sg.v[i] = ve;
       sg.p[i] = sg.p[i] - (sg.lr_step * lr_mul) * (me / fma_(sqrtf(ve), inv_sqrt_bc2, eps));
-      return;
     }
-    i -= (sg.n + 255) / 256 * 256;       // segments start on block boundaries
+    return;                                             // the tail threads of a segment's last block own nothing
   }
 }
 
@@ -621,7 +665,7 @@ extern "C" int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t
                                     const int32_t* face_start, const int32_t* face_gauss, float* dverts, void* stream) {
   OMFS_REQUIRE(verts && faces && dface && face_start && face_gauss && dverts, "null pointer");
   OMFS_REQUIRE(n_faces > 0 && v_pad > 0, "shape");
-  hipLaunchKernelGGL(face_frames_bwd_kernel, dim3(cdiv(n_faces, 256)), dim3(256), 0, (hipStream_t)stream, verts, faces,
+  hipLaunchKernelGGL(face_frames_bwd_kernel, dim3(cdiv(n_faces * 16, 256)), dim3(256), 0, (hipStream_t)stream, verts, faces,
                      n_faces, dface, face_start, face_gauss, dverts);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
@@ -650,10 +694,10 @@ extern "C" int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basi
                                     const float* expr, const float* pose, const float* sums, float* dcoef, float* dexpr,
                                     float* dpose, float* dtrans, void* stream) {
   OMFS_REQUIRE(rig && basis_dense && dv_shaped && expr && pose && sums && dcoef && dexpr && dpose && dtrans, "null pointer");
-  OMFS_REQUIRE(n_coef == rig->n_expr + 36 && rig->j_static && rig->j_expr, "shape");
+  OMFS_REQUIRE(n_coef == rig->n_expr + 36 && n_coef <= 256 && rig->j_static && rig->j_expr, "shape");
   hipStream_t s = (hipStream_t)stream;
   FrontArgs fa{rig->j_static, rig->j_expr, expr, pose, rig->n_expr, sums, cdiv(rig->n_verts, 256) * 4, dexpr, dpose, dtrans};
-  hipLaunchKernelGGL(basis_t_gemv_kernel, dim3(n_coef), dim3(256), 0, s, basis_dense, dv_shaped, 3 * rig->n_verts, dcoef, fa);
+  hipLaunchKernelGGL(basis_t_gemv_kernel, dim3(n_coef), dim3(GEMV_NT), 0, s, basis_dense, dv_shaped, 3 * rig->n_verts, dcoef, fa);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -192,9 +192,14 @@ struct AdamK {
 };
 
 // One thread: the per-iteration scalars of a training step, on the device (see omfs_step_state in the header).
-__global__ void step_advance_kernel(omfs_step_state* st, omfs_lr_schedule sch) {
+__global__ void step_advance_kernel(omfs_step_state* st, omfs_lr_schedule sch, const int32_t* __restrict__ next_table, int table_len,
+                                    int32_t* __restrict__ next_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int done = st->step;                    // iterations completed before this one
+  const int done = st->step;                    // iterations completed before this one = 0-based index of this one
+  if (next_table && table_len > 0) {
+    const long long j = (long long)done + 1 - (long long)st->table_base;
+    next_out[0] = next_table[j < 0 ? 0 : (j >= table_len ? table_len - 1 : j)];
+  }
   const int step = done + 1, fstep = st->flame_step + 1;
   st->step = step; st->flame_step = fstep;
   double lr = (double)sch.lr_init;
@@ -334,9 +339,11 @@ extern "C" int omfs_adam_step_range(float* params, const float* grads, float* m,
   return OMFS_OK;
 }
 
-extern "C" int omfs_step_advance(omfs_step_state* state_dev, const omfs_lr_schedule* sch, void* stream) {
+extern "C" int omfs_step_advance(omfs_step_state* state_dev, const omfs_lr_schedule* sch, const int32_t* next_table, int table_len,
+                                 int32_t* next_out, void* stream) {
   OMFS_REQUIRE(state_dev && sch && sch->beta1 > 0.f && sch->beta1 < 1.f && sch->beta2 > 0.f && sch->beta2 < 1.f, "args");
-  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, *sch);
+  OMFS_REQUIRE(!next_table || (table_len > 0 && next_out), "next_table needs table_len and next_out");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state_dev, *sch, next_table, table_len, next_out);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -68,6 +68,16 @@ class GaussianModel:
         self.params = torch.from_numpy(host).to(self.device)
         self.binding = torch.from_numpy(np.ascontiguousarray(binding)).to(self.device)
 
+    def caller_order(self, t: torch.Tensor) -> torch.Tensor:
+        """Per-Gaussian columns [..., >= n] of a buffer that lies in storage order (parameters, Adam moments, statistics),
+        as a CPU tensor [..., n] in the order the cloud was given in."""
+        c = t[..., :self.n].detach().cpu()
+        if self.order is None or self.order.shape[0] != self.n:
+            return c
+        inv = np.empty_like(self.order)
+        inv[self.order] = np.arange(self.n)
+        return c[..., torch.from_numpy(inv)]
+
     def to_dict(self, storage_order: bool = False) -> dict:
         """The cloud in the order it was given (storage_order: as it lies in HBM)."""
         p, b = self.params[:, :self.n].cpu().numpy(), self.binding.cpu().numpy()

@@ -252,9 +252,12 @@ def main(argv=None):
                 np.savez(pc_dir / "flame_param.npz", **split["flame"])
         if rank == 0 and it in ckpt_at:
             print(f"\n[ITER {it}] Saving Checkpoint", flush=True)
-            torch.save({"iteration": it, "params": trainer.model.params.cpu(), "binding": trainer.model.binding.cpu(),
-                        "adam_m": trainer.opt.m.cpu(), "adam_v": trainer.opt.v.cpu(), "sh_degree": trainer.sh_degree,
-                        **({"densify_stats": trainer.densify_stats.cpu()} if trainer.densify_stats is not None else {}),
+            # per-Gaussian columns in the order the cloud was given in (not the trainer's storage order): a resumed run lays
+            # the cloud out again and must end up with the same files
+            mdl = trainer.model
+            torch.save({"iteration": it, "params": mdl.caller_order(mdl.params), "binding": mdl.caller_order(mdl.binding),
+                        "adam_m": mdl.caller_order(trainer.opt.m), "adam_v": mdl.caller_order(trainer.opt.v), "sh_degree": trainer.sh_degree,
+                        **({"densify_stats": mdl.caller_order(trainer.densify_stats)} if trainer.densify_stats is not None else {}),
                         **({"flame": trainer.flame_ft.state_dict()} if trainer.flame_ft is not None else {})},
                        out / f"chkpnt{it}.pth")
     torch.cuda.synchronize()

@@ -135,7 +135,9 @@ class Trainer:
         self._graphs, self._graph_seen = {}, set()
         self._state = torch.zeros(L.STEP_STATE_WORDS, dtype=torch.int32, device=self.device)
         self._state_step, self._frames_ready = -1, None
-        self._sched = L.LrScheduleC(float(position_lr_init), float(position_lr_final), int(iterations), 0.9, 0.999)
+        self._next_table = torch.zeros(4096, dtype=torch.int32, device=self.device)     # FLAME timestep of the views of the coming iterations
+        self._table_base = -(1 << 30)
+        self._next_t = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._events = [(torch.cuda.Event(), torch.cuda.Event()), (torch.cuda.Event(), torch.cuda.Event())]
         self._prefetch = None
         self._target_f32 = None
@@ -203,7 +205,8 @@ class Trainer:
         from .distributed import view_index
         vi = view_index(it, self.rank, self.world, len(self.views), self.view_seed)
         return (vi, it & 1, self.sh_degree, self.model.n, self.model.params.data_ptr(), L.ptr(self.densify_stats),
-                self.views[vi].target.data_ptr(), self.rast.keys.data_ptr())
+                self.views[vi].target.data_ptr(), self.rast.keys.data_ptr(), self.pos_lr, self.iterations,
+                self.lr_planes[3:].tobytes(), self.lambda_dssim, tuple(self.reg))
 
     def invalidate_graphs(self) -> None:
         """Buffers a captured iteration refers to were replaced (densification): forget every graph."""
@@ -221,10 +224,12 @@ class Trainer:
         view = self.view_for_step(it)
         cam = self._cam(view, self.sh_degree)
         r, ft, lib = self.rast, self.flame_ft, L.load()
+        sched = L.LrScheduleC(float(self.pos_lr[0]), float(self.pos_lr[1]), int(self.iterations), float(self.opt.ap.beta1), float(self.opt.ap.beta2))
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             s = L.stream_ptr()
-            L.check(lib.omfs_step_advance(L.ptr(self._state), self._sched, s), "omfs_step_advance")
+            L.check(lib.omfs_step_advance(L.ptr(self._state), sched, L.ptr(self._next_table), int(self._next_table.shape[0]),
+                                          L.ptr(self._next_t), s), "omfs_step_advance")
             if ft is not None:
                 self.dflame.slot = it & 1
                 _, _, verts_all, face_all, _ = self.dflame._buffers(1)
@@ -250,25 +255,39 @@ class Trainer:
             L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd")
             rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
             L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd")
-            join = None
-            if ft is not None:
-                fork, join = torch.cuda.Event(), torch.cuda.Event()
-                fork.record()
-                with torch.cuda.stream(self._side_stream):
-                    self._side_stream.wait_event(fork)
-                    ft._t = view.timestep
-                    ft.backward(verts, 1, 0)
-                    ft.step(1.0, state_dev=L.ptr(self._state))
-                    self.dflame.slot = (it + 1) & 1
-                    self._pose_frames(it + 1)
-                    join.record(self._side_stream)
-                self.dflame.slot = it & 1
             m = self.model
             self.opt.ap.grad_scale = 1.0
-            L.check(lib.omfs_adam_step_dev(L.ptr(m.params), L.ptr(self.grads), L.ptr(self.opt.m), L.ptr(self.opt.v), m.n, m.n_pad,
-                                           self.opt.ap, L.ptr(self._state), 0, NPLANES, s), "omfs_adam_step_dev")
-            if join is not None:
-                torch.cuda.current_stream().wait_event(join)
+
+            def adam():
+                L.check(lib.omfs_adam_step_dev(L.ptr(m.params), L.ptr(self.grads), L.ptr(self.opt.m), L.ptr(self.opt.v), m.n, m.n_pad,
+                                               self.opt.ap, L.ptr(self._state), 0, NPLANES, L.stream_ptr()), "omfs_adam_step_dev")
+
+            def flame_tail():
+                # FLAME Adam, then the NEXT view's pose: its timestep comes from device memory (self._next_t, written by the
+                # graph's first node from the device-resident schedule) -- with a shuffled schedule the successor of a view
+                # changes from epoch to epoch
+                ft.step(1.0, state_dev=L.ptr(self._state))
+                self.dflame.slot = (it + 1) & 1
+                self.dflame.face_frames_indexed(self._next_t)
+                self.dflame.slot = it & 1
+
+            if ft is None:
+                adam()
+            else:
+                ft._t = view.timestep
+                ft.backward(verts, 1, 0)              # the three gathers stay in front of the Adam pass (see the eager path)
+                if os.environ.get("OMFS_GRAPH_FORK", "1") != "0":
+                    fork, join = torch.cuda.Event(), torch.cuda.Event()
+                    fork.record()
+                    with torch.cuda.stream(self._side_stream):       # a parallel branch of the graph beside the Adam pass
+                        self._side_stream.wait_event(fork)
+                        flame_tail()
+                        join.record(self._side_stream)
+                    adam()
+                    torch.cuda.current_stream().wait_event(join)
+                else:
+                    adam()
+                    flame_tail()
         return graph
 
     def _step_graph(self, it: int) -> bool:
@@ -294,10 +313,25 @@ class Trainer:
                 torch.cuda.current_stream().wait_stream(self._side_stream)
                 self.dflame.slot = it & 1
                 self._pose_frames(it)
+        if not (self._table_base <= it and it + 1 < self._table_base + int(self._next_table.shape[0])) or self._state_step != it:
+            # (re)build the device-resident schedule: the FLAME timestep of the view of every iteration from `it` on; the graph's
+            # first node reads the entry of iteration it + 1 (the view it poses last) -- nothing is copied between replays
+            torch.cuda.synchronize(self.device)
+            n_tab = int(self._next_table.shape[0])
+            tab = [self.view_for_step(sidx).timestep for sidx in range(it, it + n_tab)]
+            self._next_table.copy_(torch.tensor(tab, dtype=torch.int32))
+            self._table_base = it
+            self._state[L.STEP_STATE_TABLE_BASE:L.STEP_STATE_TABLE_BASE + 1].copy_(torch.tensor([it], dtype=torch.int32))
+            torch.cuda.synchronize(self.device)
         if graph is None:
             self.opt.set_lr(self.lr_planes)
             graph = self._graphs[key] = self._capture_step(it)
         graph.replay()
+        dbg = os.environ.get("OMFS_GRAPH_DEBUG", "")
+        if dbg == "sync":
+            torch.cuda.synchronize(self.device)
+        elif dbg == "fence":
+            self._next_t.add_(0)          # an eager kernel between two replays
         self.opt.step_count += 1
         if ft is not None:
             ft.step_count += 1
@@ -400,11 +434,14 @@ class Trainer:
         rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
         L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
         if ft_pipe:
+            # The three gathers of the FLAME backward stay on this stream: beside the bandwidth-bound Adam pass they run 3-5x
+            # slower (measured: 34 + 28 + 50 us instead of 12 + 8 + 15), which made the chain longer than the pass it
+            # hides under.  What forks are the FLAME Adam and the next view's pose (joints, LBS, triangle frames).
+            ft.backward(verts[col], nb, col)
             ev_main, ev_side = self._events[it & 1]
-            ev_main.record()                                    # dface of this step is complete
+            ev_main.record()
             with torch.cuda.stream(self._side_stream):
                 self._side_stream.wait_event(ev_main)
-                ft.backward(verts[col], nb, col)
                 ft.step(1.0)
                 nview = self.view_for_step(it + 1)
                 self.dflame.slot = (it + 1) & 1

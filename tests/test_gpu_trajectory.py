@@ -157,7 +157,7 @@ def test_graph_replay_of_whole_iterations_matches_eager_steps(finetune):
     for lo, hi in ((0, 3), (3, 6), (6, 10), (10, 11), (11, 59)):
         a, b = tg.model.params[lo:hi, :n].cpu().numpy(), te.model.params[lo:hi, :n].cpu().numpy()
         d = np.abs(a - b)
-        assert d.mean() <= 2e-4 * max(1.0, np.abs(b).max()) and d.max() <= 5e-2, (lo, d.mean(), d.max())
+        assert d.mean() <= 3e-4 * max(1.0, np.abs(b).max()) and d.max() <= 0.1, (lo, d.mean(), d.max())
     if finetune:
         for k in ("expr", "pose", "translation"):
             a, b = tg.flame_ft.params[k].cpu().numpy(), te.flame_ft.params[k].cpu().numpy()

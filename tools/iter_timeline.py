@@ -8,13 +8,24 @@ import sys
 
 import numpy as np
 
-db = glob.glob(sys.argv[1].rstrip("/") + "/*results.db")[0]
+db = (glob.glob(sys.argv[1].rstrip("/") + "/*results.db") + glob.glob(sys.argv[1].rstrip("/") + "/*/*results.db"))[0]
 n_last = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 con = sqlite3.connect(db)
 tabs = [r[0] for r in con.execute("select name from sqlite_master where type='table'")]
 kt = [t for t in tabs if "kernel_dispatch" in t][0]
 ks = [t for t in tabs if "kernel_symbol" in t][0]
-names = {k: v.split("(")[0].replace("omfs::", "").replace("void ", "") for k, v in con.execute(f"select id, kernel_name from {ks}")}
+import re
+
+
+def short(v):
+    m = re.match(r"_ZN4omfs(\d+)", v)          # mangled: _ZN4omfs<len><name>...
+    if m:
+        n = int(m.group(1))
+        return v[m.end():m.end() + n] + ("<" + re.search(r"ILi(\d+)E", v).group(1) + ">" if "ILi" in v else "")
+    return v.split("(")[0].replace("omfs::", "").replace("void ", "")
+
+
+names = {k: short(v) for k, v in con.execute(f"select id, kernel_name from {ks}")}
 rows = con.execute(f"select kernel_id, queue_id, start, end from {kt} order by start").fetchall()
 marks = [i for i, r in enumerate(rows) if names[r[0]].startswith("adam_kernel")]
 units = []
