@@ -185,11 +185,7 @@ typedef struct omfs_raster_buffers {
   uint32_t* n_visible;    /* optional [1]: number of Gaussians with radius > 0 in this view; omfs_project_fwd clears it,
                              omfs_bin_count accumulates it (what omfs_count_visible computes, without its two
                              dispatches); may be NULL                                                              */
-  uint32_t* scan_scratch; /* optional [OMFS_SCAN_SCRATCH_WORDS], zero before the first use and left zero by every call: with it
-                             omfs_bin_scan runs as several workgroups that exchange their totals through these words (same
-                             result, a quarter of the time); NULL: one workgroup                                    */
 } omfs_raster_buffers;
-#define OMFS_SCAN_SCRATCH_WORDS 1040
 #define OMFS_RB_FORWARD_ONLY 1u
 
 /* deform + project + colour for one view -> g0,g1,g2. face_xf [n_faces][16]. */

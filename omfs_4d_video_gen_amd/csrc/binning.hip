@@ -14,20 +14,20 @@
 namespace omfs {
 
 // ------------------------------------------------------------------ scan + launch order
-// One workgroup.  Thread t owns the SCAN_PER consecutive tiles starting at t * per; their counts are loaded once
-// (independent loads, one round trip) and stay in registers:
-//   0. exclusive scan of the counts -> tile_start, tile_cursor = 0, overflow flag;
-//   1. launch order: tiles by descending length CLASS (heavy tiles first; inside a class by tile index) and, with it,
-//      order_seg0[p] = OMFS_SEG-entry list segments owned by the tiles before position p (order_seg0[n_tiles] = total):
-//      the backward pass launches one wave per (segment, quadrant) and finds its tile by bisection in this array.
-// Eight classes -- >= 8192, 4096.., 2048.., 1024.., 512.., 128.., 1.., 0 entries: single powers of two where the long
-// lists are -- make the order a STABLE counting sort that needs no atomics at all: a tile's position is the number of tiles
-// in heavier classes plus its rank among the tiles of its own class, and all eight ranks come out of ONE prefix scan of
-// packed counters (8 x 16-bit tile counts in four words, 8 x 32-bit segment sums in eight words; n_tiles < 65536).
-// (History: one returning LDS atomic per tile on a dozen bucket counters serialised in the LDS, 23 us; wave-aggregated
-// counting over the distinct buckets of each wave traded that for dependent ballot / scan chains, 38 us.)
+// One workgroup.  Thread t owns the SCAN_PER consecutive tiles starting at t * per; their counts stay in registers:
+//   1. exclusive scan of the counts -> tile_start, tile_cursor = 0, overflow flag;
+//   2. launch order: tiles sorted by descending log2 bucket of their count (heavy tiles first).  One 64-bit LDS
+//      atomic per tile hands out the position inside the bucket (low word) together with the number of
+//      OMFS_SEG-entry list segments of the tiles in front of it (high word), so
+//   3. order_seg0[p] = segments owned by the tiles before position p of the launch order (order_seg0[n_tiles] =
+//      total) needs no further pass.  The backward pass launches one wave per (segment, quadrant) and finds its
+//      tile by bisection in this array.
+// What this kernel costs is what ONE compute unit can issue: three replacements of the per-tile LDS atomics (wave-
+// aggregated counting, a stable sort by packed class counters, the same across several workgroups with a flag exchange)
+// all came out SLOWER (31-43 us against 23) because they spend more instructions per tile.  What did pay is the memory
+// side: with thread t owning 8 consecutive tiles a direct global access touches 32 cache lines per wave instruction, so
+// images of up to 8192 tiles move everything through LDS -- coalesced global <-> LDS, strided / scattered LDS <-> registers.
 constexpr int SCAN_PER = 8;   // tiles per thread held in registers (n_tiles <= 8192; larger images loop)
-constexpr int SCAN_CLASSES = 8;
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
@@ -44,47 +44,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32_dpp(uint32_t v) {
   return v;
 }
 
-// 0 = heaviest.  bucket = 32 - clz(c): 14+ -> 0, 13 -> 1, 12 -> 2, 11 -> 3, 10 -> 4, 8..9 -> 5, 1..7 -> 6, empty -> 7
-__device__ __forceinline__ int scan_class(uint32_t c) {
-  if (c == 0u) return 7;
-  const int b = 32 - __clz(c);
-  return b >= 14 ? 0 : (b >= 10 ? 14 - b : (b >= 8 ? 5 : 6));
-}
-
-struct ScanPacked {            // per class: tiles (16 bits each, two per word) and segments (32 bits each)
-  uint32_t w[12];
-};
-__device__ __forceinline__ uint32_t packed_tiles(const ScanPacked& p, int cls) { return (p.w[cls >> 1] >> (16 * (cls & 1))) & 0xFFFFu; }
-__device__ __forceinline__ uint32_t packed_segs(const ScanPacked& p, int cls) { return p.w[4 + cls]; }
-__device__ __forceinline__ void packed_add(ScanPacked& p, int cls, uint32_t segs) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k) p.w[k] += (cls >> 1) == k ? (1u << (16 * (cls & 1))) : 0u;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) p.w[4 + k] += cls == k ? segs : 0u;
-}
-
 __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* __restrict__ tile_count,
                                                          uint32_t* __restrict__ tile_start,
                                                          uint32_t* __restrict__ tile_cursor,
                                                          uint32_t* __restrict__ tile_order, uint32_t dup_capacity,
                                                          uint32_t* __restrict__ status, uint32_t* __restrict__ order_seg0) {
   __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t wave_pk[16][12];     // per wave: packed class totals of its threads (of the current chunk)
-  __shared__ uint32_t carry;               // pairs of the chunks before (images with > 8192 tiles)
-  __shared__ uint32_t grand[12];           // packed class totals of the whole image
-  // ONE workgroup moves ~5 words per tile: with thread t owning 8 consecutive tiles every wave instruction of a direct
-  // global access would touch 32 cache lines (stride 32 B) -- 41 000 line accesses from a single CU, which is what this kernel's
-  // 40 us were.  Images of up to 8192 tiles therefore go through LDS: coalesced global <-> LDS, strided / scattered LDS <->
-  // registers (s_a: counts, then tile_start; s_b / s_c: tile_order / order_seg0 scattered by position).
+  __shared__ unsigned long long bucket_acc[33];   // low: tiles in the bucket, high: their segments; then running bases
+  __shared__ uint32_t carry;                      // tiles / pairs of the chunks before (images with > 8192 tiles)
   extern __shared__ __attribute__((aligned(16))) uint32_t scan_lds[];
-  uint32_t* s_a = scan_lds;
-  uint32_t* s_b = scan_lds + 1024 * SCAN_PER;
-  uint32_t* s_c = scan_lds + 2 * 1024 * SCAN_PER;
+  uint32_t* s_a = scan_lds;                       // counts, then tile_start
+  uint32_t* s_b = scan_lds + 1024 * SCAN_PER;     // tile_order by position
+  uint32_t* s_c = scan_lds + 2 * 1024 * SCAN_PER; // order_seg0 by position
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 33) bucket_acc[tid] = 0ull;
   if (tid == 0) carry = 0;
-  if (tid < 12) grand[tid] = 0;
-  uint32_t cnt[SCAN_PER];
-  const bool single = n_tiles <= 1024 * SCAN_PER;   // then cnt[] still holds this thread's counts in phase 1
+  const bool single = n_tiles <= 1024 * SCAN_PER;   // then everything is staged through LDS and cnt[] survives into pass B
   if (single) {
     for (int i = tid; i < 1024 * SCAN_PER; i += 1024) {
       const bool in = i < n_tiles;
@@ -93,7 +68,10 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
     }
   }
   __syncthreads();
-  auto load_counts = [&](int beg) {
+  // ---- pass A over chunks of 8192 tiles: scan + bucket totals
+  uint32_t cnt[SCAN_PER];
+  for (int c0 = 0; c0 < n_tiles; c0 += 1024 * SCAN_PER) {
+    const int beg = c0 + tid * SCAN_PER;
     if (single) {
       const uint4 a = *reinterpret_cast<const uint4*>(s_a + beg), b = *reinterpret_cast<const uint4*>(s_a + beg + 4);
       cnt[0] = a.x; cnt[1] = a.y; cnt[2] = a.z; cnt[3] = a.w; cnt[4] = b.x; cnt[5] = b.y; cnt[6] = b.z; cnt[7] = b.w;
@@ -101,32 +79,11 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
 #pragma unroll
       for (int k = 0; k < SCAN_PER; ++k) cnt[k] = beg + k < n_tiles ? tile_count[beg + k] : 0u;
     }
-  };
-  auto thread_packed = [&](int beg) {
-    ScanPacked t;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) t.w[k] = 0u;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k)
-      if (beg + k < n_tiles) packed_add(t, scan_class(cnt[k]), (cnt[k] + OMFS_SEG - 1) / OMFS_SEG);
-    return t;
-  };
-  // ---- phase 0 over chunks of 8192 tiles: exclusive scan -> tile_start; class totals of the image
-  for (int c0 = 0; c0 < n_tiles; c0 += 1024 * SCAN_PER) {
-    const int beg = c0 + tid * SCAN_PER;
-    load_counts(beg);
     uint32_t sum = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_PER; ++k) sum += cnt[k];
     const uint32_t incl = wave_incl_scan_u32_dpp(sum);
     if (lane == 63) wave_tot[wave] = incl;
-    // class totals: wave sums (the inclusive scan's last lane), then one LDS add per wave and word
-    const ScanPacked t = thread_packed(beg);
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const uint32_t tot = wave_incl_scan_u32_dpp(t.w[k]);
-      if (lane == 63) atomicAdd(&grand[k], tot);
-    }
     __syncthreads();
     uint32_t base = carry, chunk_total = 0;
     for (int w = 0; w < 16; ++w) {
@@ -135,206 +92,62 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
       chunk_total += v;
     }
     uint32_t run = base + incl - sum;
-    if (single) {
-      uint32_t st[SCAN_PER];
+    uint32_t st[SCAN_PER];
 #pragma unroll
-      for (int k = 0; k < SCAN_PER; ++k) { st[k] = run; run += cnt[k]; }
-      *reinterpret_cast<uint4*>(s_b + beg) = make_uint4(st[0], st[1], st[2], st[3]);
-      *reinterpret_cast<uint4*>(s_b + beg + 4) = make_uint4(st[4], st[5], st[6], st[7]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < SCAN_PER; ++k) {
-        if (beg + k < n_tiles) {
-          tile_start[beg + k] = run;       // rewritten as 0 below if the capacity overflows
-          tile_cursor[beg + k] = 0;
-          run += cnt[k];
-        }
+    for (int k = 0; k < SCAN_PER; ++k) {
+      st[k] = run;
+      if (beg + k < n_tiles) {
+        if (!single) { tile_start[beg + k] = run; tile_cursor[beg + k] = 0; }   // rewritten as 0 below if the capacity overflows
+        const uint32_t c = cnt[k];
+        const int bucket = c ? (32 - __clz(c)) : 0;  // 0..32, larger = more work
+        atomicAdd(&bucket_acc[32 - bucket], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
+        run += c;
       }
     }
-    __syncthreads();
+    __syncthreads();                               // everybody has read its counts from s_a
+    if (single) {
+      *reinterpret_cast<uint4*>(s_a + beg) = make_uint4(st[0], st[1], st[2], st[3]);
+      *reinterpret_cast<uint4*>(s_a + beg + 4) = make_uint4(st[4], st[5], st[6], st[7]);
+    }
     if (tid == 0) carry += chunk_total;
     __syncthreads();
   }
   const uint32_t total = carry;
-  if (total > dup_capacity) {
-    // every list is emptied (the frame shows the background, the flag tells the host): identity order, no segments
-    if (tid == 0) { tile_start[n_tiles] = 0u; order_seg0[n_tiles] = 0u; atomicOr(status, OMFS_STATUS_DUP_OVERFLOW); }
-    for (int t = tid; t < n_tiles; t += 1024) { tile_start[t] = 0u; tile_count[t] = 0u; tile_order[t] = (uint32_t)t; order_seg0[t] = 0u; }
-    return;
-  }
+  const bool overflow = total > dup_capacity;
   if (single)
-    for (int i = tid; i < n_tiles; i += 1024) tile_start[i] = s_b[i];     // coalesced (s_b is free again after the next barrier)
-  // ---- class bases: tiles / segments of the heavier classes (every thread computes the eight of them itself)
-  ScanPacked g;
-#pragma unroll
-  for (int k = 0; k < 12; ++k) g.w[k] = grand[k];
-  uint32_t base_tiles[SCAN_CLASSES], base_segs[SCAN_CLASSES];
-  {
-    uint32_t rt = 0, rs = 0;
-#pragma unroll
-    for (int c = 0; c < SCAN_CLASSES; ++c) { base_tiles[c] = rt; base_segs[c] = rs; rt += packed_tiles(g, c); rs += packed_segs(g, c); }
-    if (tid == 0) { tile_start[n_tiles] = total; order_seg0[n_tiles] = rs; }
+    for (int i = tid; i < n_tiles; i += 1024) tile_start[i] = overflow ? 0u : s_a[i];     // coalesced
+  if (tid == 0) {
+    tile_start[n_tiles] = overflow ? 0u : total;
+    if (overflow) atomicOr(status, OMFS_STATUS_DUP_OVERFLOW);
+    unsigned long long r = 0ull;   // exclusive scan over the buckets, both words at once
+    for (int b = 0; b < 33; ++b) {
+      const unsigned long long v = overflow ? 0ull : bucket_acc[b];   // on overflow every list is emptied: one bucket
+      bucket_acc[b] = r;
+      r += v;
+    }
+    order_seg0[n_tiles] = overflow ? 0u : (uint32_t)(r >> 32);
   }
-  __syncthreads();          // grand is re-used as the running offsets of the chunks done so far
-  if (tid < 12) grand[tid] = 0;
   __syncthreads();
-  // ---- phase 1: position = class base + rank inside the class (one packed prefix scan); counts re-read for > 8192 tiles
+  // ---- pass B: positions in the launch order (+ segment prefix); counts are re-read only for images with > 8192 tiles
   for (int c0 = 0; c0 < n_tiles; c0 += 1024 * SCAN_PER) {
     const int beg = c0 + tid * SCAN_PER;
-    if (!single) load_counts(beg);
-    const ScanPacked t = thread_packed(beg);
-    ScanPacked ex;            // exclusive prefix of this thread inside the image
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      const uint32_t incl = wave_incl_scan_u32_dpp(t.w[k]);
-      ex.w[k] = incl - t.w[k];
-      if (lane == 63) wave_pk[wave][k] = incl;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 12; ++k) {
-      uint32_t b = grand[k];
-      for (int w = 0; w < 16; ++w) b += w < wave ? wave_pk[w][k] : 0u;
-      ex.w[k] += b;
-    }
 #pragma unroll
     for (int k = 0; k < SCAN_PER; ++k) {
       if (beg + k < n_tiles) {
-        const uint32_t c = cnt[k];
-        const int cls = scan_class(c);
-        const uint32_t sg = (c + OMFS_SEG - 1) / OMFS_SEG;
-        uint32_t bt = 0, bs = 0;
-#pragma unroll
-        for (int q = 0; q < SCAN_CLASSES; ++q) { bt = cls == q ? base_tiles[q] : bt; bs = cls == q ? base_segs[q] : bs; }
-        const uint32_t pos = bt + packed_tiles(ex, cls);
-        if (single) {
-          s_b[pos] = (uint32_t)(beg + k);
-          s_c[pos] = bs + packed_segs(ex, cls);
-        } else {
-          tile_order[pos] = (uint32_t)(beg + k);
-          order_seg0[pos] = bs + packed_segs(ex, cls);
-          tile_count[beg + k] = 0;         // consumed: the next frame's omfs_bin_count accumulates from zero
-        }
-        packed_add(ex, cls, sg);
+        uint32_t c = single ? cnt[k] : tile_count[beg + k];
+        if (!single) tile_count[beg + k] = 0;          // consumed: the next frame's omfs_bin_count accumulates from zero
+        if (overflow) { c = 0; if (!single) tile_start[beg + k] = 0; }
+        const int bucket = c ? (32 - __clz(c)) : 0;
+        const unsigned long long old = atomicAdd(&bucket_acc[32 - bucket], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
+        const uint32_t pos = (uint32_t)old;
+        if (single) { s_b[pos] = (uint32_t)(beg + k); s_c[pos] = (uint32_t)(old >> 32); }
+        else { tile_order[pos] = (uint32_t)(beg + k); order_seg0[pos] = (uint32_t)(old >> 32); }
       }
     }
+  }
+  if (single) {
     __syncthreads();
-    if (single)
-      for (int i = tid; i < n_tiles; i += 1024) { tile_order[i] = s_b[i]; order_seg0[i] = s_c[i]; }
-    if (tid < 12) {           // running offsets for the next chunk
-      uint32_t a = grand[tid];
-      for (int w = 0; w < 16; ++w) a += wave_pk[w][tid];
-      grand[tid] = a;
-    }
-    __syncthreads();
-  }
-}
-
-// ---- multi-workgroup form (images whose raster buffers carry scan_scratch): one tile per thread, WGs of 1024 tiles.
-// Every WG publishes its 13 totals (pairs + packed class totals) and a flag in scan_scratch, then reads ALL WGs' totals
-// (the class bases need the whole image): with at most 64 WGs, all resident at once, waiting for a flag cannot deadlock.
-// The WG that finishes last (ticket) clears the scratch for the next launch.
-constexpr int SCAN_MAX_WGS = 64;
-static_assert(SCAN_MAX_WGS * 16 + 16 == OMFS_SCAN_SCRATCH_WORDS, "per WG: 13 totals, pad, flag at [15]; then the ticket");
-
-__global__ __launch_bounds__(1024) void tile_scan_multi_kernel(int n_tiles, uint32_t* __restrict__ tile_count,
-                                                               uint32_t* __restrict__ tile_start, uint32_t* __restrict__ tile_cursor,
-                                                               uint32_t* __restrict__ tile_order, uint32_t dup_capacity,
-                                                               uint32_t* __restrict__ status, uint32_t* __restrict__ order_seg0,
-                                                               uint32_t* __restrict__ scratch) {
-  __shared__ uint32_t wave_tot[16][13];
-  __shared__ uint32_t s_before[13], s_grand[13];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wg = blockIdx.x, n_wg = gridDim.x;
-  const int i = wg * 1024 + tid;
-  const bool in = i < n_tiles;
-  const uint32_t c = in ? tile_count[i] : 0u;
-  if (in) { tile_count[i] = 0u; tile_cursor[i] = 0u; }
-  const int cls = scan_class(c);
-  const uint32_t sg = (c + OMFS_SEG - 1) / OMFS_SEG;
-  uint32_t v[13];        // [0] pairs, [1..4] packed tile counts, [5..12] segments per class
-  v[0] = c;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v[1 + k] = in && (cls >> 1) == k ? (1u << (16 * (cls & 1))) : 0u;
-#pragma unroll
-  for (int k = 0; k < 8; ++k) v[5 + k] = in && cls == k ? sg : 0u;
-  uint32_t ex[13];
-#pragma unroll
-  for (int k = 0; k < 13; ++k) {
-    const uint32_t incl = wave_incl_scan_u32_dpp(v[k]);
-    ex[k] = incl - v[k];
-    if (lane == 63) wave_tot[wave][k] = incl;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 13; ++k) {
-    uint32_t b = 0;
-    for (int w = 0; w < 16; ++w) b += w < wave ? wave_tot[w][k] : 0u;
-    ex[k] += b;
-  }
-  // ---- publish this WG's totals, then collect everybody's
-  if (tid < 13) {
-    uint32_t t = 0;
-    for (int w = 0; w < 16; ++w) t += wave_tot[w][tid];
-    __hip_atomic_store(&scratch[wg * 16 + tid], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(&scratch[wg * 16 + 15], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  if (wave == 0) {
-    uint32_t mine[13];
-#pragma unroll
-    for (int k = 0; k < 13; ++k) mine[k] = 0u;
-    if (lane < n_wg) {
-      while (__hip_atomic_load(&scratch[lane * 16 + 15], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-      for (int k = 0; k < 13; ++k) mine[k] = __hip_atomic_load(&scratch[lane * 16 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#pragma unroll
-    for (int k = 0; k < 13; ++k) {
-      const uint32_t incl = wave_incl_scan_u32_dpp(mine[k]);      // lanes = workgroups, in order
-      const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(incl - mine[k]), wg);
-      const uint32_t grand = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      if (lane == 0) { s_before[k] = before; s_grand[k] = grand; }
-    }
-  }
-  __syncthreads();
-  const uint32_t total = s_grand[0];
-  const bool overflow = total > dup_capacity;
-  if (in) {
-    if (overflow) {
-      tile_start[i] = 0u; tile_order[i] = (uint32_t)i; order_seg0[i] = 0u;
-    } else {
-      tile_start[i] = s_before[0] + ex[0];
-      ScanPacked g, b, e;
-#pragma unroll
-      for (int k = 0; k < 12; ++k) { g.w[k] = s_grand[1 + k]; b.w[k] = s_before[1 + k]; e.w[k] = ex[1 + k]; }
-      uint32_t bt = 0, bs = 0, rt = 0, rs = 0;
-#pragma unroll
-      for (int q = 0; q < SCAN_CLASSES; ++q) {
-        bt = cls == q ? rt : bt; bs = cls == q ? rs : bs;
-        rt += packed_tiles(g, q); rs += packed_segs(g, q);
-      }
-      const uint32_t pos = bt + packed_tiles(b, cls) + packed_tiles(e, cls);
-      tile_order[pos] = (uint32_t)i;
-      order_seg0[pos] = bs + packed_segs(b, cls) + packed_segs(e, cls);
-    }
-  }
-  if (wg == 0 && tid == 0) {
-    if (overflow) { tile_start[n_tiles] = 0u; order_seg0[n_tiles] = 0u; atomicOr(status, OMFS_STATUS_DUP_OVERFLOW); }
-    else {
-      uint32_t rs = 0;
-      for (int q = 0; q < SCAN_CLASSES; ++q) rs += s_grand[5 + q];
-      tile_start[n_tiles] = total; order_seg0[n_tiles] = rs;
-    }
-  }
-  // ---- the last workgroup out clears the scratch (every workgroup has read what it needs before it takes its ticket)
-  __syncthreads();
-  if (tid == 0) {
-    const uint32_t ticket = __hip_atomic_fetch_add(&scratch[SCAN_MAX_WGS * 16], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket == (uint32_t)n_wg - 1) {
-      for (int w = 0; w < n_wg; ++w)
-        for (int k = 0; k < 16; ++k) __hip_atomic_store(&scratch[w * 16 + k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&scratch[SCAN_MAX_WGS * 16], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    for (int i = tid; i < n_tiles; i += 1024) { tile_order[i] = s_b[i]; order_seg0[i] = s_c[i]; }
   }
 }
 
@@ -853,13 +666,6 @@ extern "C" int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* 
   if (int rc = check_bin_args(cam, rb)) return rc;
   const int n_tiles = cdiv(cam->width, OMFS_TILE) * cdiv(cam->height, OMFS_TILE);
   OMFS_REQUIRE(rb->order_seg0, "order_seg0");
-  const int n_wg = cdiv(n_tiles, 1024);
-  if (rb->scan_scratch && n_wg <= SCAN_MAX_WGS) {       // several workgroups (all resident at once), one tile per thread
-    hipLaunchKernelGGL(tile_scan_multi_kernel, dim3(n_wg), dim3(1024), 0, (hipStream_t)stream, n_tiles, rb->tile_count, rb->tile_start,
-                       rb->tile_cursor, rb->tile_order, rb->dup_capacity, rb->status, rb->order_seg0, rb->scan_scratch);
-    OMFS_CHECK_HIP(hipGetLastError());
-    return OMFS_OK;
-  }
   static std::atomic<unsigned long long> attr_done{0};
   constexpr int scan_lds_bytes = 3 * 1024 * SCAN_PER * 4;     // 96 KB
   if (int rc = ensure_max_lds((const void*)tile_scan_kernel, scan_lds_bytes, attr_done)) return rc;

@@ -65,13 +65,12 @@ class Rasterizer:
         self.final_T = z(height, width)
         self.n_contrib = z(height, width, dt=torch.int32)
         self.n_visible = z(1, dt=torch.int32)
-        self.scan_scratch = z(L.SCAN_SCRATCH_WORDS, dt=torch.int32)     # multi-workgroup tile scan (kept zero by the kernel)
         self.rb = L.RasterBuffersC(L.ptr(self.g0), L.ptr(self.g1), L.ptr(self.g2), L.ptr(self.tile_count),
                                    L.ptr(self.tile_start), L.ptr(self.tile_cursor), L.ptr(self.tile_order),
                                    L.ptr(self.keys), L.ptr(self.keys_tmp), L.ptr(self.sorted_ids),
                                    self.dup_capacity, int(sort_lds_pairs), L.ptr(self.status),
                                    L.ptr(self.seg_ckpt), L.ptr(self.order_seg0), self.seg_capacity, L.ptr(self.image),
-                                   L.ptr(self.final_T), L.ptr(self.n_contrib), 0, 0, L.ptr(self.scan_scratch))
+                                   L.ptr(self.final_T), L.ptr(self.n_contrib), 0, 0)
         # backward-side buffers are created on first use
         self.dsplat = None
         self.dimage = None
