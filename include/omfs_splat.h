@@ -169,11 +169,8 @@ typedef struct omfs_raster_buffers {
   uint32_t dup_capacity;
   uint32_t sort_lds_pairs; /* longest tile list whose bucket-ordered copy is kept in LDS (0 = default 7936 pairs = 78 KB,
                               two workgroups per CU; 8 B of LDS each); longer lists keep it in keys_tmp        */
-  uint32_t* status;       /* [4] word 0: OMFS_STATUS_* bits, OR-ed by kernels (caller zeroes); word 1: stamp of the
-                             (Gaussians, camera) whose tile-test ballots keys_tmp holds (library-owned, zero initially);
-                             words 2, 3 (written by omfs_bin_scan): number of tiles whose list is longer than
-                             4 * OMFS_SEG entries (they lead tile_order; the segment-parallel forward works on them) and
-                             the frame's total of list segments -- what deep_launch / seg_launch below are estimated from */
+  uint32_t* status;       /* [2] word 0: OMFS_STATUS_* bits, OR-ed by kernels (caller zeroes); word 1: stamp of the
+                             (Gaussians, camera) whose tile-test ballots keys_tmp holds (library-owned, zero initially) */
   /* forward checkpoints for the depth-parallel backward pass: per pixel (T, C.rgb) on entering list segment k
    * (k >= 1) of tile t, stored at slot tile_start[t]/OMFS_SEG + t + k; seg_capacity >= n_tiles + dup_capacity/OMFS_SEG */
   float* seg_ckpt;        /* [seg_capacity][256][4]                                               */
@@ -185,10 +182,6 @@ typedef struct omfs_raster_buffers {
   uint32_t* n_contrib;    /* [height][width]                                                     */
   uint32_t flags;         /* OMFS_RB_FORWARD_ONLY: no backward pass will follow (render_surgery): the forward skips
                              the segment checkpoints (only the hand-over slots between its two kernels are written) */
-  uint32_t deep_launch;   /* omfs_composite_fwd: launch-order positions the segment-parallel kernel is launched for       */
-  uint32_t seg_launch;    /* omfs_composite_bwd: list segments the kernel is launched for.  Both: 0 = everything (all tiles /
-                             seg_capacity).  A caller that reads status[2], status[3] of earlier frames (asynchronously) sets
-                             them a little above; too small an estimate costs time, never work: the workgroups stride on  */
   uint32_t* n_visible;    /* optional [1]: number of Gaussians with radius > 0 in this view; omfs_project_fwd clears it,
                              omfs_bin_count accumulates it (what omfs_count_visible computes, without its two
                              dispatches); may be NULL                                                              */

@@ -52,14 +52,13 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
   __shared__ uint32_t wave_tot[16];
   __shared__ unsigned long long bucket_acc[33];   // low: tiles in the bucket, high: their segments; then running bases
   __shared__ uint32_t carry;                      // tiles / pairs of the chunks before (images with > 8192 tiles)
-  __shared__ uint32_t n_deep;                     // tiles whose list the one-wave forward hands over (> 4 segments)
   extern __shared__ __attribute__((aligned(16))) uint32_t scan_lds[];
   uint32_t* s_a = scan_lds;                       // counts, then tile_start
   uint32_t* s_b = scan_lds + 1024 * SCAN_PER;     // tile_order by position
   uint32_t* s_c = scan_lds + 2 * 1024 * SCAN_PER; // order_seg0 by position
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid < 33) bucket_acc[tid] = 0ull;
-  if (tid == 0) { carry = 0; n_deep = 0; }
+  if (tid == 0) carry = 0;
   const bool single = n_tiles <= 1024 * SCAN_PER;   // then everything is staged through LDS and cnt[] survives into pass B
   if (single) {
     for (int i = tid; i < 1024 * SCAN_PER; i += 1024) {
@@ -80,12 +79,11 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
 #pragma unroll
       for (int k = 0; k < SCAN_PER; ++k) cnt[k] = beg + k < n_tiles ? tile_count[beg + k] : 0u;
     }
-    uint32_t sum = 0, deep = 0;
+    uint32_t sum = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_PER; ++k) { sum += cnt[k]; deep += cnt[k] > 4u * OMFS_SEG ? 1u : 0u; }
+    for (int k = 0; k < SCAN_PER; ++k) sum += cnt[k];
     const uint32_t incl = wave_incl_scan_u32_dpp(sum);
-    const uint32_t deep_w = wave_incl_scan_u32_dpp(deep);
-    if (lane == 63) { wave_tot[wave] = incl; if (deep_w) atomicAdd(&n_deep, deep_w); }
+    if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     uint32_t base = carry, chunk_total = 0;
     for (int w = 0; w < 16; ++w) {
@@ -128,8 +126,6 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
       r += v;
     }
     order_seg0[n_tiles] = overflow ? 0u : (uint32_t)(r >> 32);
-    status[2] = overflow ? 0u : n_deep;              // what the next frames' launches are sized from (omfs_raster_buffers)
-    status[3] = overflow ? 0u : (uint32_t)(r >> 32);
   }
   __syncthreads();
   // ---- pass B: positions in the launch order (+ segment prefix); counts are re-read only for images with > 8192 tiles

@@ -286,12 +286,8 @@ __device__ __forceinline__ float wave_incl_prod(float v, int lane) {
   return v;
 }
 
-static_assert(FWD_SEQ_SEGS * OMFS_SEG >= 512, "a list the one-wave forward hands over has at least 512 entries (the early exit of the deep kernel relies on it)");
-// One (tile, quadrant) of the deep forward; called by every wave of the workgroup (barriers inside; every early return is
-// uniform over the workgroup).  Returns false when the tile's list is shorter than 512 entries: tile_order is sorted by
-// descending log2 bucket, so no later position can be deep either.
-__device__ __forceinline__ bool composite_fwd_deep_tile(
-    uint32_t pos, int quad, const CompCam& cam, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_start,
+__global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
+    CompCam cam, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ sorted_ids, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ g2, float* __restrict__ image, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, float4* __restrict__ seg_ckpt, int keep_ckpt) {
@@ -303,11 +299,10 @@ __device__ __forceinline__ bool composite_fwd_deep_tile(
   __shared__ float4 res[64];                  // exactly resolved pixels: (T, C.rgb)
   __shared__ uint32_t res_last[64];           // last contributor | terminated << 31
   OMFS_DBG_SPAN(1);
-  const uint32_t tile = tile_order[pos];
+  const uint32_t tile = tile_order[blockIdx.x >> 2];
   const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
-  if (tend - tbeg < 512u) return false;
-  if (tend - tbeg <= (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG)) return true;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (tend - tbeg <= (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG)) return;
+  const int quad = blockIdx.x & 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     pg0[wave][0] = make_float4(0.f, 0.f, 0.f, 0.f);
     pg1[wave][0] = make_float4(0.f, -1e30f, 0.f, 0.f);
@@ -320,13 +315,13 @@ __device__ __forceinline__ bool composite_fwd_deep_tile(
   // whatever an earlier view left there.  Lanes outside the image are never live (the hand-over of a partly inside
   // quadrant already excludes them; the mask below makes that independent of the slot's content).
   const unsigned long long in_img = __ballot(px < cam.width && py < cam.height);
-  if (in_img == 0ull) return true;
+  if (in_img == 0ull) return;
   const float4 hand = seg_ckpt[slot0 * 256 + quad * 64];
   unsigned long long live = (unsigned long long)__float_as_uint(hand.x) | ((unsigned long long)__float_as_uint(hand.y) << 32);
   live = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)live) |
          ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(live >> 32)) << 32);   // wave-uniform
   live &= in_img;
-  if (live == 0ull) return true;
+  if (live == 0ull) return;
   const float fx = (float)px, fy = (float)py;
   const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
@@ -513,25 +508,6 @@ __device__ __forceinline__ bool composite_fwd_deep_tile(
     final_T[o] = T;
     n_contrib[o] = last;
   }
-  return true;
-}
-
-// grid = (workgroups for the deep tiles) x 4 quadrants, DEEP_WAVES waves each.  The deep tiles occupy the FIRST positions of
-// tile_order, so the host launches only about as many workgroups as the last frames had deep tiles (a grid over all
-// n_tiles spent 40 % of its span dispatching 8-wave workgroups that exit at once); a workgroup goes on in strides of the
-// grid, so an estimate that is too small costs time, never a tile.
-__global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
-    CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_start,
-    const uint32_t* __restrict__ sorted_ids, const float4* __restrict__ g0, const float4* __restrict__ g1,
-    const float4* __restrict__ g2, float* __restrict__ image, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float4* __restrict__ seg_ckpt, int keep_ckpt) {
-  const int quad = blockIdx.x & 3;
-  const uint32_t stride = gridDim.x >> 2;
-  for (uint32_t pos = blockIdx.x >> 2; pos < (uint32_t)n_tiles; pos += stride) {
-    if (!composite_fwd_deep_tile(pos, quad, cam, tile_order, tile_start, sorted_ids, g0, g1, g2, image, final_T, n_contrib, seg_ckpt, keep_ckpt))
-      return;
-    __syncthreads();          // the LDS pages are reused by the next tile
-  }
 }
 
 // Sums of 9 values over each group of 8 consecutive lanes, left in the group's last lane.  v_add_f32 with a DPP
@@ -573,7 +549,7 @@ __device__ __forceinline__ void reduce9_groups_of_8(float (&v)[9]) {
 #define OMFS_BWD_WAVES 8
 #endif
 #define OMFS_BWD_ATTR __attribute__((amdgpu_waves_per_eu(OMFS_BWD_WAVES, 8)))
-__device__ __forceinline__ void composite_bwd_segment(const uint32_t seg, const CompCam& cam, int n_tiles, const uint32_t* __restrict__ tile_order,
+__global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order,
                                                            const uint32_t* __restrict__ order_seg0,
                                                            const float4* __restrict__ seg_ckpt,
                                                            const uint32_t* __restrict__ tile_start,
@@ -591,6 +567,8 @@ __device__ __forceinline__ void composite_bwd_segment(const uint32_t seg, const 
   __shared__ float red[PEND][8][9];       // [pending slot][8-lane group][value]
   __shared__ uint32_t pend_id[PEND];      // Gaussian id of each pending slot
   OMFS_DBG_SPAN(2);
+  const uint32_t seg = blockIdx.x >> 2;
+  if (seg >= order_seg0[n_tiles]) return;
   // launch-order position p with order_seg0[p] <= seg < order_seg0[p+1] (bisection, ~13 L2-resident loads)
   int lo = 0, hi = n_tiles;
   while (hi - lo > 1) {
@@ -768,27 +746,6 @@ __device__ __forceinline__ void composite_bwd_segment(const uint32_t seg, const 
   if (n_pending) flush_pending();
 }
 
-// grid = (segments to cover) x 4 quadrants, one wave each.  The host sizes it from the segment totals of the last frames
-// (a grid over the whole segment CAPACITY spent the last 30 % of the kernel's span dispatching 360 000 waves that exit at
-// once); a wave goes on in strides of the grid, so an estimate that is too small costs time, never a segment.
-__global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order,
-                                                           const uint32_t* __restrict__ order_seg0,
-                                                           const float4* __restrict__ seg_ckpt,
-                                                           const uint32_t* __restrict__ tile_start,
-                                                           const uint32_t* __restrict__ sorted_ids,
-                                                           const float4* __restrict__ g0, const float4* __restrict__ g1,
-                                                           const float4* __restrict__ g2, const float* __restrict__ image,
-                                                           const float* __restrict__ final_T,
-                                                           const uint32_t* __restrict__ n_contrib,
-                                                           const float* __restrict__ dimage, float* __restrict__ dsplat) {
-  const uint32_t total = order_seg0[n_tiles], stride = gridDim.x >> 2;
-  for (uint32_t seg = blockIdx.x >> 2; seg < total; seg += stride) {
-    composite_bwd_segment(seg, cam, n_tiles, tile_order, order_seg0, seg_ckpt, tile_start, sorted_ids, g0, g1, g2, image, final_T, n_contrib,
-                          dimage, dsplat);
-    __builtin_amdgcn_wave_barrier();       // the wave-private LDS pages are reused by the next segment
-  }
-}
-
 __global__ void image_to_rgb8_kernel(const float* __restrict__ image, int width, int height, uint8_t* __restrict__ rgb8) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = width * height;
@@ -851,8 +808,7 @@ extern "C" int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buff
                      (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt);
   OMFS_CHECK_HIP(hipGetLastError());
   // quadrants whose list is longer than FWD_SEQ_SEGS segments and still unsaturated (the rest exit at once)
-  const uint32_t deep_pos = rb->deep_launch ? (rb->deep_launch < (uint32_t)n_tiles ? rb->deep_launch : (uint32_t)n_tiles) : (uint32_t)n_tiles;
-  hipLaunchKernelGGL(composite_fwd_deep_kernel, dim3(deep_pos * 4), dim3(DEEP_WAVES * 64), 0, (hipStream_t)stream, cc, n_tiles, rb->tile_order,
+  hipLaunchKernelGGL(composite_fwd_deep_kernel, dim3(n_tiles * 4), dim3(DEEP_WAVES * 64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
                      (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt);
   OMFS_CHECK_HIP(hipGetLastError());
@@ -869,8 +825,7 @@ extern "C" int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buff
   OMFS_REQUIRE(rb->order_seg0 && rb->seg_capacity >= (uint32_t)n_tiles + rb->dup_capacity / OMFS_SEG, "segment buffers");
   // one wave per (list segment, quadrant); the grid covers the segment capacity, waves beyond the device-side
   // total (order_seg0[n_tiles]) exit at once
-  const uint32_t segs = rb->seg_launch ? (rb->seg_launch < rb->seg_capacity ? rb->seg_launch : rb->seg_capacity) : rb->seg_capacity;
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3(segs * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
                      rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
                      (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat);
   OMFS_CHECK_HIP(hipGetLastError());

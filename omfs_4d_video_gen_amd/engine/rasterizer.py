@@ -57,13 +57,7 @@ class Rasterizer:
         self.keys = z(self.dup_capacity, 2, dt=torch.int32)
         self.keys_tmp = z(self.dup_capacity, 2, dt=torch.int32)
         self.sorted_ids = z(self.dup_capacity, dt=torch.int32)
-        self.status = z(4, dt=torch.int32)      # overflow flag | tile-test replay stamp | deep tiles | list segments of the frame
-        # launch sizing of the two kernels whose grids follow the frame's content (omfs_raster_buffers.deep_launch / seg_launch):
-        # the counts the scan leaves in status[2:4] are read back asynchronously and the NEXT frames are launched a little above
-        # a decaying maximum of them -- no host sync, and a short estimate only costs time (the workgroups stride on)
-        self._status_host = torch.zeros(4, dtype=torch.int32).pin_memory() if self.device.type == "cuda" else None
-        self._status_event = None
-        self._hint_deep = self._hint_seg = 0.0
+        self.status = z(2, dt=torch.int32)      # word 0: overflow flag; word 1: the library's tile-test replay stamp
         self.seg_capacity = self.n_tiles + self.dup_capacity // L.SEG + 1
         self.seg_ckpt = z(self.seg_capacity, 256, 4)
         self.order_seg0 = z(self.n_tiles + 1, dt=torch.int32)
@@ -101,25 +95,6 @@ class Rasterizer:
 
     def bin_sort(self, model: GaussianModel, cam: L.CameraC):
         L.check(L.load().omfs_bin_sort(self._gauss(model), cam, self.rb, L.stream_ptr()), "omfs_bin_sort")
-        self.note_counts()
-
-    def note_counts(self) -> None:
-        """Call after omfs_bin_scan has been enqueued: takes the counts of an earlier frame whose read-back has landed, sizes
-        the coming launches from them and starts the next read-back.  Never waits."""
-        if self._status_host is None or torch.cuda.is_current_stream_capturing():
-            return
-        ev = self._status_event
-        if ev is not None and ev.query():
-            deep, segs = int(self._status_host[2]), int(self._status_host[3])
-            self._hint_deep = max(float(deep), 0.97 * self._hint_deep)
-            self._hint_seg = max(float(segs), 0.97 * self._hint_seg)
-            self.rb.deep_launch = min(self.n_tiles, int(1.25 * self._hint_deep) + 8)
-            self.rb.seg_launch = min(self.seg_capacity, int(1.15 * self._hint_seg) + 64)
-            self._status_event = ev = None
-        if ev is None:
-            self._status_host.copy_(self.status, non_blocking=True)
-            self._status_event = torch.cuda.Event()
-            self._status_event.record()
 
     def composite(self, cam: L.CameraC):
         L.check(L.load().omfs_composite_fwd(cam, self.rb, L.stream_ptr()), "omfs_composite_fwd")
@@ -172,7 +147,6 @@ class Rasterizer:
         rb = self.rb
         rb.keys, rb.keys_tmp, rb.sorted_ids = L.ptr(self.keys), L.ptr(self.keys_tmp), L.ptr(self.sorted_ids)
         rb.dup_capacity, rb.seg_ckpt, rb.seg_capacity = self.dup_capacity, L.ptr(self.seg_ckpt), self.seg_capacity
-        rb.seg_launch = rb.deep_launch = 0
         return self.dup_capacity
 
     # ------------------------------------------------------------------ backward

@@ -239,7 +239,7 @@ class Trainer:
             g = r._gauss(self.model)
             r.project(self.model, fxf, cam)
             L.check(lib.omfs_bin_count(g, cam, r.rb, s), "omfs_bin_count")
-            L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan")      # (launch sizes: as estimated when this was captured)
+            L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan")
             L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter")
             L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort")
             r.composite(cam)
@@ -408,7 +408,7 @@ class Trainer:
         g = r._gauss(self.model)
         s = L.stream_ptr()
         L.check(lib.omfs_bin_count(g, cam, r.rb, s), "omfs_bin_count"); tm.mark("bin_count")
-        L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); r.note_counts(); tm.mark("bin_scan")
+        L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); tm.mark("bin_scan")
         L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
         L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
         r.composite(cam); tm.mark("composite_fwd")
@@ -565,7 +565,7 @@ class Renderer:
         s = L.stream_ptr()
         r.project(self.model, fxf, cam); tm.mark("project")
         L.check(lib.omfs_bin_count(g, cam, r.rb, s), "omfs_bin_count"); tm.mark("bin_count")
-        L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); r.note_counts(); tm.mark("bin_scan")
+        L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); tm.mark("bin_scan")
         L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
         L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
         r.composite(cam); tm.mark("composite_fwd")

@@ -309,31 +309,29 @@ def test_scatter_recomputes_the_tile_test_when_the_recorded_ballots_are_not_its_
     assert torch.equal(rast.sorted_ids[:D], ids)
 
 
-def test_launch_sizes_follow_the_frame_and_a_short_estimate_loses_nothing():
-    """omfs_raster_buffers.deep_launch / seg_launch: the Rasterizer sizes the segment-parallel forward and the backward from
-    the counts the scan leaves in status[2:4] of earlier frames; with estimates forced far too small the workgroups stride
-    on and image and gradients equal the full-grid ones (up to the order of the backward's float atomics)."""
-    rig, g, seq, cam, dflame, model, rast, mk = _setup(30000, 96, 80)      # lists of thousands: deep tiles, many segments
+def test_scatter_recomputes_the_tile_test_when_the_recorded_ballots_are_not_its_own():
+    """omfs_bin_scatter replays the tile-test ballots omfs_bin_count left in keys_tmp only while they are its own (stamp in
+    status[1]); after omfs_tile_sort has used keys_tmp as scratch, or for another camera, it re-evaluates the test."""
+    from omfs_4d_video_gen_amd import _lib as L
+    rig, g, seq, cam, dflame, model, rast, mk = _setup(20000, 320, 256)
     _, face_xf = dflame.face_frames(1, 1)
-    ccam = mk(cam, bg=(0.1, 0.2, 0.3))
-    dimage = torch.randn(3, 80, 96, generator=torch.Generator().manual_seed(1)).cuda()
-    grads = [torch.zeros(59, model.n_pad, device="cuda") for _ in range(2)]
-    img_full = rast.forward(model, face_xf[0], ccam).clone()
-    rast.backward(model, face_xf[0], ccam, grads[0], dimage=dimage)
+    ccam = mk(cam)
+    rast.forward(model, face_xf[0], ccam)
     torch.cuda.synchronize()
-    st = rast.status.cpu().numpy()
-    lens = np.diff(rast.tile_start.cpu().numpy().astype(np.int64))
-    assert int(st[2]) == int((lens > 512).sum()) > 4 and int(st[3]) == int(((lens + 127) // 128).sum()) == int(rast.order_seg0[-1])
-    for _ in range(3):                       # the read-back lands after a frame or two: then the launches shrink
-        rast.forward(model, face_xf[0], ccam)
-        torch.cuda.synchronize()
-    assert 0 < rast.rb.deep_launch <= rast.n_tiles and int(st[2]) <= rast.rb.deep_launch
-    assert 0 < rast.rb.seg_launch < rast.seg_capacity and int(st[3]) <= rast.rb.seg_launch
-    rast._status_host = None                 # freeze the estimates, far too small
-    rast.rb.deep_launch, rast.rb.seg_launch = 2, 3
-    img_small = rast.forward(model, face_xf[0], ccam)
-    rast.backward(model, face_xf[0], ccam, grads[1], dimage=dimage)
+    D = int(rast.tile_start[-1])
+    ids, keys = rast.sorted_ids[:D].clone(), rast.keys[:D].clone()
+    assert int(rast.status[1]) == 0                      # the sort has released keys_tmp
+    lib, s, gs = L.load(), L.stream_ptr(), rast._gauss(model)
+    rast.keys.zero_(); rast.sorted_ids.zero_(); rast.tile_cursor.zero_()
+    L.check(lib.omfs_bin_scatter(gs, ccam, rast.rb, s), "omfs_bin_scatter")      # no count in front: nothing to replay
+    L.check(lib.omfs_tile_sort(ccam, rast.rb, s), "omfs_tile_sort")
     torch.cuda.synchronize()
-    assert torch.equal(img_small, img_full)
-    d = (grads[0] - grads[1]).abs()
-    assert float(d.max()) <= 1e-4 * float(grads[0].abs().max()) + 1e-9
+    assert torch.equal(rast.sorted_ids[:D], ids)
+    # a count for ANOTHER camera leaves ballots that are not this scatter's either
+    other = mk(synthetic.make_camera(320, 256, yaw=-0.5))
+    L.check(lib.omfs_bin_count(gs, other, rast.rb, s), "omfs_bin_count")
+    rast.tile_count.zero_(); rast.keys.zero_(); rast.sorted_ids.zero_(); rast.tile_cursor.zero_()
+    L.check(lib.omfs_bin_scatter(gs, ccam, rast.rb, s), "omfs_bin_scatter")
+    L.check(lib.omfs_tile_sort(ccam, rast.rb, s), "omfs_tile_sort")
+    torch.cuda.synchronize()
+    assert torch.equal(rast.sorted_ids[:D], ids)
