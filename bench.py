@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no_aux", action="store_true")
     ap.add_argument("--profile_steps", type=int, default=40)
     ap.add_argument("--frozen_flame", action="store_true", help="headline step with a fixed FLAME sequence (--not_finetune_flame_params)")
-    ap.add_argument("--input_order", action="store_true", help="keep the cloud in its input order (binding i mod F) instead of the surface-coherent storage order")
+    ap.add_argument("--coherent_order", action="store_true", help="store the cloud along a Morton curve over its parent triangles instead of the input order (binding i mod F)")
     return ap.parse_args()
 
 
@@ -218,7 +218,7 @@ def main():
     # FLAME parameters are optimised with the Gaussians, so FLAME LBS + triangle frames are posed INSIDE the timed step
     trainer = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3,
                       rank=rank, world_size=world, process_group=pg, finetune_flame=not args.frozen_flame,
-                      coherent_order=not args.input_order)
+                      coherent_order=args.coherent_order)
 
     def barrier():
         if world > 1:
@@ -332,7 +332,7 @@ def main():
 
     # ---- aux: render_surgery fps on the same scene (frames shard across ranks, no collective)
     if not args.no_aux:
-        rr = Renderer(rig, seq, g_init, W, H, coherent_order=not args.input_order)
+        rr = Renderer(rig, seq, g_init, W, H, coherent_order=args.coherent_order)
         frames = [View(cams[i % len(cams)], timestep=i % T) for i in range(rank, args.render_frames, world)]
         for v in frames[:5]:
             rr.render(v, rgb8=True)
@@ -390,7 +390,7 @@ def main():
             # triangle frames resident) -- not the headline
             del rr
             tf = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3, finetune_flame=args.frozen_flame,
-                         coherent_order=not args.input_order)
+                         coherent_order=args.coherent_order)
             for _ in range(20 + (2 * len(views) + 2 if tf.use_graph else 0)):
                 tf.step()
             torch.cuda.synchronize()
@@ -402,6 +402,27 @@ def main():
             out["aux"][key] = round(100 / (time.perf_counter() - t4), 2)
             del tf
             log("flame switch aux done")
+            # BASELINE config 1's size (5k Gaussians, 256x256, one view) on the GPU: device time per iteration is far below the
+            # host's enqueue time, so this is where replaying the captured iteration (hipGraph) shows
+            small = {}
+            cam_s = synthetic.make_camera(256, 256, 0.0)
+            g_s, g_t = synthetic.make_gaussians(5000, F, 0), synthetic.make_gaussians(5000, F, 1)
+            v_s = View(cam_s, 1)
+            v_s.target = Renderer(rig, seq, g_t, 256, 256).render(v_s).clone()
+            for mode in ("eager", "graph"):
+                ts = Trainer(rig, seq, g_s, [v_s], 256, 256, iterations=30000, start_sh_degree=3, finetune_flame=not args.frozen_flame)
+                ts.use_graph = mode == "graph"
+                for _ in range(30):
+                    ts.step()
+                torch.cuda.synchronize()
+                t7 = time.perf_counter()
+                for _ in range(500):
+                    ts.step()
+                torch.cuda.synchronize()
+                small[mode] = round(500 / (time.perf_counter() - t7), 1)
+                del ts
+            out["aux"]["config1_5k_256_iters_per_sec"] = small
+            log("small-config aux done")
             # flame_fitter.fit_flame_to_landmarks (reference flame_fitter.py:294-444) on 300 frames of synthetic landmarks:
             # HIP SimpleFLAME forward/backward vs the PyTorch-CPU port of the reference's loop (oracle/simple_flame.py)
             import contextlib

@@ -97,7 +97,7 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     (out_dir / "renders").mkdir(parents=True, exist_ok=True)
     (out_dir / "gt").mkdir(parents=True, exist_ok=True)
     flame = tuned_flame(Path(args.model_path) / "point_cloud" / f"iteration_{it}", split["flame"])
-    r = Renderer(load_rig(), flame, g, w, h, bg=bg, sh_degree=args.sh_degree, coherent_order=True)
+    r = Renderer(load_rig(), flame, g, w, h, bg=bg, sh_degree=args.sh_degree)
     pool = ThreadPoolExecutor(max_workers=max(1, args.png_workers))
     pending = []
     mine = range(rank, len(cams), world)

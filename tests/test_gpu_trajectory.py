@@ -166,3 +166,42 @@ def test_graph_replay_of_whole_iterations_matches_eager_steps(finetune):
     # the position learning rate the graph used at the last iteration is the eager schedule's
     from omfs_4d_video_gen_amd.engine.trainer import expon_lr
     assert abs(float(st.view(torch.float32)[2]) - expon_lr(steps - 1, 5e-3, 5e-5, 300)) < 1e-9 + 1e-6 * 5e-3
+
+
+def test_coherent_storage_order_trains_the_same_cloud():
+    """Trainer(coherent_order=True) lays the cloud out along a Morton curve over its parent triangles: the same training
+    (losses up to float-atomic noise), and `model.to_dict()` hands the cloud back in the order it was given in."""
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, Trainer, View
+    n, Wd, Hd = 6000, 160, 120
+    srig = synthetic.make_rig(0)
+    rig = FlameRig.from_synthetic(srig)
+    seq = synthetic.make_flame_sequence(4, 0)
+    cams = synthetic.make_camera_arc(Wd, Hd, 4)
+    g0, g1 = synthetic.make_gaussians(n, rig.n_faces, 0), synthetic.make_gaussians(n, rig.n_faces, 1)
+    rr = Renderer(rig, seq, g1, Wd, Hd, coherent_order=True)
+    ra = Renderer(rig, seq, g1, Wd, Hd)
+    views = []
+    for i, c in enumerate(cams):
+        v = View(c, timestep=i)
+        v.target = rr.render(v).clone()
+        assert float((v.target - ra.render(v)).abs().max()) < 2e-3          # the same picture from either layout
+        views.append(v)
+    out = {}
+    for coherent in (False, True):
+        tr = Trainer(rig, seq, g0, views, Wd, Hd, iterations=300, start_sh_degree=3, coherent_order=coherent)
+        losses = []
+        for _ in range(24):
+            tr.step()
+            losses.append(tr.loss_value())
+        torch.cuda.synchronize()
+        out[coherent] = (np.array(losses), tr.model.to_dict(), tr.model)
+    la, da, _ = out[False]
+    lb, db, mb = out[True]
+    assert mb.order is not None and not np.array_equal(mb.order, np.arange(n))
+    assert np.array_equal(da["binding"], g0["binding"]) and np.array_equal(db["binding"], g0["binding"])
+    assert np.unique(mb.binding.cpu().numpy()[:512]).size < 64              # 512 stored neighbours share a few triangles
+    assert np.abs(la - lb).max() < 2e-3 * la.max()
+    for k in ("xyz", "log_scale", "opacity", "sh"):
+        d = np.abs(da[k] - db[k])
+        assert d.mean() <= 3e-4 * max(1.0, np.abs(da[k]).max()), k
