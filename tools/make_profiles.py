@@ -19,6 +19,7 @@ with open(os.path.join(pr, f"{tag}_kernel_stats.csv"), "w") as f:
 for src, dst in ((f"bench_{suf}.json", f"{tag}_bench_default.json"), (f"bench_prof_{suf}.json", f"{tag}_bench_under_rocprof.json")):
     line = open(os.path.join(go, src)).read().strip().splitlines()[-1]
     open(os.path.join(pr, dst), "w").write(line + "\n")
+os.environ["OMFS_PROFILE_TAG"] = tag
 subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), os.path.join(go, f"pmc_fetch_{suf}", "pmc_results.db"),
                 os.path.join(go, f"pmc_write_{suf}", "pmc_results.db"), "1920x1080x300000", os.path.join(pr, "traffic.json")], check=True,
                stdout=subprocess.DEVNULL)

@@ -24,6 +24,7 @@ STAGES = {
     "project_bwd": ["project_bwd_kernel", "count_visible_kernel"],
     "adam": ["adam_kernel"],
     "flame": ["flame_joints_kernel", "flame_lbs_kernel", "face_frames_kernel"],
+    "flame_bwd": ["face_frames_bwd_kernel", "flame_skin_bwd_kernel", "basis_t_gemv_kernel", "adam_flat_multi_kernel"],
 }
 
 
@@ -46,10 +47,11 @@ def main():
     res["_note"] = ("HBM bytes per launch from rocprofv3 --pmc (separate FETCH_SIZE and WRITE_SIZE passes, tools/run_scene.py "
                     "--train, averaged over the last %d launches): 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; the x2 on FETCH_SIZE is "
                     "the gfx950 correction of MI355X_MICROARCH.md. Stages sum their kernels (tools/pmc_traffic.py)." % last)
+    res["_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `tools/run_scene.py --train --finetune` (eager launches), profile " + os.environ.get("OMFS_PROFILE_TAG", "?")
     json.dump(res, open(out, "w"), indent=1)
     json.dump(raw, open(out.replace(".json", "_raw.json"), "w"), indent=1)
     for k, v in res.items():
-        if k != "_note":
+        if not k.startswith("_"):
             print(k, v)
 
 
