@@ -326,6 +326,27 @@ int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v,
 int omfs_adam_step_range(float* params, const float* grads, float* m, float* v, int n_pad, long long offset, long long count,
                          const omfs_adam_params* ap, void* stream);
 
+/* One training view from the projection to the parameter gradients in ONE call: omfs_project_fwd, the four binning
+ * steps, omfs_composite_fwd, [omfs_rgb8_to_image when the target is 8-bit], omfs_loss_l1_ssim, omfs_composite_bwd,
+ * omfs_project_bwd, enqueued in this order on `stream` exactly as the separate calls would be.  For hosts whose per-call
+ * cost matters (a Python host pays ~10 us per ctypes call: at 5k Gaussians / 256x256 the device needs less per iteration
+ * than twelve such calls take). */
+typedef struct omfs_view_step {
+  const omfs_gaussians* g;
+  const float* face_xf;
+  const omfs_camera* cam;
+  const omfs_raster_buffers* rb;
+  const omfs_grad_buffers* gb;
+  const omfs_reg_params* reg;
+  const float* target;         /* [3][H][W] fp32, or NULL when target_rgb8 is given                                     */
+  const uint8_t* target_rgb8;  /* [H][W][3]; expanded into target_scratch [3][H][W] first                                */
+  float* target_scratch;
+  float lambda_dssim;
+  float* loss_out;             /* [1]                                                                                    */
+  float* loss_scratch;         /* 3 * 3*H*W floats                                                                       */
+} omfs_view_step;
+int omfs_view_forward_backward(const omfs_view_step* v, void* stream);
+
 /* ---- device-resident per-iteration scalars.  With them nothing about a training iteration is a kernel ARGUMENT any more
  * (the learning-rate schedule and Adam's bias corrections were the last ones), so a whole iteration can be captured in a
  * hipGraph once per view and replayed.  omfs_step_advance (one thread) increments both step counters and derives, in double

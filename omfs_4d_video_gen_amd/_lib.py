@@ -80,6 +80,12 @@ class AdamParamsC(C.Structure):
                 ("step", C.c_int), ("grad_scale", C.c_float)]
 
 
+class ViewStepC(C.Structure):
+    _fields_ = [("g", C.POINTER(GaussiansC)), ("face_xf", c_void_p), ("cam", C.POINTER(CameraC)), ("rb", C.POINTER(RasterBuffersC)),
+                ("gb", C.POINTER(GradBuffersC)), ("reg", C.POINTER(RegParamsC)), ("target", c_void_p), ("target_rgb8", c_void_p),
+                ("target_scratch", c_void_p), ("lambda_dssim", C.c_float), ("loss_out", c_void_p), ("loss_scratch", c_void_p)]
+
+
 class LrScheduleC(C.Structure):
     _fields_ = [("lr_init", C.c_float), ("lr_final", C.c_float), ("max_steps", C.c_int), ("beta1", C.c_float), ("beta2", C.c_float)]
 
@@ -111,6 +117,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p]),
     "omfs_adam_step_range": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_longlong, C.c_longlong,
                                        C.POINTER(AdamParamsC), c_void_p]),
+    "omfs_view_forward_backward": (C.c_int, [C.POINTER(ViewStepC), c_void_p]),
     "omfs_step_advance": (C.c_int, [c_void_p, C.POINTER(LrScheduleC), c_void_p, C.c_int, c_void_p, c_void_p]),
     "omfs_adam_step_dev": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), c_void_p,
                                      C.c_int, C.c_int, c_void_p]),

@@ -16,3 +16,24 @@ int set_error(int code, const char* fmt, ...) {
 
 extern "C" int omfs_abi_version(void) { return OMFS_ABI_VERSION; }
 extern "C" const char* omfs_last_error(void) { return omfs::g_last_error; }
+
+// One training view in one call (see the header): the separate entry points in their order, stopping at the first error.
+extern "C" int omfs_view_forward_backward(const omfs_view_step* v, void* stream) {
+  if (!v || !v->g || !v->face_xf || !v->cam || !v->rb || !v->gb || !v->reg || !(v->target || (v->target_rgb8 && v->target_scratch)) ||
+      !v->loss_out || !v->loss_scratch)
+    return omfs::set_error(OMFS_ERR_ARG, "omfs_view_forward_backward: null pointer");
+  int rc;
+  if ((rc = omfs_project_fwd(v->g, v->face_xf, v->cam, v->rb, stream))) return rc;
+  if ((rc = omfs_bin_sort(v->g, v->cam, v->rb, stream))) return rc;
+  if ((rc = omfs_composite_fwd(v->cam, v->rb, stream))) return rc;
+  const float* target = v->target;
+  if (!target) {
+    if ((rc = omfs_rgb8_to_image(v->target_rgb8, v->cam->width, v->cam->height, v->target_scratch, stream))) return rc;
+    target = v->target_scratch;
+  }
+  if ((rc = omfs_loss_l1_ssim(v->rb->image, target, v->cam->width, v->cam->height, v->lambda_dssim, const_cast<float*>(v->gb->dimage),
+                              v->loss_out, v->loss_scratch, stream)))
+    return rc;
+  if ((rc = omfs_composite_bwd(v->cam, v->rb, v->gb, stream))) return rc;
+  return omfs_project_bwd(v->g, v->face_xf, v->cam, v->rb, v->gb, v->reg, stream);
+}

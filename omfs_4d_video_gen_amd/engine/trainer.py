@@ -123,6 +123,7 @@ class Trainer:
         # all-gather of the updated parameters (the Adam moments of the other shards are not maintained on this rank)
         self.sharded_dp = self.dp and mode == "sharded"
         self._dp_patterns = {}
+        self._view_steps = {}
         self._gshard = None
         self.drgb_local = self.drgb_scratch = self.drgb_all = self.cam_pos_table = None
         if self.compact_dp:
@@ -131,7 +132,7 @@ class Trainer:
         self._side_stream = torch.cuda.Stream(device=self.device)
         # whole iterations as hipGraphs (one per view and buffer parity; single GPU): the step-dependent scalars -- position
         # learning rate, Adam bias corrections -- live in an omfs_step_state on the device, advanced by the graph's first node
-        self.use_graph = world_size == 1 and os.environ.get("OMFS_STEP_GRAPH", "1") != "0"
+        self.use_graph = world_size == 1 and os.environ.get("OMFS_STEP_GRAPH", "0") == "1"
         self._graphs, self._graph_seen = {}, set()
         self._state = torch.zeros(L.STEP_STATE_WORDS, dtype=torch.int32, device=self.device)
         self._state_step, self._frames_ready = -1, None
@@ -195,6 +196,29 @@ class Trainer:
             pat = (ts, vs, ts.to(torch.int64))
             self._dp_patterns[ids] = pat
         return pat
+
+    def _view_step(self, view: View, cam, fxf: torch.Tensor, g, ft):
+        """omfs_view_step of this view (cached with everything it points at: the structs must outlive the call)."""
+        target = view.target
+        key = (id(view), id(cam), fxf.data_ptr(), g.n, g.params, L.ptr(self.densify_stats), L.ptr(ft.dface) if ft is not None else 0,
+               target.data_ptr(), self.lambda_dssim, tuple(self.reg), self.rast.rb.keys, self.rast.rb.dup_capacity)
+        hit = self._view_steps.get(key)
+        if hit is None:
+            if len(self._view_steps) > 8 * max(len(self.views), 1):
+                self._view_steps.clear()
+            r = self.rast
+            gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
+                                L.ptr(ft.dface) if ft is not None else 0, 0)
+            rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
+            u8 = target.dtype == torch.uint8
+            if u8 and self._target_f32 is None:
+                self._target_f32 = torch.empty(3, r.height, r.width, device=self.device)
+            import ctypes as C
+            vs = L.ViewStepC(C.pointer(g), L.ptr(fxf), C.pointer(cam), C.pointer(r.rb), C.pointer(gb), C.pointer(rp),
+                             0 if u8 else L.ptr(target), L.ptr(target) if u8 else 0, L.ptr(self._target_f32) if u8 else 0,
+                             float(self.lambda_dssim), L.ptr(r.loss), L.ptr(r.loss_scratch))
+            hit = self._view_steps[key] = (vs, g, gb, rp, cam, fxf)
+        return hit[0]
 
     def view_for_step(self, step: int) -> View:
         from .distributed import view_index
@@ -403,36 +427,42 @@ class Trainer:
             self.dflame.slot = slot
         tm.mark("flame")
         fxf = face_xf[col]
-        r.project(self.model, fxf, cam); tm.mark("project")
-        lib = L.load()
-        g = r._gauss(self.model)
-        s = L.stream_ptr()
-        L.check(lib.omfs_bin_count(g, cam, r.rb, s), "omfs_bin_count"); tm.mark("bin_count")
-        L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); tm.mark("bin_scan")
-        L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
-        L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
-        r.composite(cam); tm.mark("composite_fwd")
-        target = view.target
-        if target.dtype == torch.uint8:        # 8-bit [H][W][3] targets (large datasets): expanded per view on the device
-            if self._target_f32 is None:
-                self._target_f32 = torch.empty(3, r.height, r.width, device=self.device)
-            L.check(lib.omfs_rgb8_to_image(L.ptr(target), r.width, r.height, L.ptr(self._target_f32), s), "omfs_rgb8_to_image")
-            target = self._target_f32
-        r.loss_l1_ssim(target, self.lambda_dssim); tm.mark("loss")
-        if self.compact_dp and (self.drgb_local is None or self.drgb_local.shape[1] != self.model.n_pad):
-            self.drgb_local = torch.zeros(3, self.model.n_pad, device=self.device)
-            self.drgb_scratch = torch.zeros(3, self.model.n_pad, device=self.device)
-            self.drgb_all = torch.zeros(self.world, 3, self.model.n_pad, device=self.device)
-        gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
-                            L.ptr(ft.dface) if ft is not None else 0, L.ptr(self.drgb_scratch) if self.compact_dp else 0)
-        L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")
         gather = None
-        if self.compact_dp:            # dL/dcolour is final here: its all-gather runs under project_bwd
-            from .distributed import allgather_into_
-            L.check(lib.omfs_extract_drgb(r.rb, L.ptr(r.dsplat), self.model.n, self.model.n_pad, L.ptr(self.drgb_local), s), "omfs_extract_drgb")
-            gather = allgather_into_(self.drgb_all, self.drgb_local, self.pg, async_op=True)
-        rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
-        L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
+        if not tm.enabled and not self.dp:
+            # one C-ABI call for the whole view (projection ... parameter gradients): a Python host pays ~10 us per ctypes call
+            lib, s, g = L.load(), L.stream_ptr(), r._gauss(self.model)
+            L.check(lib.omfs_view_forward_backward(self._view_step(view, cam, fxf, g, ft), s), "omfs_view_forward_backward")
+        else:
+            r.project(self.model, fxf, cam); tm.mark("project")
+            lib = L.load()
+            g = r._gauss(self.model)
+            s = L.stream_ptr()
+            L.check(lib.omfs_bin_count(g, cam, r.rb, s), "omfs_bin_count"); tm.mark("bin_count")
+            L.check(lib.omfs_bin_scan(cam, r.rb, s), "omfs_bin_scan"); tm.mark("bin_scan")
+            L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
+            L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
+            r.composite(cam); tm.mark("composite_fwd")
+            target = view.target
+            if target.dtype == torch.uint8:        # 8-bit [H][W][3] targets (large datasets): expanded per view on the device
+                if self._target_f32 is None:
+                    self._target_f32 = torch.empty(3, r.height, r.width, device=self.device)
+                L.check(lib.omfs_rgb8_to_image(L.ptr(target), r.width, r.height, L.ptr(self._target_f32), s), "omfs_rgb8_to_image")
+                target = self._target_f32
+            r.loss_l1_ssim(target, self.lambda_dssim); tm.mark("loss")
+            if self.compact_dp and (self.drgb_local is None or self.drgb_local.shape[1] != self.model.n_pad):
+                self.drgb_local = torch.zeros(3, self.model.n_pad, device=self.device)
+                self.drgb_scratch = torch.zeros(3, self.model.n_pad, device=self.device)
+                self.drgb_all = torch.zeros(self.world, 3, self.model.n_pad, device=self.device)
+            gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
+                                L.ptr(ft.dface) if ft is not None else 0, L.ptr(self.drgb_scratch) if self.compact_dp else 0)
+            L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")
+            gather = None
+            if self.compact_dp:            # dL/dcolour is final here: its all-gather runs under project_bwd
+                from .distributed import allgather_into_
+                L.check(lib.omfs_extract_drgb(r.rb, L.ptr(r.dsplat), self.model.n, self.model.n_pad, L.ptr(self.drgb_local), s), "omfs_extract_drgb")
+                gather = allgather_into_(self.drgb_all, self.drgb_local, self.pg, async_op=True)
+            rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
+            L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
         if ft_pipe:
             # The three gathers of the FLAME backward stay on this stream: beside the bandwidth-bound Adam pass they run 3-5x
             # slower (measured: 34 + 28 + 50 us instead of 12 + 8 + 15), which made the chain longer than the pass it

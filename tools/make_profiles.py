@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Turn the merged gpurun_out/ results of a profiling call into the tracked files under profiles/:
   make_profiles.py <tag> <suffix>      e.g.  make_profiles.py r01_h h
+make_profiles.py <tag> <suffix> <out_dir> on the GPU box itself (then only the summaries are merged back).
 reads gpurun_out/{bench_<s>.json, bench_prof_<s>.json, prof_<s>/, pmc_fetch_<s>/, pmc_write_<s>/, pmc_inst_<s>/, pmc_busy_<s>/}."""
 import json
 import os
@@ -13,7 +14,8 @@ from pmc_summary import summarise  # noqa: E402
 
 tag, suf = sys.argv[1], sys.argv[2]
 go = os.path.join(ROOT, "gpurun_out")
-pr = os.path.join(ROOT, "profiles")
+pr = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")     # on the GPU box: a directory under gpurun_out/ (the
+os.makedirs(pr, exist_ok=True)                                               # databases themselves are too big to travel back)
 with open(os.path.join(pr, f"{tag}_kernel_stats.csv"), "w") as f:
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_stats.py"), os.path.join(go, f"prof_{suf}", "prof_results.db")], stdout=f, check=True)
 for src, dst in ((f"bench_{suf}.json", f"{tag}_bench_default.json"), (f"bench_prof_{suf}.json", f"{tag}_bench_under_rocprof.json")):

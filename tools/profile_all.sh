@@ -6,13 +6,13 @@ S=$1
 # a failing pass does not abort the others
 PY=$(python -c 'import sys; print(sys.executable)')
 export TMPDIR=/tmp
-# the PMC passes look at single kernels: eager launches (a replayed graph profiles the same kernels, less conveniently)
+# the traced run leaves the aux workloads out (--no_aux): every launch of a kernel then belongs to the headline workload and
+# the per-kernel averages of the trace are comparable with the stage times bench.py measures itself
 R=$PWD
 "$PY" bench.py > gpurun_out/bench_$S.json 2> gpurun_out/bench_$S.err
 tail -1 gpurun_out/bench_$S.json | cut -c1-160
 cd /tmp
-export OMFS_STEP_GRAPH=0
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$S -o prof -- "$PY" $R/bench.py --no_cpu_baseline > $R/gpurun_out/bench_prof_$S.json 2> $R/gpurun_out/bench_prof_$S.err
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$S -o prof -- "$PY" $R/bench.py --no_cpu_baseline --no_aux > $R/gpurun_out/bench_prof_$S.json 2> $R/gpurun_out/bench_prof_$S.err
 echo trace done
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch_$S -o pmc -- "$PY" $R/tools/run_scene.py --train --finetune --pretrain 20 --iters 16 > $R/gpurun_out/pmc_fetch_$S.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write_$S -o pmc -- "$PY" $R/tools/run_scene.py --train --finetune --pretrain 20 --iters 16 > $R/gpurun_out/pmc_write_$S.log 2>&1
