@@ -93,9 +93,27 @@ struct DbgSpan {
 };
 #define OMFS_DBG_SPAN(k) DbgSpan omfs_dbg_span_(k, blockIdx.x)
 #define OMFS_DBG_WORK() (++omfs_dbg_span_.work)
+// composite_fwd only: shader-clock cycles per phase (0 waiting for the gather, 1 staging, 2 walking, 3 everything else)
+__device__ uint32_t omfs_dbg_phase[4][OMFS_DBG_TL];
+struct DbgPhase {
+  unsigned long long t; uint32_t acc[4];
+  __device__ DbgPhase() : t(__builtin_readcyclecounter()), acc{0u, 0u, 0u, 0u} {}
+  __device__ void mark(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += (uint32_t)(n - t); t = n; }
+  __device__ ~DbgPhase() {
+    mark(3);
+    if (threadIdx.x == 0 && blockIdx.x < (uint32_t)OMFS_DBG_TL)
+      for (int i = 0; i < 4; ++i) omfs_dbg_phase[i][blockIdx.x] = acc[i];
+  }
+};
+#define OMFS_DBG_PHASES() DbgPhase omfs_dbg_phase_
+#define OMFS_DBG_PHASE(i) omfs_dbg_phase_.mark(i)
+#define OMFS_DBG_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define OMFS_DBG_SPAN(k) do { } while (0)
 #define OMFS_DBG_WORK() do { } while (0)
+#define OMFS_DBG_PHASES() do { } while (0)
+#define OMFS_DBG_PHASE(i) do { } while (0)
+#define OMFS_DBG_WAIT_VM() do { } while (0)
 #endif
 constexpr int WB = 64;   // splats staged per wave and step
 #ifndef OMFS_FWD_SEQ_SEGS
@@ -133,6 +151,7 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
   __shared__ float4 s1[WB + 1];
   __shared__ float4 s2[WB + 1];   // .x = blue (one address register serves the three reads of an entry)
   OMFS_DBG_SPAN(0);
+  OMFS_DBG_PHASES();
   const uint32_t tile = tile_order[blockIdx.x >> 2];
   const int quad = blockIdx.x & 3, lane = threadIdx.x;
   const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
@@ -170,6 +189,9 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
     // ---- stage this step's 64 entries
     const uint32_t k = b + lane;
     uint32_t mask = 0;
+    OMFS_DBG_PHASE(3);
+    OMFS_DBG_WAIT_VM();
+    OMFS_DBG_PHASE(0);
     __builtin_amdgcn_wave_barrier();
     if (k < end) {
       const float A = r0.z, B = r0.w, C = r1.x;
@@ -198,6 +220,7 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
     };
     unsigned long long m = combine(live);
     const uint32_t base = b - beg;
+    OMFS_DBG_PHASE(1);
     // Four entries per iteration, no branch inside: the bit scans are scalar, the twelve LDS reads of a batch are issued
     // together, and the four alpha evaluations are independent of each other -- only the short T / stop chain is serial.
     // A wave that runs alone on its SIMD (the silhouette quadrants every launch ends on) is bound by dependent-issue
@@ -246,6 +269,7 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
       }
     }
     live = __ballot(!done);
+    OMFS_DBG_PHASE(2);
   }
   if (deep) {
     // hand-over: the state at boundary FWD_SEQ_SEGS and, in the tile's unused boundary-0 slot, the live mask
@@ -838,6 +862,11 @@ extern "C" int omfs_debug_timeline(int kernel, unsigned long long* out, int n, i
   for (int e = 0; e < 2; ++e)
     OMFS_CHECK_HIP(hipMemcpyFromSymbol(out + (size_t)e * n, HIP_SYMBOL(omfs_dbg_tl), (size_t)n * 8,
                                        ((size_t)kernel * 2 + e) * OMFS_DBG_TL * 8));
+  if (out && n > 0 && reset == 3) {      // reset == 3: out [4][n/2] (as uint32 [4][n]) = the phase cycles of composite_fwd
+    for (int i = 0; i < 4; ++i)
+      OMFS_CHECK_HIP(hipMemcpyFromSymbol((uint32_t*)out + (size_t)i * n, HIP_SYMBOL(omfs_dbg_phase), (size_t)n * 4, (size_t)i * OMFS_DBG_TL * 4));
+    return OMFS_OK;
+  }
   if (out && n > 0 && reset >= 2) {      // reset == 2: out [n] also receives the work counters after the two time rows
     OMFS_CHECK_HIP(hipMemcpyFromSymbol(out + (size_t)2 * n, HIP_SYMBOL(omfs_dbg_work), (size_t)n * 4, (size_t)kernel * OMFS_DBG_TL * 4));
     return OMFS_OK;

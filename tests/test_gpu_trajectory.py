@@ -202,7 +202,8 @@ def test_coherent_storage_order_trains_the_same_cloud():
     assert np.array_equal(da["binding"], g0["binding"]) and np.array_equal(db["binding"], g0["binding"])
     centres = srig.v_template[srig.faces].mean(1)
     hop = lambda b: np.linalg.norm(np.diff(centres[b], axis=0), axis=1).mean()     # mean distance between stored neighbours' triangles
-    assert hop(mb.binding.cpu().numpy()) < 0.3 * hop(g0["binding"])
+    # (the synthetic mesh numbers its faces row by row, so the caller's order is coherent already: the bar is a shuffled cloud)
+    assert hop(mb.binding.cpu().numpy()) < 0.3 * hop(np.random.default_rng(0).permutation(g0["binding"]))
     assert np.abs(la - lb).max() < 2e-3 * la.max()
     for k in ("xyz", "log_scale", "opacity", "sh"):
         d = np.abs(da[k] - db[k])

@@ -54,3 +54,18 @@ for k, name, waves_per in ((0, "composite_fwd (one wave per entry)", 1), (1, "co
         fit = np.polyfit(w[big], dur[big], 1)
         print(f"   longest 1 %: {int(big.sum())} waves, splats visited p50 {np.percentile(w[big], 50):.0f} max {w[big].max()}, "
               f"duration = {fit[0] * 1e3:.0f} ns per visited splat + {fit[1]:.1f} us")
+    if k == 0:
+        # phase split of the one-wave forward (shader-clock cycles): waiting for the gather, staging, walking, the rest
+        pbuf = (ctypes.c_uint32 * (4 * NTL))()
+        assert cd.omfs_debug_timeline(0, ctypes.cast(pbuf, ctypes.POINTER(ctypes.c_ulonglong)), NTL, 3) == 0
+        ph = np.frombuffer(pbuf, dtype=np.uint32).reshape(4, NTL).astype(np.float64)[:, ok]
+        tot = ph.sum(0)
+        mhz = np.median(tot[dur > 20] / dur[dur > 20]) if (dur > 20).any() else float("nan")
+        print(f"   shader clock against the real-time counter: {mhz:.0f} cycles per us")
+        for name_, sel in (("all waves", np.ones(big.shape, bool)), ("longest 1 %", big), ("start in the first tenth", t0 < edges[1])):
+            q = ph[:, sel].sum(1)
+            print(f"   {name_:24s}: wait for gather {q[0] / q.sum():.2f}  stage {q[1] / q.sum():.2f}  walk {q[2] / q.sum():.2f}  other {q[3] / q.sum():.2f}"
+                  f"   (mean {ph[:, sel].sum(0).mean() / mhz:.1f} us per wave)")
+        lw = ph[:, big]
+        print(f"   longest 1 %: per visited splat {np.median(lw[2] / np.maximum(w[big], 1)):.0f} walk cycles; per 64-entry step "
+              f"{np.median(lw[1] / np.maximum(np.ceil(w[big] / 50.0), 1)):.0f} staging cycles (assuming ~50 visits per step)")
