@@ -1,11 +1,14 @@
 #!/usr/bin/env bash
 # Builds libomfs_splat.so for gfx950 in-tree (cross-compiles without a GPU).
 # -ffp-contract=off: FMAs are written explicitly so the geometric stage is bit-exact vs oracle/.
+# -fno-slp-vectorize: the SLP pass pairs scalar fp32 operations into v_pk_* and pays for every pair with register moves to make
+#   its operands adjacent -- the one-wave forward carried 22 v_mov per 4 list entries for 18 packed operations (measured: composite
+#   forward 0.233 -> 0.213 ms, loss, binning and the FLAME backward a few us each; same bits either way).
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libomfs_splat.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
 objs=()
 for src in flame project binning composite project_bwd loss_adam simple_flame densify; do
   "$HIPCC" $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$here/$src.hip" -o "$here/$src.o" &

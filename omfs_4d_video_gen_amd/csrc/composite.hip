@@ -107,12 +107,18 @@ struct DbgPhase {
 };
 #define OMFS_DBG_PHASES() DbgPhase omfs_dbg_phase_
 #define OMFS_DBG_PHASE(i) omfs_dbg_phase_.mark(i)
+// composite_fwd only: at the end of 64-entry step s (s < 8), 10 ns ticks since the wave started and entries walked so far
+__device__ uint32_t omfs_dbg_step[2][8][OMFS_DBG_TL];
+#define OMFS_DBG_STEP(s) do { if (threadIdx.x == 0 && blockIdx.x < (uint32_t)OMFS_DBG_TL && (s) < 8u) { \
+    omfs_dbg_step[0][s][blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - omfs_dbg_span_.t0); \
+    omfs_dbg_step[1][s][blockIdx.x] = omfs_dbg_span_.work; } } while (0)
 #define OMFS_DBG_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #else
 #define OMFS_DBG_SPAN(k) do { } while (0)
 #define OMFS_DBG_WORK() do { } while (0)
 #define OMFS_DBG_PHASES() do { } while (0)
 #define OMFS_DBG_PHASE(i) do { } while (0)
+#define OMFS_DBG_STEP(s) do { } while (0)
 #define OMFS_DBG_WAIT_VM() do { } while (0)
 #endif
 constexpr int WB = 64;   // splats staged per wave and step
@@ -124,6 +130,17 @@ constexpr int WB = 64;   // splats staged per wave and step
 #endif
 constexpr int FWD_SEQ_SEGS = OMFS_FWD_SEQ_SEGS;   // list segments the one-wave forward walks before handing over
 constexpr int DEEP_WAVES = OMFS_DEEP_WAVES;       // segments evaluated in parallel per deep quadrant
+
+// Lowest set bit of a wave-uniform 64-bit mask: returns its index + 1 (0 for an empty mask) and clears it.  Two scalar
+// instructions (s_ff1_i32_b64 yields -1 for an empty mask, s_bitset0_b64 then clears bit 63 of a mask that is already 0)
+// where `ffsll(m); m &= m - 1` compiles to seven: the scalar unit retires one instruction per ~4 cycles and SIMD
+// (tools/micro/valu_rate.hip), so the bit scans of the visit loops are not free.
+__device__ __forceinline__ int pop_lowest_bit(unsigned long long& m) {
+  int i;
+  asm("s_ff1_i32_b64 %0, %1" : "=s"(i) : "s"(m));
+  asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(i));
+  return i + 1;
+}
 
 // Forward.  One 64-lane workgroup (= one wave) per (tile, 8x8 quadrant); lane l owns pixel (l&7, l>>3) of
 // the quadrant.  No workgroup barrier exists: a wave whose pixels have all saturated simply exits and
@@ -159,6 +176,7 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
   const bool inside = px < cam.width && py < cam.height;
   if (__ballot(inside) == 0ull) return;
   const float fx = (float)px, fy = (float)py;
+  float open = inside ? 1.f : 0.f;               // 1.0 while the pixel takes splats (see the walk)
   const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);  // 4x4 sub-block of this lane's pixel
   unsigned long long sbl[4];
@@ -166,7 +184,6 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
   for (int sb = 0; sb < 4; ++sb) sbl[sb] = __ballot(sidx == sb);
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
   uint32_t last = 0;
-  bool done = !inside;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
   float r2 = 0.f;
   if (beg + lane < end) {
@@ -178,7 +195,7 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
     s1[0] = make_float4(0.f, -1e30f, 0.f, 0.f);
     s2[0] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  unsigned long long live = __ballot(!done);
+  unsigned long long live = __ballot(inside);
   // lists longer than FWD_SEQ_SEGS segments are finished by composite_fwd_deep_kernel (segment-parallel)
   const bool deep = end - beg > (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG);
   const uint32_t lim = deep ? beg + (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG) : end;
@@ -232,44 +249,56 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
       float rb[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        jx[u] = __builtin_ffsll((long long)m);      // 1-based staged index, 0 (the inert record) when the mask is empty
-        m &= m - 1ull;
+        jx[u] = pop_lowest_bit(m);      // 1-based staged index, 0 (the inert record) when the mask is empty
         OMFS_DBG_WORK();
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) { ra[u] = s0[jx[u]]; rc[u] = s1[jx[u]]; rb[u] = s2[jx[u]].x; }
+      // Every decision below is a compare feeding a select -- no lane predicate is combined with another one.  Combined
+      // predicates (hit && !stop, done || stop) compile to 64-bit scalar mask arithmetic, and the scalar unit retires
+      // ONE instruction per ~4.3 cycles and SIMD however many waves are resident (tools/micro/valu_rate.hip): the walk
+      // used to carry 23 scalar instructions per entry next to its 26 vector ones.
+      //   the four raw alphas do not depend on the pixel state (0 unless the splat is hit) and are evaluated side by side;
+      //   `open` is 1.0 while the pixel takes splats and 0.0 once it is done (or outside the image): alpha * open is exact;
+      //   with alpha == 0, Tn == T and w == 0 (T >= 1e-4 always: no false stop); w > 0 exactly when the splat was composited.
+      float ar[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const float4 a = ra[u], c = rc[u];
         const float dx = a.x - fx, dy = a.y - fy;
         const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
         const float e = p2 + c.y;
-        const bool hit = !done && p2 <= 0.f && e >= LOG2_INV255;
+        const float ev = p2 <= 0.f ? e : -1e30f;
+        const float ex = fminf(0.99f, __builtin_amdgcn_exp2f(ev));
+        ar[u] = ev >= LOG2_INV255 ? ex : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float alpha = ar[u] * open;
 #ifdef OMFS_DEBUG_COUNTERS
-        { const unsigned long long hb = __ballot(hit); OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb)); }
+        { const unsigned long long hb = __ballot(alpha > 0.f); OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb)); }
 #endif
-        const float alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
         const float Tn = T * (1.f - alpha);
-        // the splat that would take T below the threshold is not composited: weight 0, T and last stay
-        const bool stop = hit && Tn < 1e-4f;
-        const bool upd = hit && !stop;
-        const float w = upd ? alpha * T : 0.f;
-        C0 = fma_(c.z, w, C0);
-        C1 = fma_(c.w, w, C1);
+        // the splat that would take T below the threshold is not composited: weight 0, T and last stay, the pixel is done
+        const bool stop = Tn < 1e-4f;
+        const float w = stop ? 0.f : alpha * T;
+        C0 = fma_(rc[u].z, w, C0);
+        C1 = fma_(rc[u].w, w, C1);
         C2 = fma_(rb[u], w, C2);
-        T = upd ? Tn : T;
-        last = upd ? base + (uint32_t)jx[u] : last;
-        done = done || stop;
+        T = stop ? T : Tn;
+        open = stop ? 0.f : open;
+        last = w > 0.f ? base + (uint32_t)jx[u] : last;
       }
       // saturation is looked at once per batch
-      const unsigned long long nl = __ballot(!done);
+      const unsigned long long nl = __ballot(open != 0.f);
       if (nl != live) {
         live = nl;
         m &= combine(live);
       }
     }
-    live = __ballot(!done);
+    live = __ballot(open != 0.f);
     OMFS_DBG_PHASE(2);
+    OMFS_DBG_STEP((b - beg) / WB);
   }
   if (deep) {
     // hand-over: the state at boundary FWD_SEQ_SEGS and, in the tile's unused boundary-0 slot, the live mask
@@ -862,6 +891,14 @@ extern "C" int omfs_debug_timeline(int kernel, unsigned long long* out, int n, i
   for (int e = 0; e < 2; ++e)
     OMFS_CHECK_HIP(hipMemcpyFromSymbol(out + (size_t)e * n, HIP_SYMBOL(omfs_dbg_tl), (size_t)n * 8,
                                        ((size_t)kernel * 2 + e) * OMFS_DBG_TL * 8));
+  if (out && n > 0 && reset == 4) {      // reset == 4: out as uint32 [2][8][n] = per-step ticks and entries of composite_fwd
+    for (int i = 0; i < 16; ++i)
+      OMFS_CHECK_HIP(hipMemcpyFromSymbol((uint32_t*)out + (size_t)i * n, HIP_SYMBOL(omfs_dbg_step), (size_t)n * 4, (size_t)i * OMFS_DBG_TL * 4));
+    void* p = nullptr;
+    OMFS_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(omfs_dbg_step)));
+    OMFS_CHECK_HIP(hipMemset(p, 0, sizeof(uint32_t) * 16 * OMFS_DBG_TL));
+    return OMFS_OK;
+  }
   if (out && n > 0 && reset == 3) {      // reset == 3: out [4][n/2] (as uint32 [4][n]) = the phase cycles of composite_fwd
     for (int i = 0; i < 4; ++i)
       OMFS_CHECK_HIP(hipMemcpyFromSymbol((uint32_t*)out + (size_t)i * n, HIP_SYMBOL(omfs_dbg_phase), (size_t)n * 4, (size_t)i * OMFS_DBG_TL * 4));

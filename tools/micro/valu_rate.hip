@@ -7,6 +7,9 @@
 #define REP8(x) x x x x x x x x
 template <int KIND>
 __global__ void rate_kernel(float* out, long long* cycles, int iters) {
+  __shared__ float4 lds_pad[16];
+  if (threadIdx.x < 16) lds_pad[threadIdx.x] = make_float4(1.f, 2.f, 3.f, 4.f);
+  __syncthreads();
   float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
   const float b = 1.0001f, c = 0.5f;
   long long t0 = clock64();
@@ -41,6 +44,35 @@ __global__ void rate_kernel(float* out, long long* cycles, int iters) {
       REP8(asm volatile("v_readlane_b32 s20, %0, 3\n v_readlane_b32 s21, %1, 5\n v_readlane_b32 s22, %2, 7\n v_readlane_b32 s23, %3, 9\n"
                         "v_readlane_b32 s24, %4, 3\n v_readlane_b32 s25, %5, 5\n v_readlane_b32 s26, %6, 7\n v_readlane_b32 s27, %7, 9\n"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : "s20","s21","s22","s23","s24","s25","s26","s27");)
+    } else if (KIND == 7) {   // scalar only: eight independent 32-bit adds
+      REP8(asm volatile("s_add_u32 s20, s20, 1\n s_add_u32 s21, s21, 1\n s_add_u32 s22, s22, 1\n s_add_u32 s23, s23, 1\n"
+                        "s_add_u32 s24, s24, 1\n s_add_u32 s25, s25, 1\n s_add_u32 s26, s26, 1\n s_add_u32 s27, s27, 1\n"
+                        : : : "s20","s21","s22","s23","s24","s25","s26","s27","scc");)
+    } else if (KIND == 8) {   // scalar only, the bit-scan idiom of the composite kernels: ffs, m-1 (two halves), and
+      REP8(asm volatile("s_ff1_i32_b64 s28, s[20:21]\n s_add_u32 s22, s20, -1\n s_addc_u32 s23, s21, -1\n s_and_b64 s[20:21], s[20:21], s[22:23]\n"
+                        "s_ff1_i32_b64 s29, s[24:25]\n s_add_u32 s26, s24, -1\n s_addc_u32 s27, s25, -1\n s_and_b64 s[24:25], s[24:25], s[26:27]\n"
+                        : : : "s20","s21","s22","s23","s24","s25","s26","s27","s28","s29","scc");)
+    } else if (KIND == 9) {   // eight vector fma + eight independent scalar adds, interleaved: sum or max of the two?
+      REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n s_add_u32 s20, s20, 1\n v_fma_f32 %1, %1, %8, %9\n s_add_u32 s21, s21, 1\n"
+                        "v_fma_f32 %2, %2, %8, %9\n s_add_u32 s22, s22, 1\n v_fma_f32 %3, %3, %8, %9\n s_add_u32 s23, s23, 1\n"
+                        "v_fma_f32 %4, %4, %8, %9\n s_add_u32 s24, s24, 1\n v_fma_f32 %5, %5, %8, %9\n s_add_u32 s25, s25, 1\n"
+                        "v_fma_f32 %6, %6, %8, %9\n s_add_u32 s26, s26, 1\n v_fma_f32 %7, %7, %8, %9\n s_add_u32 s27, s27, 1\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)
+                        : "s20","s21","s22","s23","s24","s25","s26","s27","scc");)
+    } else if (KIND == 10) {  // compare -> scalar use of the mask (the ballot idiom): v_cmp to an SGPR pair, s_and, s_cmp
+      REP8(asm volatile("v_cmp_lt_f32 s[20:21], %0, %8\n s_and_b64 s[22:23], s[20:21], exec\n v_cmp_lt_f32 s[24:25], %1, %8\n s_and_b64 s[26:27], s[24:25], exec\n"
+                        "v_cmp_lt_f32 s[20:21], %2, %8\n s_and_b64 s[22:23], s[20:21], exec\n v_cmp_lt_f32 s[24:25], %3, %8\n s_and_b64 s[26:27], s[24:25], exec\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)
+                        : "s20","s21","s22","s23","s24","s25","s26","s27","scc");)
+    } else if (KIND == 11) {  // LDS: eight broadcast 16-byte reads (every lane the same address) per group
+      REP8(asm volatile("ds_read_b128 v[40:43], %0\n ds_read_b128 v[44:47], %0 offset:16\n ds_read_b128 v[48:51], %0 offset:32\n ds_read_b128 v[52:55], %0 offset:48\n"
+                        "ds_read_b128 v[40:43], %0 offset:64\n ds_read_b128 v[44:47], %0 offset:80\n ds_read_b128 v[48:51], %0 offset:96\n ds_read_b128 v[52:55], %0 offset:112\n"
+                        "s_waitcnt lgkmcnt(0)\n"
+                        : : "v"(0) : "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","memory");)
+    } else if (KIND == 12) {  // s_cbranch that is never taken + scalar compare (loop-control idiom)
+      REP8(asm volatile("s_cmp_eq_u32 s20, 77\n s_cbranch_scc1 1f\n s_cmp_eq_u32 s20, 78\n s_cbranch_scc1 1f\n"
+                        "s_cmp_eq_u32 s20, 79\n s_cbranch_scc1 1f\n s_cmp_eq_u32 s20, 80\n s_cbranch_scc1 1f\n 1:\n"
+                        : : : "s20","scc");)
     }
   }
   long long t1 = clock64();
@@ -82,6 +114,12 @@ int main() {
     run<4>("mul/min", w, out, cyc);
     run<5>("fma_dep", w, out, cyc);
     run<6>("readlane", w, out, cyc);
+    run<7>("s_add", w, out, cyc);
+    run<8>("s_bitscan", w, out, cyc);
+    run<9>("fma+s_add", w, out, cyc);
+    run<10>("cmp->sgpr", w, out, cyc);
+    run<11>("lds_b128", w, out, cyc);
+    run<12>("cmp+branch", w, out, cyc);
   }
   return 0;
 }

@@ -29,6 +29,8 @@ cd = ctypes.CDLL(os.path.join(os.path.dirname(L.__file__), "libomfs_splat.so"))
 NTL = 1 << 19
 buf = (ctypes.c_ulonglong * (3 * NTL))()
 cd.omfs_debug_timeline(0, buf, NTL, 1)
+_clr = (ctypes.c_uint32 * (16 * NTL))()
+cd.omfs_debug_timeline(0, ctypes.cast(_clr, ctypes.POINTER(ctypes.c_ulonglong)), NTL, 4)      # clears the per-step table
 t.step()
 torch.cuda.synchronize()
 for k, name, waves_per in ((0, "composite_fwd (one wave per entry)", 1), (1, "composite_fwd_deep (8-wave workgroups)", 8), (2, "composite_bwd", 1)):
@@ -66,6 +68,19 @@ for k, name, waves_per in ((0, "composite_fwd (one wave per entry)", 1), (1, "co
             q = ph[:, sel].sum(1)
             print(f"   {name_:24s}: wait for gather {q[0] / q.sum():.2f}  stage {q[1] / q.sum():.2f}  walk {q[2] / q.sum():.2f}  other {q[3] / q.sum():.2f}"
                   f"   (mean {ph[:, sel].sum(0).mean() / mhz:.1f} us per wave)")
+        sbuf = (ctypes.c_uint32 * (16 * NTL))()
+        assert cd.omfs_debug_timeline(0, ctypes.cast(sbuf, ctypes.POINTER(ctypes.c_ulonglong)), NTL, 4) == 0
+        st = np.frombuffer(sbuf, dtype=np.uint32).reshape(2, 8, NTL).astype(np.float64)[:, :, ok][:, :, big]
+        full = st[0, 7] > 0                       # long waves that walked all eight 64-entry steps
+        if full.any():
+            tt, ww = st[0][:, full] * 10e-3, st[1][:, full]
+            start = (t0[big][full] - t0.min()) * 10e-3
+            print(f"   {int(full.sum())} of the longest waves walked 8 steps; per step: end time since the launch began (us), duration (us), entries walked, ns per entry")
+            prev_t, prev_w = np.zeros(tt.shape[1]), np.zeros(tt.shape[1])
+            for s_ in range(8):
+                d, e = tt[s_] - prev_t, ww[s_] - prev_w
+                print(f"      step {s_}: ends {np.mean(start + tt[s_]):6.1f}  lasts {d.mean():5.1f}  entries {e.mean():5.1f}  {1e3 * d.sum() / max(e.sum(), 1):5.0f} ns/entry")
+                prev_t, prev_w = tt[s_], ww[s_]
         lw = ph[:, big]
         print(f"   longest 1 %: per visited splat {np.median(lw[2] / np.maximum(w[big], 1)):.0f} walk cycles; per 64-entry step "
               f"{np.median(lw[1] / np.maximum(np.ceil(w[big] / 50.0), 1)):.0f} staging cycles (assuming ~50 visits per step)")
