@@ -10,8 +10,12 @@ out="$here/../libomfs_splat.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function"
 objs=()
+# machine-scheduler strategy per translation unit (measured on the bench workload, tools/_ab/flags.sh: the loss kernels 0.104 ->
+# 0.099 ms and composite_bwd 0.237 -> 0.234 ms with max-ilp, project_bwd 0.056 -> 0.052 ms with max-memory-clause; the rest do not care)
+declare -A SCHED=([loss_adam]="-mllvm -amdgpu-sched-strategy=max-ilp" [composite]="-mllvm -amdgpu-sched-strategy=max-ilp"
+                  [project_bwd]="-mllvm -amdgpu-sched-strategy=max-memory-clause")
 for src in flame project binning composite project_bwd loss_adam simple_flame densify; do
-  "$HIPCC" $FLAGS ${EXTRA_HIPCC_FLAGS:-} -c "$here/$src.hip" -o "$here/$src.o" &
+  "$HIPCC" $FLAGS ${SCHED[$src]:-} ${EXTRA_HIPCC_FLAGS:-} -c "$here/$src.hip" -o "$here/$src.o" &
   objs+=("$here/$src.o")
 done
 "$HIPCC" $FLAGS -x hip -c "$here/api.cpp" -o "$here/api.o" &
