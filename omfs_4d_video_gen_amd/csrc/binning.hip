@@ -180,8 +180,31 @@ struct WaveRects {            // one wave's published rectangles (36 B per lane)
   uint32_t scan[64];          // inclusive prefix sum of rectangle areas
   uint32_t rect[64];          // packed x0 | y0<<8 | x1<<16 | y1<<24
   uint32_t depth[64];         // depth bits
+  uint32_t coarse[8];         // scan[7], scan[15], ..., scan[63]: first level of the owner search
 };
 constexpr size_t BIN_SCRATCH_BYTES = sizeof(WaveRects) * BIN_WAVES;
+
+// Which Gaussian lane l of this wave owns (bin_count_kernel and bin_scatter_kernel, which must agree: the scatter replays the
+// count's ballots).  The Gaussians are stored in mesh order, so neighbours have similar footprints, and with 512 consecutive
+// Gaussians per workgroup / 64 per wave the launch ended on the workgroups that own the large splats of one region (63 walk
+// steps for the heaviest wave against a mean of 22 on the bench scene).  Two levels of dealing instead:
+//   * a workgroup takes 8 STRIPES of 64 consecutive Gaussians that lie n_workgroups * 64 apart (stripe s of workgroup b is
+//     chunk s * gridDim.x + b): every workgroup gets the same mix of regions, yet touches only ~8 small neighbourhoods of
+//     tiles, so the LDS aggregation of the counters keeps most of its factor (dealing single runs over the whole grid
+//     balances as well but triples the global atomics: OMFS_BIN_DEAL_GRID, measured 0.041 / 0.048 ms);
+//   * inside the workgroup the 128 runs of four (64 contiguous bytes of each record array) go round-robin to the waves,
+//     two runs of every stripe each, so the waves of a workgroup finish together.
+static_assert(BIN_THREADS == 512, "bin_gaussian deals 8 stripes of 64 to 8 waves");
+__device__ __forceinline__ int bin_gaussian(int l) {
+  const int w = (int)(threadIdx.x >> 6), q = l >> 2;
+#ifdef OMFS_BIN_DEAL_GRID
+  const int waves = (int)gridDim.x * BIN_WAVES;
+  return ((q * waves + (int)blockIdx.x * BIN_WAVES + w) << 2) + (l & 3);
+#else
+  const int stripe = q >> 1, run = ((q & 1) << 3) | w;          // run q * 8 + w of the workgroup's 128
+  return ((stripe * (int)gridDim.x + (int)blockIdx.x) << 6) + (run << 2) + (l & 3);
+#endif
+}
 
 // calls f(tile) for every tile of Gaussian i's rectangle that passes the test (lane-per-Gaussian form, fallback kernels)
 template <typename F>
@@ -215,6 +238,7 @@ __device__ __forceinline__ uint32_t publish_rects(const PairSource& ps, int i, i
   const uint32_t area = (((rect >> 16) & 255u) - (rect & 255u)) * ((rect >> 24) - ((rect >> 8) & 255u));
   const uint32_t incl = wave_incl_scan_u32(area, lane);
   wr->r0[lane] = r0; wr->r1[lane] = r1; wr->scan[lane] = incl; wr->rect[lane] = rect; wr->depth[lane] = depth;
+  if ((lane & 7) == 7) wr->coarse[lane >> 3] = incl;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   return (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -233,11 +257,17 @@ __device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* 
                                                                unsigned long long* hits, F&& f) {
   const int lane = lane_id();
   uint32_t step = 0;
+  const uint4 ca = *reinterpret_cast<const uint4*>(&wr->coarse[0]), cb = *reinterpret_cast<const uint4*>(&wr->coarse[4]);
   for (uint32_t p = lane; p < total; p += 64, ++step) {
-    int j = 0;
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1)
-      if (wr->scan[j + s - 1] <= p) j += s;          // first j with scan[j] > p
+    // owner = first j with scan[j] > p = #{g : scan[g] <= p} (scan is non-decreasing).  Two 8-way levels -- the eight
+    // group ends, then the eight entries of the group -- are two LDS round trips of two 16-byte reads each; the 6-step
+    // bisection this replaces was a chain of six dependent LDS reads per walk step, and these kernels spend half (count)
+    // to two thirds (scatter) of their wave-cycles waiting (profiles/r02_b_pmc_wait.json).
+    const int jh = (int)(ca.x <= p) + (int)(ca.y <= p) + (int)(ca.z <= p) + (int)(ca.w <= p) + (int)(cb.x <= p) + (int)(cb.y <= p) +
+                   (int)(cb.z <= p);                  // coarse[7] = total > p
+    const uint4 fa = *reinterpret_cast<const uint4*>(&wr->scan[8 * jh]), fb = *reinterpret_cast<const uint4*>(&wr->scan[8 * jh + 4]);
+    const int j = 8 * jh + (int)(fa.x <= p) + (int)(fa.y <= p) + (int)(fa.z <= p) + (int)(fa.w <= p) + (int)(fb.x <= p) +
+                  (int)(fb.y <= p) + (int)(fb.z <= p);   // scan[8 jh + 7] = coarse[jh] > p
     const uint32_t rect = wr->rect[j];
     const int x0 = rect & 255u, y0 = (rect >> 8) & 255u, x1 = (rect >> 16) & 255u, y1 = rect >> 24;
     const int w = x1 - x0;
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSourc
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
   if (threadIdx.x == 0) s_vis = 0u;
-  const int i = blockIdx.x * BIN_THREADS + threadIdx.x;
+  const int i = bin_gaussian(lane_id());
   bool vis;
   const uint32_t total = publish_rects(ps, i, n, wr, &vis);
   __syncthreads();
@@ -306,20 +336,25 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSou
   unsigned long long* hits = hits_all ? hits_all + ((size_t)blockIdx.x * BIN_WAVES + (threadIdx.x >> 6)) * HITS_PER_WAVE : nullptr;
   if (tile_start[n_tiles] == 0u) return;                // nothing visible, or capacity overflow (flagged by the scan)
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
-  const int i = blockIdx.x * BIN_THREADS + threadIdx.x;
+  const int i = bin_gaussian(lane_id());
   const uint32_t total = publish_rects(ps, i, n, wr);
   __syncthreads();
   for_each_touched_tile_balanced<HITS_REPLAY>(wr, total, gx, hits, [&](int t, int) { atomicAdd(&hist[t], 1u); });
   __syncthreads();
-  for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) {
-    const uint32_t c = hist[t];
-    if (c) hist[t] = tile_start[t] + atomicAdd(&tile_cursor[t], c);
+  // the block's slot ranges: eight returning atomics in flight per thread (one round trip per eight tiles, not one per tile)
+  for (int t0 = threadIdx.x; t0 < n_tiles; t0 += 8 * BIN_THREADS) {
+    uint32_t c[8], at[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const int t = t0 + k * BIN_THREADS; c[k] = t < n_tiles ? hist[t] : 0u; }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) at[k] = c[k] ? atomicAdd(&tile_cursor[t0 + k * BIN_THREADS], c[k]) : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (c[k]) hist[t0 + k * BIN_THREADS] = tile_start[t0 + k * BIN_THREADS] + at[k];
   }
   __syncthreads();
-  const uint32_t id0 = (uint32_t)(i - lane_id());
   for_each_touched_tile_balanced<HITS_REPLAY>(wr, total, gx, hits, [&](int t, int j) {
     const uint32_t pos = atomicAdd(&hist[t], 1u);
-    keys[pos] = make_uint2(wr->depth[j], id0 + (uint32_t)j);
+    keys[pos] = make_uint2(wr->depth[j], (uint32_t)bin_gaussian(j));
   });
 }
 
