@@ -26,7 +26,19 @@ constexpr int SRH_B = OMFS_SSIM_ROWS_BWD;   // the backward kernel's own strip h
 constexpr int SROWS_B = SRH_B + 2 * HALO;
 static_assert(SROWS_B % 11 == 0, "the register ring is unrolled by the 11 window taps");
 
+#ifndef OMFS_SSIM_PF
+#define OMFS_SSIM_PF 3
+#endif
+constexpr int SSIM_PF = OMFS_SSIM_PF;   // input rows in flight per wave
 struct GaussW { float g[11]; };  // normalised 11-tap window, passed by value (scalar registers)
+
+// Packed fp32: one v_pk_fma_f32 / v_pk_mul_f32 does two IEEE operations for ~1.2x the issue time of one (4.7 against 2.7-4
+// cycles per wave-instruction, tools/micro/valu_rate.hip), and these kernels are bound by instruction issue, not by HBM
+// (17.1 M + 11.0 M VALU wave-instructions per launch at 2.5 TB/s).  The five moment maps of the forward pass and the three
+// derivative maps of the backward pass are convolved in pairs; the arithmetic per element is unchanged (same operations,
+// same order), so the results are bit-identical to the scalar form.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(float g, f2 b, f2 c) { return __builtin_elementwise_fma((f2){g, g}, b, c); }
 
 // Streaming separable window: one wave owns a 64-column strip and walks SROWS input rows top to bottom.
 // Each row goes through LDS once for the horizontal taps; the vertical taps read a ring of the last 11
@@ -36,7 +48,7 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
                                                       int width, int height, float w_l1, float w_ssim, GaussW gw,
                                                       float* __restrict__ map_mu1, float* __restrict__ map_xx,
                                                       float* __restrict__ map_xy, float* __restrict__ partials) {
-  __shared__ float sx[SW + 2 * HALO], sy[SW + 2 * HALO];
+  __shared__ f2 sxy[SW + 2 * HALO];       // (image, target) of one input row
   const int l = threadIdx.x, ch = blockIdx.z;
   const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH;
   const size_t plane = (size_t)width * height;
@@ -53,38 +65,49 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
       if (inb) { v[2] = ip[ro + xb]; v[3] = gp[ro + xb]; }
     }
   };
-  float ring[11][5];
-  float cur[4], nxt[4], nn[4];
+  f2 ring_m[11], ring_q[11];      // horizontally filtered (x, y) and (x^2, y^2) of the last 11 rows
+  float ring_c[11];               // ... and x y
+  float cur[4], pre[SSIM_PF][4];          // rows iy + 1 .. iy + SSIM_PF are in flight while row iy is filtered
   load_row(0, cur);
-  load_row(1, nxt);
+#pragma unroll
+  for (int k = 0; k < SSIM_PF; ++k) load_row(1 + k, pre[k]);
   float contrib = 0.f;
   for (int base = 0; base < SROWS; base += 11) {
 #pragma unroll
     for (int r = 0; r < 11; ++r) {
       const int iy = base + r;
-      sx[l] = cur[0]; sy[l] = cur[1];
-      if (l < 2 * HALO) { sx[SW + l] = cur[2]; sy[SW + l] = cur[3]; }
+      sxy[l] = (f2){cur[0], cur[1]};
+      if (l < 2 * HALO) sxy[SW + l] = (f2){cur[2], cur[3]};
       __syncthreads();
-      load_row(iy + 2, nn);
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cur[k] = pre[0][k];
+#pragma unroll
+      for (int q = 0; q + 1 < SSIM_PF; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pre[q][k] = pre[q + 1][k];
+      load_row(iy + 1 + SSIM_PF, pre[SSIM_PF - 1]);
+      f2 am = {0.f, 0.f}, aq = {0.f, 0.f};
+      float ac = 0.f;
 #pragma unroll
       for (int t = 0; t < 11; ++t) {
-        const float g = gw.g[t], x = sx[l + t], y = sy[l + t];
-        a0 = fma_(g, x, a0); a1 = fma_(g, y, a1); a2 = fma_(g, x * x, a2); a3 = fma_(g, y * y, a3); a4 = fma_(g, x * y, a4);
+        const float g = gw.g[t];
+        const f2 v = sxy[l + t];
+        am = pk_fma(g, v, am); aq = pk_fma(g, v * v, aq); ac = fma_(g, v.x * v.y, ac);
       }
-      ring[r][0] = a0; ring[r][1] = a1; ring[r][2] = a2; ring[r][3] = a3; ring[r][4] = a4;
+      ring_m[r] = am; ring_q[r] = aq; ring_c[r] = ac;
       const int yin = oy - HALO + iy;
-      if (iy >= HALO && iy < HALO + SRH && yin < height && ino) contrib += w_l1 * fabsf(sx[l + HALO] - sy[l + HALO]);
+      if (iy >= HALO && iy < HALO + SRH && yin < height && ino) { const f2 c = sxy[l + HALO]; contrib += w_l1 * fabsf(c.x - c.y); }
       const int yout = oy + iy - 2 * HALO;
       if (iy >= 2 * HALO && yout < height && ino) {
-        float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+        f2 mu = {0.f, 0.f}, ee = {0.f, 0.f};
+        float exy = 0.f;
 #pragma unroll
         for (int t = 0; t < 11; ++t) {
           const float g = gw.g[t];
           const int q = (r + 1 + t) % 11;
-          mu1 = fma_(g, ring[q][0], mu1); mu2 = fma_(g, ring[q][1], mu2);
-          exx = fma_(g, ring[q][2], exx); eyy = fma_(g, ring[q][3], eyy); exy = fma_(g, ring[q][4], exy);
+          mu = pk_fma(g, ring_m[q], mu); ee = pk_fma(g, ring_q[q], ee); exy = fma_(g, ring_c[q], exy);
         }
+        const float mu1 = mu.x, mu2 = mu.y, exx = ee.x, eyy = ee.y;
         const float C1 = 0.0001f, C2 = 0.0009f;
         const float s11 = exx - mu1 * mu1, s22 = eyy - mu2 * mu2, s12 = exy - mu1 * mu2;
         const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2, B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
@@ -98,8 +121,6 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
         map_xy[o] = 2.f * A1 * iB;
         contrib -= w_ssim * ssim;
       }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { cur[k] = nxt[k]; nxt[k] = nn[k]; }
     }
   }
   contrib = wave_sum_all(contrib);
@@ -111,7 +132,8 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ 
                                                       int width, int height, float w_l1, float w_ssim, GaussW gw,
                                                       const float* __restrict__ map_mu1, const float* __restrict__ map_xx,
                                                       const float* __restrict__ map_xy, float* __restrict__ dimage) {
-  __shared__ float s0[SW + 2 * HALO], s1[SW + 2 * HALO], s2[SW + 2 * HALO];
+  __shared__ f2 s01[SW + 2 * HALO];       // (d/dmu1, d/dE[xx]) of one map row
+  __shared__ float s2[SW + 2 * HALO];     // d/dE[xy]
   const int l = threadIdx.x, ch = blockIdx.z;
   const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH_B;
   const size_t plane = (size_t)width * height;
@@ -131,41 +153,50 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ 
     const int yo = oy + iy - 2 * HALO;
     if (iy >= 2 * HALO && iy < SROWS_B && yo < height && ino) { v[6] = img[co + (size_t)yo * width + xo]; v[7] = gt[co + (size_t)yo * width + xo]; }
   };
-  float ring[11][3];
-  float cur[8], nxt[8], nn[8];
+  f2 ring01[11];
+  float ring2[11];
+  float cur[8], pre[SSIM_PF][8];
   load_row(0, cur);
-  load_row(1, nxt);
+#pragma unroll
+  for (int k = 0; k < SSIM_PF; ++k) load_row(1 + k, pre[k]);
   for (int base = 0; base < SROWS_B; base += 11) {
 #pragma unroll
     for (int r = 0; r < 11; ++r) {
       const int iy = base + r;
-      s0[l] = cur[0]; s1[l] = cur[1]; s2[l] = cur[2];
-      if (l < 2 * HALO) { s0[SW + l] = cur[3]; s1[SW + l] = cur[4]; s2[SW + l] = cur[5]; }
+      s01[l] = (f2){cur[0], cur[1]}; s2[l] = cur[2];
+      if (l < 2 * HALO) { s01[SW + l] = (f2){cur[3], cur[4]}; s2[SW + l] = cur[5]; }
       __syncthreads();
-      load_row(iy + 2, nn);
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+      const float xv = cur[6], yv = cur[7];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cur[k] = pre[0][k];
+#pragma unroll
+      for (int q = 0; q + 1 < SSIM_PF; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pre[q][k] = pre[q + 1][k];
+      load_row(iy + 1 + SSIM_PF, pre[SSIM_PF - 1]);
+      f2 a01 = {0.f, 0.f};
+      float a2 = 0.f;
 #pragma unroll
       for (int t = 0; t < 11; ++t) {
         const float g = gw.g[t];
-        a0 = fma_(g, s0[l + t], a0); a1 = fma_(g, s1[l + t], a1); a2 = fma_(g, s2[l + t], a2);
+        a01 = pk_fma(g, s01[l + t], a01); a2 = fma_(g, s2[l + t], a2);
       }
-      ring[r][0] = a0; ring[r][1] = a1; ring[r][2] = a2;
+      ring01[r] = a01; ring2[r] = a2;
       const int yout = oy + iy - 2 * HALO;
       if (iy >= 2 * HALO && yout < height && ino) {
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        f2 c01 = {0.f, 0.f};
+        float c2 = 0.f;
 #pragma unroll
         for (int t = 0; t < 11; ++t) {
           const float g = gw.g[t];
           const int q = (r + 1 + t) % 11;
-          c0 = fma_(g, ring[q][0], c0); c1 = fma_(g, ring[q][1], c1); c2 = fma_(g, ring[q][2], c2);
+          c01 = pk_fma(g, ring01[q], c01); c2 = fma_(g, ring2[q], c2);
         }
-        const float xv = cur[6], yv = cur[7];
+        const float c0 = c01.x, c1 = c01.y;
         const float d = xv - yv;
         const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
         dimage[co + (size_t)yout * width + xo] = w_l1 * sgn - w_ssim * (c0 + 2.f * xv * c1 + yv * c2);
       }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) { cur[k] = nxt[k]; nxt[k] = nn[k]; }
     }
   }
 }

@@ -69,6 +69,18 @@ __global__ void rate_kernel(float* out, long long* cycles, int iters) {
                         "ds_read_b128 v[40:43], %0 offset:64\n ds_read_b128 v[44:47], %0 offset:80\n ds_read_b128 v[48:51], %0 offset:96\n ds_read_b128 v[52:55], %0 offset:112\n"
                         "s_waitcnt lgkmcnt(0)\n"
                         : : "v"(0) : "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55","memory");)
+    } else if (KIND == 13) {  // packed fp32 fma: two fmas per instruction -- at the price of one?
+      REP8(asm volatile("v_pk_fma_f32 v[40:41], v[40:41], v[56:57], v[58:59]\n v_pk_fma_f32 v[42:43], v[42:43], v[56:57], v[58:59]\n"
+                        "v_pk_fma_f32 v[44:45], v[44:45], v[56:57], v[58:59]\n v_pk_fma_f32 v[46:47], v[46:47], v[56:57], v[58:59]\n"
+                        "v_pk_fma_f32 v[48:49], v[48:49], v[56:57], v[58:59]\n v_pk_fma_f32 v[50:51], v[50:51], v[56:57], v[58:59]\n"
+                        "v_pk_fma_f32 v[52:53], v[52:53], v[56:57], v[58:59]\n v_pk_fma_f32 v[54:55], v[54:55], v[56:57], v[58:59]\n"
+                        : : : "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55");)
+    } else if (KIND == 14) {  // packed fp32 mul / add
+      REP8(asm volatile("v_pk_mul_f32 v[40:41], v[40:41], v[56:57]\n v_pk_add_f32 v[42:43], v[42:43], v[56:57]\n"
+                        "v_pk_mul_f32 v[44:45], v[44:45], v[56:57]\n v_pk_add_f32 v[46:47], v[46:47], v[56:57]\n"
+                        "v_pk_mul_f32 v[48:49], v[48:49], v[56:57]\n v_pk_add_f32 v[50:51], v[50:51], v[56:57]\n"
+                        "v_pk_mul_f32 v[52:53], v[52:53], v[56:57]\n v_pk_add_f32 v[54:55], v[54:55], v[56:57]\n"
+                        : : : "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55");)
     } else if (KIND == 12) {  // s_cbranch that is never taken + scalar compare (loop-control idiom)
       REP8(asm volatile("s_cmp_eq_u32 s20, 77\n s_cbranch_scc1 1f\n s_cmp_eq_u32 s20, 78\n s_cbranch_scc1 1f\n"
                         "s_cmp_eq_u32 s20, 79\n s_cbranch_scc1 1f\n s_cmp_eq_u32 s20, 80\n s_cbranch_scc1 1f\n 1:\n"
@@ -120,6 +132,8 @@ int main() {
     run<10>("cmp->sgpr", w, out, cyc);
     run<11>("lds_b128", w, out, cyc);
     run<12>("cmp+branch", w, out, cyc);
+    run<13>("pk_fma", w, out, cyc);
+    run<14>("pk_mul/add", w, out, cyc);
   }
   return 0;
 }
