@@ -241,6 +241,7 @@ def main(argv=None):
             # views and overflow independently; no collective is involved, each rank grows its own buffers.
             if trainer.rast.overflowed():
                 new_cap = trainer.rast.grow_dup_capacity(2.0)
+                trainer.invalidate_graphs()          # captured iterations (OMFS_STEP_GRAPH=1) hold the old buffers' addresses
                 print(f"[ITER {it}] rank {rank}: tile-list capacity exceeded within the last {args.log_every} iterations "
                       f"(those rendered empty lists): grown to {new_cap} pairs", flush=True)
         if rank == 0 and it in save_at:
