@@ -568,7 +568,10 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
 // compiler's own lowering of the same pattern is a v_mov_dpp plus a packed add.  A VGPR written by a VALU
 // instruction needs two wait states before a DPP read: the s_nop covers the first row, the 8 instructions
 // between two uses of the same register cover the rest.
-__device__ __forceinline__ void reduce9_groups_of_8(float (&v)[9]) {
+#ifndef OMFS_BWD_GROUP
+#define OMFS_BWD_GROUP 4               // lanes per partial sum of the DPP reduction (8: three steps; 4: two steps, twice the partials)
+#endif
+__device__ __forceinline__ void reduce9_groups(float (&v)[9]) {
 #define OMFS_DPP_ROW(SH)                                                                      \
   "v_add_f32_dpp %0, %0, %0 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
   "v_add_f32_dpp %1, %1, %1 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
@@ -579,7 +582,11 @@ __device__ __forceinline__ void reduce9_groups_of_8(float (&v)[9]) {
   "v_add_f32_dpp %6, %6, %6 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
   "v_add_f32_dpp %7, %7, %7 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
   "v_add_f32_dpp %8, %8, %8 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#if OMFS_BWD_GROUP == 4
+  asm volatile("s_nop 1\n\t" OMFS_DPP_ROW(1) OMFS_DPP_ROW(2)
+#else
   asm volatile("s_nop 1\n\t" OMFS_DPP_ROW(1) OMFS_DPP_ROW(2) OMFS_DPP_ROW(4)
+#endif
                : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]));
 #undef OMFS_DPP_ROW
 }
@@ -588,15 +595,17 @@ __device__ __forceinline__ void reduce9_groups_of_8(float (&v)[9]) {
 // of a silhouette quadrant is bounded by the segment length.  A pixel whose last contributor lies behind this
 // segment enters it with the (T, C) the forward pass checkpointed at the next segment's start: T directly,
 // and the colour behind the boundary as (C_final - C_checkpoint) / T.  The segment is walked back to front;
-// per visited splat the 64 pixel contributions are reduced with three DPP steps to 8 partials per value,
+// per visited splat the 64 pixel contributions are reduced with two DPP steps to 16 partials per value,
 // parked in one of PEND wave-private slots, and flushed 4 splats per wave-instruction: 16 lanes per 64-byte
-// dsplat record, lane q < 9 sums the 8 partials of value q and adds them with one float atomic, so every
+// dsplat record, lane q < 9 sums the 16 partials of value q and adds them with one float atomic, so every
 // atomic wave-instruction covers whole 64-byte segments (MI355X_MICROARCH "Global float atomics").
 // Residency is what this kernel lives on (every lever that lowered it lost): 4 pending slots instead of 16 bring the
 // wave-private LDS from 7.5 KB to 4 KB -- the wave slots, not the LDS, now bound the residency -- and 64 VGPRs keep all
-// 8 slots per SIMD usable (0.277 -> 0.245 ms; 2, 6, 8, 12 slots: 0.251, 0.251, 0.261, 0.258).
+// 8 slots per SIMD usable (0.277 -> 0.245 ms; 2, 6, 8, 12 slots: 0.251, 0.251, 0.261, 0.258).  Round 2: the reduction stops
+// at 4-lane groups (18 DPP adds instead of 27; the flush sums 16 partials instead of 8) with 3 pending slots, which keeps
+// the wave-private LDS at 4.5 KB = 35 waves per CU: 0.235 -> 0.230 ms (with 4 slots, 5.1 KB = 31 waves: 0.250; 2 slots: 0.241).
 #ifndef OMFS_BWD_PEND
-#define OMFS_BWD_PEND 4
+#define OMFS_BWD_PEND 3
 #endif
 #ifndef OMFS_BWD_WAVES
 #define OMFS_BWD_WAVES 8
@@ -617,7 +626,8 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
   __shared__ float4 s1[WB];
   __shared__ float2 s2[WB];               // (blue, opacity)
   __shared__ uint32_t sid[WB];
-  __shared__ float red[PEND][8][9];       // [pending slot][8-lane group][value]
+  constexpr int NGRP = 64 / OMFS_BWD_GROUP;
+  __shared__ float red[PEND][NGRP][9];    // [pending slot][lane group][value]
   __shared__ uint32_t pend_id[PEND];      // Gaussian id of each pending slot
   OMFS_DBG_SPAN(2);
   const uint32_t seg = blockIdx.x >> 2;
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
         const float* src = &red[slot][0][q];
         float sum = 0.f;
 #pragma unroll
-        for (int p8 = 0; p8 < 8; ++p8) sum += src[p8 * 9];
+        for (int p8 = 0; p8 < NGRP; ++p8) sum += src[p8 * 9];
         const float out = sum;   // moments; omfs_project_bwd turns them into d mean2d / d conic
         if (out != 0.f) atomicAdd(&dsplat[(size_t)pend_id[slot] * 16 + q], out);
       }
@@ -781,9 +791,9 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
         v[4] = v[1] * dy;
         v[5] = G * dLa;                                 // d opacity
       }
-      reduce9_groups_of_8(v);   // lanes 7, 15, ..., 63 hold the sums of their 8-lane groups
-      if ((lane & 7) == 7) {
-        float* dst = &red[n_pending][lane >> 3][0];
+      reduce9_groups(v);   // the last lane of every OMFS_BWD_GROUP-lane group holds the group's sums
+      if ((lane & (OMFS_BWD_GROUP - 1)) == OMFS_BWD_GROUP - 1) {
+        float* dst = &red[n_pending][lane / OMFS_BWD_GROUP][0];
 #pragma unroll
         for (int q = 0; q < 9; ++q) dst[q] = v[q];
       }
