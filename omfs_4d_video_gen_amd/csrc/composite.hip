@@ -582,7 +582,9 @@ __device__ __forceinline__ void reduce9_groups(float (&v)[9]) {
   "v_add_f32_dpp %6, %6, %6 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
   "v_add_f32_dpp %7, %7, %7 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"      \
   "v_add_f32_dpp %8, %8, %8 row_shr:" #SH " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-#if OMFS_BWD_GROUP == 4
+#if OMFS_BWD_GROUP == 2
+  asm volatile("s_nop 1\n\t" OMFS_DPP_ROW(1)
+#elif OMFS_BWD_GROUP == 4
   asm volatile("s_nop 1\n\t" OMFS_DPP_ROW(1) OMFS_DPP_ROW(2)
 #else
   asm volatile("s_nop 1\n\t" OMFS_DPP_ROW(1) OMFS_DPP_ROW(2) OMFS_DPP_ROW(4)
