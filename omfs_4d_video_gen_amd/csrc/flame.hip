@@ -53,12 +53,26 @@ __global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restric
   // global memory every chain step was its own round trip (14 us alone, 58-81 us beside the Adam pass)
   __shared__ float s_je[15 * 128];
   __shared__ float s_e[128];
-  for (int k = lane; k < 15 * n_expr; k += 64) s_je[k] = j_expr[k];
-  for (int k = lane; k < n_expr; k += 64) s_e[k] = e[k];
+  // all loads of a pass in flight together (a plain copy loop waits for every load before its LDS store: 24 round trips
+  // for the 1500 words of the regressor -- 32 us for this kernel beside the Adam pass, where a round trip takes 3-5x longer)
+  const float jst = lane < 15 ? j_static[lane] : 0.f;
+  const int n_je = 15 * n_expr;
+  for (int k0 = lane; k0 < n_je; k0 += 24 * 64) {      // 24 x 64 = 1536 words: one pass for FLAME's 15 x 100
+    float v[24];
+#pragma unroll
+    for (int u = 0; u < 24; ++u) { const int k = k0 + u * 64; v[u] = k < n_je ? j_expr[k] : 0.f; }
+#pragma unroll
+    for (int u = 0; u < 24; ++u) { const int k = k0 + u * 64; if (k < n_je) s_je[k] = v[u]; }
+  }
+  {
+    const float e0 = lane < n_expr ? e[lane] : 0.f, e1 = lane + 64 < n_expr ? e[lane + 64] : 0.f;
+    if (lane < n_expr) s_e[lane] = e0;
+    if (lane + 64 < n_expr) s_e[lane + 64] = e1;
+  }
   __syncthreads();
   const float* R = sR;
   if (lane < 15) {  // J[j][c] = j_static + sum_k j_expr[j*3+c][k] * e[k]
-    float acc = j_static[lane];
+    float acc = jst;
     const float* row = s_je + lane * n_expr;
     for (int k = 0; k < n_expr; ++k) acc = fma_(row[k], s_e[k], acc);
     sJ[lane] = acc;
@@ -66,7 +80,7 @@ __global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restric
   // coefficient column: expr, then pose features (R_j - I), j = 1..4, row-major, then zero padding
   for (int k = lane; k < k_pad; k += 64) {
     float v = 0.f;
-    if (k < n_expr) v = e[k];
+    if (k < n_expr) v = s_e[k];
     else if (k < n_expr + 36) {
       const int i = (k - n_expr) % 9;
       v = R[9 + (k - n_expr)] - ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f);
@@ -123,17 +137,29 @@ __global__ __launch_bounds__(64) void flame_lbs_kernel(const float* __restrict__
     const float* vs = v_static + (size_t)c * v_pad + strip * 16 + grp * 4;
     acc[c] = f32x4{vs[0], vs[1], vs[2], vs[3]};
   }
-  for (int kt = 0; kt < n_kt; ++kt) {
-    f32x4 a[3];
+  // five k-tiles of operands in flight per pass (the MFMA chain itself stays in ascending k): with one tile per iteration
+  // every iteration was a memory round trip of its own -- nine of them, 12 us alone and 27-31 us beside the Adam pass
+  constexpr int KU = 5;
+  for (int kt0 = 0; kt0 < n_kt; kt0 += KU) {
+    f32x4 a[KU][3];
+    float bv[KU][4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-      a[c] = *reinterpret_cast<const f32x4*>(basis_tiled + ((((size_t)c * n_strips + strip) * n_kt + kt) * 64 + lane) * 4);
+    for (int u = 0; u < KU; ++u) {
+      const int kt = kt0 + u < n_kt ? kt0 + u : n_kt - 1;        // clamped: the surplus loads are not used
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // B operand: lane holds coef[k = 16kt + 4j + grp][frame col]
-      float bv = coef[(size_t)(kt * 16 + j * 4 + grp) * b_pad + cb * 16 + col];
+      for (int c = 0; c < 3; ++c)
+        a[u][c] = *reinterpret_cast<const f32x4*>(basis_tiled + ((((size_t)c * n_strips + strip) * n_kt + kt) * 64 + lane) * 4);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c][j], bv, acc[c], 0, 0, 0);
+      for (int j = 0; j < 4; ++j)   // B operand: lane holds coef[k = 16kt + 4j + grp][frame col]
+        bv[u][j] = coef[(size_t)(kt * 16 + j * 4 + grp) * b_pad + cb * 16 + col];
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (kt0 + u >= n_kt) break;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c][j], bv[u][j], acc[c], 0, 0, 0);
     }
   }
   if (frame >= n_frames) return;
@@ -618,7 +644,7 @@ extern "C" int omfs_adam_flat_multi(int n_tensors, float* const* params, float* 
 extern "C" int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, const float* rotmats, int n_frames,
                                  float* joint_xf, float* coef, const int32_t* frame_index, void* stream) {
   OMFS_REQUIRE(rig && expr && rotmats && joint_xf && coef, "null pointer");
-  OMFS_REQUIRE(n_frames > 0 && rig->n_expr > 0 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36, "shape");
+  OMFS_REQUIRE(n_frames > 0 && rig->n_expr > 0 && rig->n_expr <= 128 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36, "shape");
   int b_pad = cdiv(n_frames, 16) * 16;
   hipLaunchKernelGGL(flame_joints_kernel, dim3(b_pad), dim3(64), 0, (hipStream_t)stream, rig->j_static,
                      rig->j_expr, expr, const_cast<float*>(rotmats), (const float*)nullptr, n_frames, rig->n_expr, rig->k_pad, b_pad,
@@ -630,7 +656,7 @@ extern "C" int omfs_flame_joints(const omfs_flame_rig* rig, const float* expr, c
 extern "C" int omfs_flame_joints_pose(const omfs_flame_rig* rig, const float* expr, const float* pose, float* rotmats, int n_frames,
                                       float* joint_xf, float* coef, const int32_t* frame_index, void* stream) {
   OMFS_REQUIRE(rig && expr && pose && rotmats && joint_xf && coef, "null pointer");
-  OMFS_REQUIRE(n_frames > 0 && rig->n_expr > 0 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36, "shape");
+  OMFS_REQUIRE(n_frames > 0 && rig->n_expr > 0 && rig->n_expr <= 128 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36, "shape");
   int b_pad = cdiv(n_frames, 16) * 16;
   hipLaunchKernelGGL(flame_joints_kernel, dim3(b_pad), dim3(64), 0, (hipStream_t)stream, rig->j_static,
                      rig->j_expr, expr, rotmats, pose, n_frames, rig->n_expr, rig->k_pad, b_pad, joint_xf, coef, frame_index);

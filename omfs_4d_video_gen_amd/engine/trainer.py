@@ -130,6 +130,11 @@ class Trainer:
             cp = np.stack([np.asarray(make_camera_struct(v.camera).cam_pos, np.float32) for v in views])
             self.cam_pos_table = torch.from_numpy(cp).to(self.device)
         self._side_stream = torch.cuda.Stream(device=self.device)
+        # FLAME Adam + the next view's pose: in stream order in front of the Gaussians' Adam pass (default), or forked onto the
+        # side stream beside it (OMFS_FLAME_FORK=1).  Measured at the bench size: alone the four small kernels take 5 + 7 + 12 +
+        # 5 us; beside the bandwidth-bound Adam pass 12 + 23 + 37 + 5 us, ending after it, plus ~13 us for the cross-queue
+        # event to arrive: 1110 against 1101 it/s.
+        self._flame_fork = os.environ.get("OMFS_FLAME_FORK", "0") == "1"
         # whole iterations as hipGraphs (one per view and buffer parity; single GPU): the step-dependent scalars -- position
         # learning rate, Adam bias corrections -- live in an omfs_step_state on the device, advanced by the graph's first node
         self.use_graph = world_size == 1 and os.environ.get("OMFS_STEP_GRAPH", "0") == "1"
@@ -390,7 +395,8 @@ class Trainer:
         if ft is not None:
             ft.begin(view.timestep, self.model.binding, all_timesteps=self.compact_dp)
             if ft_pipe and self._prefetch is not None and self._prefetch[0] == (it, view.timestep):
-                torch.cuda.current_stream().wait_event(self._prefetch[1])
+                if self._prefetch[1] is not None:
+                    torch.cuda.current_stream().wait_event(self._prefetch[1])
                 self.dflame.slot = it & 1
                 verts, face_xf, nb, col, pat = self._prefetch[2]
             else:
@@ -464,20 +470,27 @@ class Trainer:
             rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
             L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
         if ft_pipe:
-            # The three gathers of the FLAME backward stay on this stream: beside the bandwidth-bound Adam pass they run 3-5x
-            # slower (measured: 34 + 28 + 50 us instead of 12 + 8 + 15), which made the chain longer than the pass it
-            # hides under.  What forks are the FLAME Adam and the next view's pose (joints, LBS, triangle frames).
+            # The three gathers of the FLAME backward always stay on this stream: beside the bandwidth-bound Adam pass they run
+            # 3-5x slower (measured: 34 + 28 + 50 us instead of 12 + 8 + 15).  The FLAME Adam and the next view's pose (joints,
+            # LBS, triangle frames) follow in stream order, or fork with OMFS_FLAME_FORK=1 (see __init__).
             ft.backward(verts[col], nb, col)
-            ev_main, ev_side = self._events[it & 1]
-            ev_main.record()
-            with torch.cuda.stream(self._side_stream):
-                self._side_stream.wait_event(ev_main)
+            if self._flame_fork:
+                ev_main, ev_side = self._events[it & 1]
+                ev_main.record()
+                with torch.cuda.stream(self._side_stream):
+                    self._side_stream.wait_event(ev_main)
+                    ft.step(1.0)
+                    nview = self.view_for_step(it + 1)
+                    self.dflame.slot = (it + 1) & 1
+                    nxt = self._pose_frames(it + 1)
+                    ev_side.record(self._side_stream)
+                self._prefetch = ((it + 1, nview.timestep), ev_side, nxt)
+            else:                                   # the same chain in stream order, in front of the Adam pass
                 ft.step(1.0)
                 nview = self.view_for_step(it + 1)
                 self.dflame.slot = (it + 1) & 1
                 nxt = self._pose_frames(it + 1)
-                ev_side.record(self._side_stream)
-            self._prefetch = ((it + 1, nview.timestep), ev_side, nxt)
+                self._prefetch = ((it + 1, nview.timestep), None, nxt)
             self.dflame.slot = it & 1
             tm.mark("flame_bwd")
         elif ft is not None:
