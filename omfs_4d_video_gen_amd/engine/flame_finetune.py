@@ -44,7 +44,14 @@ class FlameFineTuner:
         self.expr = dflame.expr                             # [T][E]   the arrays the forward kernels read
         self.translation = dflame.translation               # [T][3]
         self.params = {"expr": self.expr, "pose": self.pose, "translation": self.translation}
-        self.grad = {k: torch.zeros_like(v) for k, v in self.params.items()}
+        # the three gradient tensors are views of ONE buffer: data-parallel ranks sum them with a single small all-reduce
+        # (three latency-bound collectives per iteration otherwise)
+        sizes = {k: v.numel() for k, v in self.params.items()}
+        self.grad_flat = torch.zeros(sum(sizes.values()), device=dev)
+        self.grad, off = {}, 0
+        for k, v in self.params.items():
+            self.grad[k] = self.grad_flat[off:off + sizes[k]].view(v.shape)
+            off += sizes[k]
         self.m = {k: torch.zeros_like(v) for k, v in self.params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.params.items()}
         self.lr = {**FLAME_LR, **(lr or {})}

@@ -515,8 +515,7 @@ class Trainer:
             else:
                 allreduce_sum_(self.grads, self.pg)
             if ft is not None and not self.compact_dp:   # every rank touched a different timestep: dense (tiny) tensors, summed
-                for gr in ft.grads():
-                    allreduce_sum_(gr, self.pg)
+                allreduce_sum_(ft.grad_flat, self.pg)          # expr, pose, translation gradients: one buffer
             tm.mark("allreduce")
         lr = expon_lr(it, self.pos_lr[0], self.pos_lr[1], self.iterations)
         self.lr_planes[0:3] = lr
@@ -526,8 +525,7 @@ class Trainer:
             self.opt.apply_planes(self.grads, P_SH + 3, NPLANES - (P_SH + 3))     # the rebuilt SH planes
             if ft is not None:
                 from .distributed import allreduce_sum_
-                for gr in ft.grads():
-                    allreduce_sum_(gr, self.pg)
+                allreduce_sum_(ft.grad_flat, self.pg)          # expr, pose, translation gradients: one buffer
             reduce14.wait()
             self.opt.apply_planes(self.grads, 0, P_SH + 3)
         elif self.sharded_dp:
