@@ -81,6 +81,14 @@ __global__ void rate_kernel(float* out, long long* cycles, int iters) {
                         "v_pk_mul_f32 v[48:49], v[48:49], v[56:57]\n v_pk_add_f32 v[50:51], v[50:51], v[56:57]\n"
                         "v_pk_mul_f32 v[52:53], v[52:53], v[56:57]\n v_pk_add_f32 v[54:55], v[54:55], v[56:57]\n"
                         : : : "v40","v41","v42","v43","v44","v45","v46","v47","v48","v49","v50","v51","v52","v53","v54","v55");)
+    } else if (KIND == 15 || KIND == 16 || KIND == 17) {  // fma with a partial execution mask: does the SIMD skip rows (16 lanes) that are all off?
+      const unsigned long long saved = __builtin_amdgcn_read_exec();
+      const unsigned long long mk = KIND == 15 ? 0xFFFFull : (KIND == 16 ? 0xFFFFFFFFull : 0x0000FFFF0000FFFFull);
+      asm volatile("s_mov_b64 exec, %0" : : "s"(mk));
+      REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                        "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+      asm volatile("s_mov_b64 exec, %0" : : "s"(saved));
     } else if (KIND == 12) {  // s_cbranch that is never taken + scalar compare (loop-control idiom)
       REP8(asm volatile("s_cmp_eq_u32 s20, 77\n s_cbranch_scc1 1f\n s_cmp_eq_u32 s20, 78\n s_cbranch_scc1 1f\n"
                         "s_cmp_eq_u32 s20, 79\n s_cbranch_scc1 1f\n s_cmp_eq_u32 s20, 80\n s_cbranch_scc1 1f\n 1:\n"
@@ -133,6 +141,9 @@ int main() {
     run<11>("lds_b128", w, out, cyc);
     run<12>("cmp+branch", w, out, cyc);
     run<13>("pk_fma", w, out, cyc);
+    run<15>("fma_16of64", w, out, cyc);
+    run<16>("fma_32of64", w, out, cyc);
+    run<17>("fma_rows0+2", w, out, cyc);
     run<14>("pk_mul/add", w, out, cyc);
   }
   return 0;
