@@ -443,17 +443,24 @@ __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
   float* dexpr = fa.dexpr; float* dpose = fa.dpose; float* dtrans = fa.dtrans;
   __shared__ float sJ[15], sdJ[15];
   __shared__ float sums[64];
-  __shared__ float part4[4][64];
+  __shared__ float part16[16][64];
   __shared__ float s_dcoef[256];     // dcoef was written by the other blocks: fetched once, by all threads in parallel
   __shared__ float s_pose[15];
   const int lane = threadIdx.x;
   if (lane < n_expr + 36 && lane < 256) s_dcoef[lane] = dcoef[lane];
   if (lane < 15) s_pose[lane] = pose[lane];
-  if (lane < 256) {   // add up the per-wave rows of flame_skin_bwd: thread (w, q) sums value q over the rows r = w (mod 4), in row order
+  {   // add up the per-wave rows of flame_skin_bwd: thread (w, q) of the 1024 sums value q over the rows r = w (mod 16), in row
+      // order, eight loads in flight at a time (the 4-way form walked 21 rows per thread one memory round trip after the other)
     const int w = lane >> 6, q = lane & 63;
     float t = 0.f;
-    for (int r = w; r < n_rows; r += 4) t += partial[(size_t)r * 64 + q];
-    part4[w][q] = t;
+    for (int r0 = w; r0 < n_rows; r0 += 8 * 16) {
+      float pv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int r = r0 + u * 16; pv[u] = r < n_rows ? partial[(size_t)r * 64 + q] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += pv[u];
+    }
+    part16[w][q] = t;
   }
   __shared__ float s_je[15 * 128];   // joint regressor's expression part and the coefficients: one coalesced round trip
   __shared__ float s_e[128];
@@ -475,7 +482,9 @@ __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
   }
   __syncthreads();
   if (lane < 64) {
-    const float t = (part4[0][lane] + part4[1][lane]) + (part4[2][lane] + part4[3][lane]);
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += part16[w][lane];
     sums[lane] = t;
     if (lane >= 60 && lane < 63) dtrans[lane - 60] = t;
   }
