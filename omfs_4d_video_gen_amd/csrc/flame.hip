@@ -248,6 +248,10 @@ __global__ __launch_bounds__(256) void face_frames_bwd_kernel(const float* __res
   const bool live = f < n_faces;
   const int lo = live ? face_start[f] : 0, hi = live ? face_start[f + 1] : 0;
   float acc = 0.f;
+  // the triangle's own vertices: fetched now, used after the gather (two more round trips otherwise)
+  const float4* vb = reinterpret_cast<const float4*>(verts);
+  const int i0 = live ? faces[f * 3 + 0] : 0, i1 = live ? faces[f * 3 + 1] : 0, i2 = live ? faces[f * 3 + 2] : 0;
+  const float4 v0 = vb[i0], v1 = vb[i1], v2 = vb[i2];
   // every row of the wave runs the same number of batches (lane permutes are wave-wide instructions)
   int nb = (hi - lo + 15) >> 4;
 #pragma unroll
@@ -268,9 +272,6 @@ __global__ __launch_bounds__(256) void face_frames_bwd_kernel(const float* __res
 #pragma unroll
   for (int k = 0; k < 13; ++k) g[k] = __shfl(acc, row0 + k, 64);
   if (lo == hi) return;
-  const float4* vb = reinterpret_cast<const float4*>(verts);
-  const int i0 = faces[f * 3 + 0], i1 = faces[f * 3 + 1], i2 = faces[f * 3 + 2];
-  const float4 v0 = vb[i0], v1 = vb[i1], v2 = vb[i2];
   float da0[3] = {g[0], g[3], g[6]}, dn[3] = {g[1], g[4], g[7]}, da2[3] = {g[2], g[5], g[8]};
   const float dc[3] = {g[9], g[10], g[11]};
   const float ds = g[12];
@@ -328,14 +329,17 @@ __global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __rest
                                                              const float* __restrict__ joint_xf, float* __restrict__ dverts,
                                                              int n_verts, float* __restrict__ dv_shaped, float* __restrict__ sums) {
   __shared__ float X[60];
-  if (threadIdx.x < 60) X[threadIdx.x] = joint_xf[threadIdx.x];
-  __syncthreads();
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   const bool on = v < n_verts;
   float w[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, dv[3] = {0.f, 0.f, 0.f}, vs[4] = {0.f, 0.f, 0.f, 1.f};
-  if (on) {
+  float4 d = make_float4(0.f, 0.f, 0.f, 0.f), a = d;
+  if (on) {                // every load of the thread is in flight before the barrier (one memory round trip, not two)
     for (int j = 0; j < 5; ++j) w[j] = lbs_weights[(size_t)v * 8 + j];
-    const float4 d = reinterpret_cast<const float4*>(dverts)[v], a = reinterpret_cast<const float4*>(v_shaped)[v];
+    d = reinterpret_cast<const float4*>(dverts)[v]; a = reinterpret_cast<const float4*>(v_shaped)[v];
+  }
+  if (threadIdx.x < 60) X[threadIdx.x] = joint_xf[threadIdx.x];
+  __syncthreads();
+  if (on) {
     reinterpret_cast<float4*>(dverts)[v] = make_float4(0.f, 0.f, 0.f, 0.f);   // consumed: the next frame's atomics start from zero
     dv[0] = d.x; dv[1] = d.y; dv[2] = d.z;
     vs[0] = a.x; vs[1] = a.y; vs[2] = a.z;
