@@ -294,11 +294,13 @@ __device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* 
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSource ps, int gx, int n_tiles,
                                                                 uint32_t* __restrict__ tile_count,
                                                                 unsigned long long* __restrict__ hits_all,
+                                                                uint2* __restrict__ lists_all,
                                                                 uint32_t* __restrict__ n_visible, uint32_t* __restrict__ status,
                                                                 uint32_t stamp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ uint32_t s_vis;
+  __shared__ uint32_t s_vis, s_nlist;
   if (blockIdx.x == 0 && threadIdx.x == 0) status[1] = hits_all ? stamp : 0u;   // whose tile-test ballots keys_tmp now holds
+  if (threadIdx.x == 0) s_nlist = 0u;
   WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
@@ -314,11 +316,19 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSourc
   unsigned long long* hits = hits_all ? hits_all + ((size_t)blockIdx.x * BIN_WAVES + (threadIdx.x >> 6)) * HITS_PER_WAVE : nullptr;
   for_each_touched_tile_balanced<HITS_RECORD>(wr, total, gx, hits, [&](int t, int) { atomicAdd(&hist[t], 1u); });
   __syncthreads();
+  // the block's non-empty (tile, count) pairs also go to a list of its own behind the ballots (entry 0: their number):
+  // bin_scatter_kernel takes its slot ranges from it instead of walking every rectangle a second time just to count
+  uint2* list = lists_all ? lists_all + (size_t)blockIdx.x * (size_t)(n_tiles + 1) : nullptr;
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) {
     const uint32_t c = hist[t];
-    if (c) atomicAdd(&tile_count[t], c);
+    if (c) {
+      atomicAdd(&tile_count[t], c);
+      if (list) list[1u + atomicAdd(&s_nlist, 1u)] = make_uint2((uint32_t)t, c);
+    }
   }
   if (n_visible && threadIdx.x == 0 && s_vis) atomicAdd(n_visible, s_vis);
+  __syncthreads();
+  if (list && threadIdx.x == 0) list[0] = make_uint2(s_nlist, 0u);
 }
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSource ps, int gx, int n_tiles,
@@ -326,32 +336,55 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_scatter_kernel(int n, PairSou
                                                                   uint32_t* __restrict__ tile_cursor,
                                                                   uint2* __restrict__ keys,
                                                                   unsigned long long* __restrict__ hits_all,
+                                                                  const uint2* __restrict__ lists_all,
                                                                   const uint32_t* __restrict__ status, uint32_t stamp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);  // count, then this block's next slot in the tile
   // the recorded ballots are replayed only if they are the ones omfs_bin_count left for THESE Gaussians and THIS camera
   // (stamp in status[1]; omfs_tile_sort, which reuses keys_tmp, clears it): any other call order recomputes the test
-  if (status[1] != stamp) hits_all = nullptr;
+  if (status[1] != stamp) { hits_all = nullptr; lists_all = nullptr; }
   unsigned long long* hits = hits_all ? hits_all + ((size_t)blockIdx.x * BIN_WAVES + (threadIdx.x >> 6)) * HITS_PER_WAVE : nullptr;
   if (tile_start[n_tiles] == 0u) return;                // nothing visible, or capacity overflow (flagged by the scan)
-  for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
   const int i = bin_gaussian(lane_id());
+  if (lists_all) {
+    // the count kernel left this block's (tile, count) pairs: the slot ranges come straight from them (eight returning
+    // atomics in flight per thread); only the listed tiles' cursors are ever read below, so nothing is zeroed
+    const uint2* list = lists_all + (size_t)blockIdx.x * (size_t)(n_tiles + 1);
+    const int nl = (int)list[0].x;
+    for (int e0 = threadIdx.x; e0 < nl; e0 += 8 * BIN_THREADS) {
+      uint2 tc[8];
+      uint32_t at[8], ts[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const int e = e0 + k * BIN_THREADS; tc[k] = e < nl ? list[1 + e] : make_uint2(0u, 0u); }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        at[k] = tc[k].y ? atomicAdd(&tile_cursor[tc[k].x], tc[k].y) : 0u;
+        ts[k] = tc[k].y ? tile_start[tc[k].x] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (tc[k].y) hist[tc[k].x] = ts[k] + at[k];
+    }
+  } else {
+    for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
+  }
   const uint32_t total = publish_rects(ps, i, n, wr);
   __syncthreads();
-  for_each_touched_tile_balanced<HITS_REPLAY>(wr, total, gx, hits, [&](int t, int) { atomicAdd(&hist[t], 1u); });
-  __syncthreads();
-  // the block's slot ranges: eight returning atomics in flight per thread (one round trip per eight tiles, not one per tile)
-  for (int t0 = threadIdx.x; t0 < n_tiles; t0 += 8 * BIN_THREADS) {
-    uint32_t c[8], at[8];
+  if (!lists_all) {
+    for_each_touched_tile_balanced<HITS_REPLAY>(wr, total, gx, hits, [&](int t, int) { atomicAdd(&hist[t], 1u); });
+    __syncthreads();
+    // the block's slot ranges: eight returning atomics in flight per thread (one round trip per eight tiles, not one per tile)
+    for (int t0 = threadIdx.x; t0 < n_tiles; t0 += 8 * BIN_THREADS) {
+      uint32_t c[8], at[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const int t = t0 + k * BIN_THREADS; c[k] = t < n_tiles ? hist[t] : 0u; }
+      for (int k = 0; k < 8; ++k) { const int t = t0 + k * BIN_THREADS; c[k] = t < n_tiles ? hist[t] : 0u; }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) at[k] = c[k] ? atomicAdd(&tile_cursor[t0 + k * BIN_THREADS], c[k]) : 0u;
+      for (int k = 0; k < 8; ++k) at[k] = c[k] ? atomicAdd(&tile_cursor[t0 + k * BIN_THREADS], c[k]) : 0u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) if (c[k]) hist[t0 + k * BIN_THREADS] = tile_start[t0 + k * BIN_THREADS] + at[k];
+      for (int k = 0; k < 8; ++k) if (c[k]) hist[t0 + k * BIN_THREADS] = tile_start[t0 + k * BIN_THREADS] + at[k];
+    }
+    __syncthreads();
   }
-  __syncthreads();
   for_each_touched_tile_balanced<HITS_REPLAY>(wr, total, gx, hits, [&](int t, int j) {
     const uint32_t pos = atomicAdd(&hist[t], 1u);
     keys[pos] = make_uint2(wr->depth[j], (uint32_t)bin_gaussian(j));
@@ -653,6 +686,13 @@ static unsigned long long* hits_buffer(int n, const omfs_raster_buffers* rb) {
   const size_t need = (size_t)cdiv(n, BIN_THREADS) * BIN_WAVES * HITS_PER_WAVE;
   return need <= (size_t)rb->dup_capacity ? reinterpret_cast<unsigned long long*>(rb->keys_tmp) : nullptr;
 }
+// ... followed by one list of (tile, count) pairs per workgroup of the count kernel (n_tiles + 1 entries each); NULL when
+// keys_tmp cannot hold them (the scatter then counts for itself)
+static uint2* lists_buffer(int n, int n_tiles, const omfs_raster_buffers* rb) {
+  const size_t blocks = (size_t)cdiv(n, BIN_THREADS), hits = blocks * BIN_WAVES * HITS_PER_WAVE;
+  const size_t need = hits + blocks * (size_t)(n_tiles + 1);
+  return need <= (size_t)rb->dup_capacity ? reinterpret_cast<uint2*>(rb->keys_tmp) + hits : nullptr;
+}
 
 // identifies (Gaussian set, camera) of a bin_count / bin_scatter pair: FNV-1a over the words both calls are given; never 0
 static uint32_t hits_stamp(const omfs_gaussians* g, const omfs_camera* cam) {
@@ -689,7 +729,7 @@ extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, c
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = ensure_max_lds((const void*)bin_count_kernel, 159 * 1024, attr_done)) return rc;   // + a static word
     hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles, rb->tile_count,
-                       hits_buffer(g->n, rb), rb->n_visible, rb->status, hits_stamp(g, cam));
+                       hits_buffer(g->n, rb), lists_buffer(g->n, n_tiles, rb), rb->n_visible, rb->status, hits_stamp(g, cam));
   } else {
     hipLaunchKernelGGL(bin_count_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, rb->tile_count, rb->n_visible);
   }
@@ -722,7 +762,8 @@ extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam,
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = ensure_max_lds((const void*)bin_scatter_kernel, 160 * 1024, attr_done)) return rc;
     hipLaunchKernelGGL(bin_scatter_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles,
-                       rb->tile_start, rb->tile_cursor, (uint2*)rb->keys, hits_buffer(g->n, rb), rb->status, hits_stamp(g, cam));
+                       rb->tile_start, rb->tile_cursor, (uint2*)rb->keys, hits_buffer(g->n, rb), lists_buffer(g->n, n_tiles, rb), rb->status,
+                       hits_stamp(g, cam));
   } else {
     hipLaunchKernelGGL(bin_scatter_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, n_tiles,
                        rb->tile_start, rb->tile_cursor, (uint2*)rb->keys);
