@@ -197,9 +197,10 @@ int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_c
  *  scan    : tile_count -> tile_start (exclusive scan), tile_order, zeroed tile_cursor; tile_count is consumed (left
  *            zeroed for the next view: it must be zero before the first omfs_bin_count)
  *  scatter : (depth bits, id) pairs into their tile's segment of keys; REPLAYS the tile-test outcomes that the
- *            omfs_bin_count of the same view recorded in keys_tmp (one 64-bit ballot per walk step) when status[1]
+ *            omfs_bin_count of the same view recorded in keys_tmp (one 64-bit ballot per walk step, followed by every
+ *            workgroup's list of non-empty (tile, count) pairs, from which the slot ranges are taken) when status[1]
  *            still carries that call's stamp (same g->n, g->params and camera, no omfs_tile_sort in between); in any
- *            other call order the test is re-evaluated (slower, same result)
+ *            other call order the test is re-evaluated and the pairs are counted again (slower, same result)
  *  sort    : per-tile sort by (depth bits, id) -> sorted_ids (keys_tmp is scratch again from here on)       */
 int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
