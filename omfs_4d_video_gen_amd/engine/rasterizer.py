@@ -46,7 +46,10 @@ class Rasterizer:
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
         self.n_tiles = self.gx * self.gy
         # 288 GB of HBM: be generous rather than re-allocate; overflow is flagged by the device
-        self.dup_capacity = int(dup_capacity if dup_capacity else max(1 << 20, 48 * n))
+        # default capacity: 48 pairs per Gaussian at 1080p, growing with the image area beyond that (a splat covers four times
+        # as many tiles at 3840x2160); exceeding it is flagged by the device, engine/train.py grows the buffers
+        area = max(1.0, (width * height) / float(1920 * 1080))
+        self.dup_capacity = int(dup_capacity if dup_capacity else max(1 << 20, int(48 * n * area)))
         dev = self.device
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
         self.g0, self.g1, self.g2 = z(n, 4), z(n, 4), z(n, 4)
