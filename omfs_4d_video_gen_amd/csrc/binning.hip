@@ -52,6 +52,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
   __shared__ uint32_t wave_tot[16];
   __shared__ unsigned long long bucket_acc[33];   // low: tiles in the bucket, high: their segments; then running bases
   __shared__ uint32_t carry;                      // tiles / pairs of the chunks before (images with > 8192 tiles)
+  __shared__ uint32_t s_nonempty, s_total_segs, carry_e;   // empty tiles take no atomic: they follow the others in index order
   extern __shared__ __attribute__((aligned(16))) uint32_t scan_lds[];
   uint32_t* s_a = scan_lds;                       // counts, then tile_start
   uint32_t* s_b = scan_lds + 1024 * SCAN_PER;     // tile_order by position
@@ -99,8 +100,9 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
       if (beg + k < n_tiles) {
         if (!single) { tile_start[beg + k] = run; tile_cursor[beg + k] = 0; }   // rewritten as 0 below if the capacity overflows
         const uint32_t c = cnt[k];
-        const int bucket = c ? (32 - __clz(c)) : 0;  // 0..32, larger = more work
-        atomicAdd(&bucket_acc[32 - bucket], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
+        // empty tiles (more than half of them at 1080p) are not counted here: all lanes hitting the one counter of the empty
+        // class serialised in the LDS atomic unit, and their place in the launch order needs no counter (pass B)
+        if (c) atomicAdd(&bucket_acc[32 - (32 - __clz(c))], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
         run += c;
       }
     }
@@ -126,24 +128,54 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, uint32_t* 
       r += v;
     }
     order_seg0[n_tiles] = overflow ? 0u : (uint32_t)(r >> 32);
+    s_nonempty = (uint32_t)r;                       // tiles with a list: the empty ones are placed behind them
+    s_total_segs = overflow ? 0u : (uint32_t)(r >> 32);
+    carry_e = 0u;
   }
   __syncthreads();
   // ---- pass B: positions in the launch order (+ segment prefix); counts are re-read only for images with > 8192 tiles
+  const uint32_t n_nonempty = s_nonempty, total_segs = s_total_segs;
   for (int c0 = 0; c0 < n_tiles; c0 += 1024 * SCAN_PER) {
     const int beg = c0 + tid * SCAN_PER;
+    uint32_t cb[SCAN_PER], n_e = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER; ++k) {
+      cb[k] = 0u;
+      if (beg + k < n_tiles) {
+        cb[k] = single ? cnt[k] : tile_count[beg + k];
+        if (!single) tile_count[beg + k] = 0;          // consumed: the next frame's omfs_bin_count accumulates from zero
+        if (overflow) { cb[k] = 0; if (!single) tile_start[beg + k] = 0; }
+        n_e += cb[k] == 0u;
+      }
+    }
+    // rank of this thread's first empty tile among the empty tiles (index order): one more block scan per chunk
+    const uint32_t incl_e = wave_incl_scan_u32_dpp(n_e);
+    if (lane == 63) wave_tot[wave] = incl_e;
+    __syncthreads();
+    uint32_t e_rank = carry_e + incl_e - n_e, chunk_e = 0;
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t v = wave_tot[w];
+      if (w < wave) e_rank += v;
+      chunk_e += v;
+    }
 #pragma unroll
     for (int k = 0; k < SCAN_PER; ++k) {
       if (beg + k < n_tiles) {
-        uint32_t c = single ? cnt[k] : tile_count[beg + k];
-        if (!single) tile_count[beg + k] = 0;          // consumed: the next frame's omfs_bin_count accumulates from zero
-        if (overflow) { c = 0; if (!single) tile_start[beg + k] = 0; }
-        const int bucket = c ? (32 - __clz(c)) : 0;
-        const unsigned long long old = atomicAdd(&bucket_acc[32 - bucket], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
-        const uint32_t pos = (uint32_t)old;
-        if (single) { s_b[pos] = (uint32_t)(beg + k); s_c[pos] = (uint32_t)(old >> 32); }
-        else { tile_order[pos] = (uint32_t)(beg + k); order_seg0[pos] = (uint32_t)(old >> 32); }
+        const uint32_t c = cb[k];
+        uint32_t pos, seg;
+        if (c) {
+          const unsigned long long old = atomicAdd(&bucket_acc[32 - (32 - __clz(c))], 1ull | ((unsigned long long)((c + OMFS_SEG - 1) / OMFS_SEG) << 32));
+          pos = (uint32_t)old; seg = (uint32_t)(old >> 32);
+        } else {
+          pos = n_nonempty + e_rank++; seg = total_segs;
+        }
+        if (single) { s_b[pos] = (uint32_t)(beg + k); s_c[pos] = seg; }
+        else { tile_order[pos] = (uint32_t)(beg + k); order_seg0[pos] = seg; }
       }
     }
+    __syncthreads();                               // wave_tot and carry_e are reused by the next chunk
+    if (tid == 0) carry_e += chunk_e;
+    __syncthreads();
   }
   if (single) {
     __syncthreads();
