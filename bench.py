@@ -75,11 +75,12 @@ def host_cores() -> int:
     return max(1, min(n, 64))
 
 
-def cpu_baseline_train(n_s, w_s, h_s, views=16):
-    """CPU restatement of ONE full training iteration at the bench workload itself (same seeded scene, FLAME fine-tuning on):
-    FLAME pose + projection + tile test + binning + per-tile sort by the plain-C bit-level oracle (oracle/splat_oracle.c,
-    one core), then composite, L1 + D-SSIM, autograd backward down to the FLAME parameters and Adam by the PyTorch-CPU
-    oracle (oracle/torch_splat.py, all usable cores).  Returns (seconds, D)."""
+def cpu_baseline_train(snap):
+    """CPU restatement of ONE full training iteration of the bench workload itself, on the SAME state the GPU line reports:
+    `snap` holds the Gaussian parameters, the (fine-tuned) FLAME sequence, the camera / timestep and the target of the step
+    whose tile-pair count D the JSON line carries.  FLAME pose + projection + tile test + binning + per-tile sort by the
+    plain-C bit-level oracle (oracle/splat_oracle.c, one core), then composite, L1 + D-SSIM, autograd backward down to the
+    FLAME parameters and Adam by the PyTorch-CPU oracle (oracle/torch_splat.py, all usable cores).  Returns (seconds, D)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle import c_oracle as CO
     from oracle import torch_splat as O
@@ -89,11 +90,9 @@ def cpu_baseline_train(n_s, w_s, h_s, views=16):
     from omfs_4d_video_gen_amd.engine.rasterizer import make_camera_struct
     torch.set_num_threads(host_cores())
     rig = synthetic.make_rig(0)
-    g = synthetic.make_gaussians(n_s, rig.faces.shape[0], 0)
-    seq = synthetic.make_flame_sequence(max(views, 2), 0)
-    cam = synthetic.make_camera_arc(w_s, h_s, views)[1 % views]
-    t = 1
-    dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq)          # host arrays for the C oracle (inputs already resident)
+    g, seq, cam, t, target = snap["gaussians"], snap["seq"], snap["camera"], snap["timestep"], snap["target"]
+    n_s, (h_s, w_s) = int(g["xyz"].shape[0]), target.shape[1:]
+    dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq, device="cpu")   # host arrays for the C oracle (inputs already resident)
     ccam = CO.camera(make_camera_struct(cam, sh_degree=3))
     params = pack_params(g)
     org = {"v_template": torch.from_numpy(rig.v_template), "shapedirs": torch.from_numpy(rig.shapedirs),
@@ -107,7 +106,6 @@ def cpu_baseline_train(n_s, w_s, h_s, views=16):
     names = ("xyz", "log_scale", "rot", "opacity", "sh")
     for k in names:
         og[k].requires_grad_(True)
-    target = torch.rand(3, h_s, w_s)
     m = {k: torch.zeros_like(og[k]) for k in names}
     v = {k: torch.zeros_like(og[k]) for k in names}
     t0 = time.perf_counter()
@@ -263,6 +261,18 @@ def main():
     stages = trainer.timer.summary()
     log("stage timing done: " + ", ".join(f"{k}={v[0]:.3f}" for k, v in stages.items()))
     trainer.timer = StageTimer(False)
+    # The step whose tile-pair count D, visit count and (rank 0, one GPU) CPU-baseline sample the line reports: the state in
+    # front of it is copied to the host, then it runs like every other step.
+    torch.cuda.synchronize()
+    snap = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from omfs_4d_video_gen_amd.engine.distributed import view_index
+        sv = views[view_index(trainer.step_idx, rank, world, len(views), trainer.view_seed)]
+        snap = {"gaussians": trainer.model.to_dict(),
+                "seq": trainer.flame_ft.to_flame_params(seq) if trainer.flame_ft is not None else seq,
+                "camera": sv.camera, "timestep": sv.timestep, "target": sv.target.float().cpu()}
+    trainer.step()
+    torch.cuda.synchronize()
     D = int(trainer.rast.tile_start[-1].item())
     n_contrib = trainer.rast.n_contrib
     P = W * H
@@ -277,6 +287,11 @@ def main():
     sb["flame"] = 0 if getattr(trainer, "_frames_all", None) is not None else \
         trainer.dflame.k_pad * trainer.dflame.v_pad * 3 * 4 + trainer.dflame.v_pad * 16 + F * (64 + 12)
     sb["flame_bwd"] = N * 64 + F * 48 + trainer.dflame.v_pad * 76 + trainer.dflame.k_pad * trainer.dflame.v_pad * 3 * 4
+    if trainer.flame_ft is not None and world == 1:
+        # fine-tuning on one GPU: the FLAME Adam and the pose of the NEXT view (joints, LBS, frames) are enqueued behind the
+        # FLAME backward, i.e. inside the `flame_bwd` stage; the `flame` stage only picks the prefetched buffers up (no kernel)
+        sb["flame_bwd"] += sb["flame"]
+        sb["flame"] = 0
     # the dominant KERNEL stage (with more than one rank the "adam" stage also waits for the collectives: not a kernel time)
     # Among equals a stage that is ONE kernel is preferred: its time can be compared directly with the per-kernel average of a trace.
     multi_kernel = {"composite_fwd": 2, "loss": 3, "tile_sort": 2, "flame": 3, "flame_bwd": 3}
@@ -306,6 +321,10 @@ def main():
         for kname, vals in json.load(open(mix)).items():
             if f"{dom}_kernel" in kname and "valu_issue_util" in vals:
                 roofline["valu_issue_util"] = vals["valu_issue_util"]
+                # `bound` names the roofline the fraction is priced against (the contract's hbm | mfma); `limiter` is what the
+                # counters say actually holds the kernel
+                roofline["limiter"] = "valu_issue" if vals["valu_issue_util"] >= 0.6 else "latency / memory"
+
                 roofline["valu_note"] = "SQ_ACTIVE_INST_VALU*4/(1024 SIMDs x kernel cycles), " + os.path.basename(mix)
     except Exception:
         pass
@@ -336,8 +355,10 @@ def main():
 
     # ---- aux: render_surgery fps on the same scene (frames shard across ranks, no collective)
     if not args.no_aux:
-        rr = Renderer(rig, seq, g_init, W, H, coherent_order=args.coherent_order)
-        frames = [View(cams[i % len(cams)], timestep=i % T) for i in range(rank, args.render_frames, world)]
+        # config 3: a render_frames-timestep FLAME sequence (every frame its own pose), cameras cycling over the arc
+        seq_r = synthetic.make_flame_sequence(args.render_frames, 0)
+        rr = Renderer(rig, seq_r, g_init, W, H, coherent_order=args.coherent_order)
+        frames = [View(cams[i % len(cams)], timestep=i) for i in range(rank, args.render_frames, world)]
         for v in frames[:5]:
             rr.render(v, rgb8=True)
         torch.cuda.synchronize(); barrier()
@@ -353,7 +374,8 @@ def main():
             dtr = float(tt.item())
         log("render aux done")
         out["aux"] = {"render_surgery_fps": round(args.render_frames / dtr, 2),
-                      "render_note": f"{args.render_frames} frames {W}x{H}, {N} Gaussians, GPU-resident rgb8 output, PNG encode excluded"}
+                      "render_note": f"{args.render_frames} frames of a {args.render_frames}-timestep FLAME sequence, {W}x{H}, {N} Gaussians, "
+                                     f"FLAME posed {rr.flame_batch} timesteps per pass, GPU-resident rgb8 output, PNG encode excluded"}
         if world == 1:
             # the same loop with the PNG egress render.py uses (device->host copy + zlib level 1 on a thread pool), bounded sample
             from concurrent.futures import ThreadPoolExecutor
@@ -467,14 +489,15 @@ def main():
 
     # ---- CPU baseline (rank 0, single GPU run only): the PyTorch-CPU oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sec, D_s = cpu_baseline_train(N, W, H, args.views)
-        log(f"cpu baseline done: {sec:.2f}s")
+        sec, D_s = cpu_baseline_train(snap)
+        log(f"cpu baseline done: {sec:.2f}s, D_cpu={D_s} D_gpu={D}")
         out["cpu_baseline"] = {
             "value": round(1.0 / sec, 6), "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 full training iteration of the bench workload itself, not extrapolated ({N} Gaussians {W}x{H}, D={D_s} tile pairs, "
+            "sample": f"1 full training iteration of the bench workload itself, not extrapolated, on the parameter state, view and target of the "
+                      f"GPU step that config.tile_pairs_D is read from ({N} Gaussians {W}x{H}, D={D_s} tile pairs, "
                       f"FLAME fine-tuning on): pose/project/bin/sort by the C oracle (oracle/splat_oracle.c, 1 core), composite + "
                       f"L1/D-SSIM + autograd backward + Adam by the PyTorch-CPU oracle (oracle/torch_splat.py, {torch.get_num_threads()} threads): {sec:.2f} s",
-            "sample_seconds": round(sec, 3)}
+            "sample_seconds": round(sec, 3), "D": D_s, "D_equals_gpu_tile_pairs_D": bool(D_s == D)}
     if world > 1:
         from omfs_4d_video_gen_amd.engine.distributed import replicas_in_sync
         out["replicas_in_sync"] = replicas_in_sync(trainer.model.params)

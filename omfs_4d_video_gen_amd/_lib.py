@@ -90,8 +90,15 @@ class LrScheduleC(C.Structure):
     _fields_ = [("lr_init", C.c_float), ("lr_final", C.c_float), ("max_steps", C.c_int), ("beta1", C.c_float), ("beta2", C.c_float)]
 
 
-STEP_STATE_WORDS = 16     # omfs_step_state: device memory (int32 step, int32 flame_step, 5 floats, int32 table_base, padding)
-STEP_STATE_TABLE_BASE = 7
+class StepStateC(C.Structure):
+    """omfs_step_state lives in DEVICE memory (the trainer keeps it as an int32 tensor); this mirror states its layout."""
+    _fields_ = [("step", C.c_int32), ("flame_step", C.c_int32), ("lr_xyz", C.c_float), ("inv_bc1", C.c_float),
+                ("inv_sqrt_bc2", C.c_float), ("flame_inv_bc1", C.c_float), ("flame_inv_sqrt_bc2", C.c_float),
+                ("table_base", C.c_int32), ("reserved", C.c_float * 8)]
+
+
+STEP_STATE_WORDS = C.sizeof(StepStateC) // 4
+STEP_STATE_TABLE_BASE = StepStateC.table_base.offset // 4
 
 
 class FlameFitC(C.Structure):

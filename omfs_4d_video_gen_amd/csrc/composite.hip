@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
 }
 
 #ifdef OMFS_DEBUG_COUNTERS
-__device__ unsigned long long omfs_dbg[8];   // bwd: visits, visits with a hit, hit lanes; fwd: visits, visits with a hit, hit lanes
+__device__ unsigned long long omfs_dbg[32];   // bwd: visits, visits with a hit, hit lanes; fwd: visits, visits with a hit, hit lanes
 #define OMFS_DBG_ADD(i, v) do { if (lane_id() == 0) atomicAdd(&omfs_dbg[i], (unsigned long long)(v)); } while (0)
 #else
 #define OMFS_DBG_ADD(i, v) do { } while (0)
@@ -276,7 +276,12 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
       for (int u = 0; u < 4; ++u) {
         const float alpha = ar[u] * open;
 #ifdef OMFS_DEBUG_COUNTERS
-        { const unsigned long long hb = __ballot(alpha > 0.f); OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb)); }
+        { const unsigned long long hb = __ballot(alpha > 0.f); OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb));
+          if (jx[u]) {
+            int nsb = 0, nfl = 0;
+            for (int sb = 0; sb < 4; ++sb) { nsb += (hb & sbl[sb]) != 0ull; nfl += ((ms[sb] >> (jx[u] - 1)) & 1ull) && (live & sbl[sb]); }
+            OMFS_DBG_ADD(16, 1); OMFS_DBG_ADD(17, nsb); OMFS_DBG_ADD(18, nfl); OMFS_DBG_ADD(19, __popcll(__ballot(ar[u] > 0.f)));
+          } }
 #endif
         const float Tn = T * (1.f - alpha);
         // the splat that would take T below the threshold is not composited: weight 0, T and last stay, the pixel is done
@@ -710,6 +715,9 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
       r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
     }
   }
+#ifdef OMFS_DEBUG_COUNTERS
+  int rowtot_dbg[4] = {0, 0, 0, 0};
+#endif
   for (int st = n_steps - 1; st >= 0; --st) {
     const uint32_t cbase = (uint32_t)st * WB;                       // list position of bit 0, 0-based
     const int cnt = (int)min((uint32_t)WB, n_visit - cbase);
@@ -727,14 +735,27 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
     // splats worth visiting: can touch a sub-block one of whose pixels has its last contributor at or
     // behind the splat (list position <= that sub-block's maximum)
     unsigned long long m = 0ull;
+#ifdef OMFS_DEBUG_COUNTERS
+    unsigned long long mr_dbg[4] = {0ull, 0ull, 0ull, 0ull};
+#endif
 #pragma unroll
     for (int sb = 0; sb < 4; ++sb) {
       const unsigned long long bal = __ballot((mask >> sb) & 1u);
       if (smax[sb] > cbase) {
         const uint32_t lim = smax[sb] - cbase;
         m |= bal & (lim >= 64u ? ~0ull : ((1ull << lim) - 1ull));
+#ifdef OMFS_DEBUG_COUNTERS
+        mr_dbg[sb] = bal & (lim >= 64u ? ~0ull : ((1ull << lim) - 1ull));
+#endif
       }
     }
+#ifdef OMFS_DEBUG_COUNTERS
+    {
+      const int p0 = __popcll(mr_dbg[0]), p1 = __popcll(mr_dbg[1]), p2_ = __popcll(mr_dbg[2]), p3 = __popcll(mr_dbg[3]);
+      OMFS_DBG_ADD(8, __popcll(m)); OMFS_DBG_ADD(9, max(max(p0, p1), max(p2_, p3))); OMFS_DBG_ADD(10, p0 + p1 + p2_ + p3);
+      rowtot_dbg[0] += p0; rowtot_dbg[1] += p1; rowtot_dbg[2] += p2_; rowtot_dbg[3] += p3;
+    }
+#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (st > 0) {   // every earlier step is full
@@ -763,6 +784,15 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
       const bool hit = contributor <= last && p2 <= 0.f && e >= LOG2_INV255;
       const unsigned long long hit_bal = __ballot(hit);
       OMFS_DBG_ADD(0, 1); OMFS_DBG_ADD(1, hit_bal != 0ull); OMFS_DBG_ADD(2, __popcll(hit_bal));
+#ifdef OMFS_DEBUG_COUNTERS
+      {
+        const unsigned long long geo = __ballot(p2 <= 0.f && e >= LOG2_INV255);
+        OMFS_DBG_ADD(12, __popcll(geo));
+        int nsb = 0;
+        for (int sb = 0; sb < 4; ++sb) nsb += (hit_bal & __ballot(sidx == sb)) != 0ull;
+        OMFS_DBG_ADD(13, nsb);
+      }
+#endif
       if (hit_bal == 0ull) return;    // nobody in this quadrant was touched: nothing to reduce
       {
         // Branch-free: G is masked to 0 for lanes that are not hit, which makes alpha = 0, 1/(1-alpha) = 1 and every
@@ -809,6 +839,10 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
     }
   }
   if (n_pending) flush_pending();
+#ifdef OMFS_DEBUG_COUNTERS
+  OMFS_DBG_ADD(11, max(max(rowtot_dbg[0], rowtot_dbg[1]), max(rowtot_dbg[2], rowtot_dbg[3])));
+  OMFS_DBG_ADD(14, 1);
+#endif
 }
 
 __global__ void image_to_rgb8_kernel(const float* __restrict__ image, int width, int height, uint8_t* __restrict__ rgb8) {
@@ -931,8 +965,8 @@ extern "C" int omfs_debug_timeline(int kernel, unsigned long long* out, int n, i
 
 #ifdef OMFS_DEBUG_COUNTERS
 extern "C" int omfs_debug_counters(unsigned long long* out8, int reset) {
-  OMFS_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(omfs_dbg), 64));
-  if (reset) { unsigned long long z[8] = {0}; OMFS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(omfs_dbg), z, 64)); }
+  OMFS_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(omfs_dbg), 256));
+  if (reset) { unsigned long long z[32] = {0}; OMFS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(omfs_dbg), z, 256)); }
   return OMFS_OK;
 }
 #endif

@@ -44,7 +44,13 @@ def test_struct_layouts_match_the_header():
     from omfs_4d_video_gen_amd import _lib as L
     names = {"omfs_flame_rig": L.FlameRigC, "omfs_simpleflame": L.SimpleFlameC, "omfs_camera": L.CameraC, "omfs_gaussians": L.GaussiansC,
              "omfs_raster_buffers": L.RasterBuffersC, "omfs_grad_buffers": L.GradBuffersC, "omfs_reg_params": L.RegParamsC,
-             "omfs_adam_params": L.AdamParamsC}
+             "omfs_adam_params": L.AdamParamsC, "omfs_view_set": L.ViewSetC, "omfs_view_step": L.ViewStepC,
+             "omfs_lr_schedule": L.LrScheduleC, "omfs_flame_fit": L.FlameFitC, "omfs_densify_params": L.DensifyParamsC,
+             "omfs_step_state": L.StepStateC}
+    # every struct the header declares has a ctypes mirror here: a struct added to the ABI must be added to this table
+    import re
+    declared = set(re.findall(r"^}\s*(omfs_\w+);", (ROOT / "include" / "omfs_splat.h").read_text(), flags=re.M))
+    assert declared == set(names), declared ^ set(names)
     src = '#include <stdio.h>\n#include "omfs_splat.h"\nint main(){' + "".join(f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
         (Path(d) / "s.c").write_text(src)

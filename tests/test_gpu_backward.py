@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 GROUPS = {"xyz": (0, 3), "log_scale": (3, 6), "rot": (6, 10), "opacity": (10, 11), "sh": (11, 59)}
 
 
-def _scene(n, width, height, seed=0, big_scale=False):
+def _scene(n, width, height, seed=0, big_scale=False, identity=False):
     from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig, DeviceFlame
     from omfs_4d_video_gen_amd.engine.gaussians import GaussianModel
     from omfs_4d_video_gen_amd.engine.rasterizer import Rasterizer, make_camera_struct
@@ -23,8 +23,8 @@ def _scene(n, width, height, seed=0, big_scale=False):
     if big_scale:   # push some Gaussians over the regulariser thresholds
         g["log_scale"][: n // 4] += 1.0
         g["xyz"][: n // 8] *= 6.0
-    seq = synthetic.make_flame_sequence(3, seed)
-    cam = synthetic.make_camera(width, height, yaw=0.25)
+    seq = synthetic.make_flame_sequence(3, seed, identity=identity)
+    cam = synthetic.make_camera(width, height, yaw=0.0 if identity else 0.25)
     dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq)
     return rig, g, seq, cam, dflame, GaussianModel(g), Rasterizer(n, width, height), make_camera_struct
 
@@ -37,10 +37,12 @@ def _grads_to_groups(grads, n):
 
 @pytest.mark.parametrize("n,width,height,bg,big", [(1200, 80, 64, (1.0, 1.0, 1.0), False), (3000, 128, 96, (0.1, 0.2, 0.3), True),
                                                    (16000, 64, 48, (0.3, 0.1, 0.2), False),    # deep lists
+                                                   (5000, 256, 256, (0.0, 0.0, 0.0), False),   # BASELINE config 1 at its stated size (identity pose)
                                                    (40000, 448, 252, (0.0, 0.0, 0.0), False)])   # as large as autograd takes in a few seconds
 def test_backward_matches_autograd(n, width, height, bg, big):
     from oracle import torch_splat as O
-    rig, g, seq, cam, dflame, model, rast, mk = _scene(n, width, height, seed=4, big_scale=big)
+    config1 = (n, width, height) == (5000, 256, 256)
+    rig, g, seq, cam, dflame, model, rast, mk = _scene(n, width, height, seed=0 if config1 else 4, big_scale=big, identity=config1)
     t = 1
     _, face_xf = dflame.face_frames(t, 1)
     ccam = mk(cam, sh_degree=3, bg=bg)

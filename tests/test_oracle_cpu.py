@@ -56,6 +56,24 @@ def test_oracle_identity_pose_plumbing(rig_small):
     assert out["image"].shape == (3, 64, 64) and float(out["image"].max()) > 0.05
 
 
+def test_config1_at_its_stated_size_on_the_cpu(rig_small):
+    """BASELINE config 1 as stated: a single 256x256 frame, 5 k Gaussians, identity FLAME pose, forward splat on the CPU --
+    the PyTorch oracle and the C oracle (the bit-level spec the HIP path is held to in tests/test_gpu_bitexact.py) agree."""
+    rig = rig_small
+    n, W, Hh = 5000, 256, 256
+    g = synthetic.make_gaussians(n, rig.faces.shape[0], 0)
+    seq = synthetic.make_flame_sequence(1, 0, identity=True)
+    cam = synthetic.make_camera(W, Hh, yaw=0.0)
+    t = O.render(H.oracle_rig(rig), H.oracle_gaussians(g), H.oracle_frame(seq, 0), cam, sh_degree=3)
+    assert torch.allclose(t["verts"], torch.from_numpy(rig.v_template), atol=1e-7)
+    dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq, device="cpu")
+    ccam = make_camera_struct(cam, sh_degree=3, bg=(0.0, 0.0, 0.0))
+    c = CO.render(dflame, 0, pack_params(g), g["binding"], n, CO.camera(ccam))
+    assert np.allclose(c["verts"], rig.v_template, atol=1e-7)      # skinning weights sum to 1 up to an ulp
+    assert np.abs(c["image"] - t["image"].numpy()).mean() < 1e-4
+    assert float(t["image"].max()) > 0.05 and len(c["ids"]) > n
+
+
 def test_tile_culling_does_not_change_the_image(rig_small):
     """The engine drops (Gaussian, tile) pairs that cannot reach alpha >= 1/255 inside the tile.
     The composite of the culled lists must be BIT-IDENTICAL to the composite of the upstream-style

@@ -16,7 +16,7 @@ t = Trainer(rig, seq, g0, views, W, H, start_sh_degree=3)
 for _ in range(20): t.step()
 torch.cuda.synchronize()
 lib = L.load()._lib if hasattr(L.load(), "_lib") else L.load()
-buf = (ctypes.c_ulonglong * 8)()
+buf = (ctypes.c_ulonglong * 32)()
 cd = ctypes.CDLL(os.path.join(os.path.dirname(L.__file__), "libomfs_splat.so"))
 cd.omfs_debug_counters(buf, 1)
 for _ in range(16): t.step()
@@ -25,3 +25,8 @@ cd.omfs_debug_counters(buf, 0)
 b = [x / 16 for x in buf]
 print("bwd: visits %.0f, with hit %.0f (%.1f%%), hit lanes per hit-visit %.1f" % (b[0], b[1], 100 * b[1] / b[0], b[2] / max(b[1], 1)))
 print("fwd(F1): visits %.0f, with hit %.0f (%.1f%%), hit lanes per hit-visit %.1f" % (b[3], b[4], 100 * b[4] / b[3], b[5] / max(b[4], 1)))
+print("bwd per-step: union %.0f, max_row %.0f (%.3f of union), sum_rows %.0f (k = %.2f sub-blocks per visit); per-wave max row total %.0f (%.3f of union); waves %.0f"
+      % (b[8], b[9], b[9] / b[8], b[10], b[10] / b[8], b[11], b[11] / b[8], b[14]))
+print("bwd: geometric hit lanes per visit %.1f, hit lanes per visit %.1f, sub-blocks with a hit per visit %.2f" % (b[12] / b[0], b[2] / b[0], b[13] / b[0]))
+print("fwd: real visits %.0f, sub-blocks with a hit per visit %.2f, flagged live sub-blocks per visit %.2f, geometric hit lanes %.1f, hit lanes %.1f"
+      % (b[16], b[17] / b[16], b[18] / b[16], b[19] / b[16], b[5] / b[16]))
