@@ -733,7 +733,7 @@ extern "C" int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basi
                                     const float* expr, const float* pose, const float* sums, float* dcoef, float* dexpr,
                                     float* dpose, float* dtrans, void* stream) {
   OMFS_REQUIRE(rig && basis_dense && dv_shaped && expr && pose && sums && dcoef && dexpr && dpose && dtrans, "null pointer");
-  OMFS_REQUIRE(n_coef == rig->n_expr + 36 && n_coef <= 256 && rig->j_static && rig->j_expr, "shape");
+  OMFS_REQUIRE(n_coef == rig->n_expr + 36 && n_coef <= 256 && rig->n_expr <= 128 && rig->j_static && rig->j_expr, "shape");
   hipStream_t s = (hipStream_t)stream;
   FrontArgs fa{rig->j_static, rig->j_expr, expr, pose, rig->n_expr, sums, cdiv(rig->n_verts, 256) * 4, dexpr, dpose, dtrans};
   hipLaunchKernelGGL(basis_t_gemv_kernel, dim3(n_coef), dim3(GEMV_NT), 0, s, basis_dense, dv_shaped, 3 * rig->n_verts, dcoef, fa);

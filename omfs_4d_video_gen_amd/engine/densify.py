@@ -61,6 +61,7 @@ class DensityController:
     def densify_and_prune(self, iteration: int, size_prune: bool = False) -> dict:
         t, m = self.t, self.t.model
         n, dev = m.n, m.params.device
+        t.sync_optimizer_state()       # "sharded" exchange: the compaction below reads every Gaussian's moments
         stats = t.densify_stats
         if t.world > 1:
             from .distributed import allreduce_sum_

@@ -254,6 +254,8 @@ def main(argv=None):
                 np.savez(pc_dir / "flame_param_source.npz", **split["flame"])
             else:
                 np.savez(pc_dir / "flame_param.npz", **split["flame"])
+        if it in ckpt_at:
+            trainer.sync_optimizer_state()     # every rank (a collective in the "sharded" exchange): rank 0 saves WHOLE moments
         if rank == 0 and it in ckpt_at:
             print(f"\n[ITER {it}] Saving Checkpoint", flush=True)
             # per-Gaussian columns in the order the cloud was given in (not the trainer's storage order): a resumed run lays

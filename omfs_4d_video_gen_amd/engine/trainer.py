@@ -205,7 +205,7 @@ class Trainer:
     def _view_step(self, view: View, cam, fxf: torch.Tensor, g, ft):
         """omfs_view_step of this view (cached with everything it points at: the structs must outlive the call)."""
         target = view.target
-        key = (id(view), id(cam), fxf.data_ptr(), g.n, g.params, L.ptr(self.densify_stats), L.ptr(ft.dface) if ft is not None else 0,
+        key = (id(view), id(cam), fxf.data_ptr(), g.n, g.n_pad, g.params, g.binding, L.ptr(self.densify_stats), L.ptr(ft.dface) if ft is not None else 0,
                target.data_ptr(), self.lambda_dssim, tuple(self.reg), self.rast.rb.keys, self.rast.rb.dup_capacity)
         hit = self._view_steps.get(key)
         if hit is None:
@@ -238,9 +238,20 @@ class Trainer:
                 self.lr_planes[3:].tobytes(), self.lambda_dssim, tuple(self.reg))
 
     def invalidate_graphs(self) -> None:
-        """Buffers a captured iteration refers to were replaced (densification): forget every graph."""
+        """Buffers a captured iteration or a cached omfs_view_step refers to were replaced (densification): forget them all."""
         self._graphs.clear()
         self._graph_seen.clear()
+        self._view_steps.clear()
+
+    def sync_optimizer_state(self) -> None:
+        """"sharded" exchange only: a rank maintains Adam's moments for its own 1/W of the flat [59 * n_pad] range; before anything
+        reads them WHOLE (a checkpoint, the compaction of a densification, whose new n_pad also moves every shard boundary)
+        the shards are all-gathered into every rank's full buffers.  A no-op in every other mode."""
+        if not self.sharded_dp:
+            return
+        from .distributed import allgather_shards_
+        allgather_shards_(self.opt.m.view(-1), self.pg)
+        allgather_shards_(self.opt.v.view(-1), self.pg)
 
     def _graph_eligible(self) -> bool:
         return (self.use_graph and not self.dp and not self.timer.enabled

@@ -27,7 +27,7 @@ def _scene():
     return FlameRig.from_synthetic(rig), seq, g, views
 
 
-def _worker(rank, world, port, q, exchange="compact", finetune=False):
+def _worker(rank, world, port, q, exchange="compact", finetune=False, resume_after=0):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       OMFS_DP_EXCHANGE=exchange)
     torch.cuda.set_device(0)
@@ -35,37 +35,61 @@ def _worker(rank, world, port, q, exchange="compact", finetune=False):
     from omfs_4d_video_gen_amd.engine.distributed import replicas_in_sync
     from omfs_4d_video_gen_amd.engine.trainer import Trainer
     rig, seq, g, views = _scene()
-    tr = Trainer(rig, seq, g, views, W, H, start_sh_degree=3, rank=rank, world_size=world, process_group=dist.group.WORLD,
-                 finetune_flame=finetune, flame_lr={"translation": 1e-4, "pose": 1e-4})
+
+    def make():
+        return Trainer(rig, seq, g, views, W, H, start_sh_degree=3, rank=rank, world_size=world, process_group=dist.group.WORLD,
+                       finetune_flame=finetune, flame_lr={"translation": 1e-4, "pose": 1e-4})
+    tr = make()
     assert tr.compact_dp == (exchange == "compact") and tr.sharded_dp == (exchange == "sharded")
     used = []
     for _ in range(STEPS):
         used.append(next(i for i, v in enumerate(tr.views) if v is tr.view_for_step(tr.step_idx)))
         tr.step()
     torch.cuda.synchronize()
+    extra = None
+    if resume_after:
+        # what engine/train.py does at a checkpoint: the moments are made whole on every rank (a collective in the sharded
+        # exchange), rank 0's copy is what a checkpoint holds; a fresh trainer on every rank loads it and goes on
+        tr.sync_optimizer_state()
+        moments_whole = replicas_in_sync(tr.opt.m) and replicas_in_sync(tr.opt.v)
+        state = [tr.model.params.clone(), tr.opt.m.clone(), tr.opt.v.clone(), tr.opt.step_count, tr.step_idx]
+        dist.broadcast_object_list(obj := [[t.cpu() if torch.is_tensor(t) else t for t in state]], src=0)
+        p_, m_, v_, n_, i_ = obj[0]
+        tr2 = make()
+        tr2.model.params.copy_(p_); tr2.opt.m.copy_(m_); tr2.opt.v.copy_(v_)
+        tr2.opt.step_count, tr2.step_idx = n_, i_
+        for t in (tr, tr2):
+            for _ in range(resume_after):
+                t.step()
+        torch.cuda.synchronize()
+        extra = (moments_whole, tr2.model.params.cpu().numpy(), replicas_in_sync(tr2.model.params))
     ok = replicas_in_sync(tr.model.params)
     if finetune:
         ok = ok and replicas_in_sync(tr.flame_ft.translation) and replicas_in_sync(tr.flame_ft.pose) and replicas_in_sync(tr.flame_ft.expr)
         moved = float((tr.flame_ft.translation.cpu() - torch.from_numpy(np.asarray(seq["translation"], np.float32).reshape(-1, 3))).abs().max())
         ok = ok and moved > 0
-    q.put((rank, ok, used, tr.model.params.cpu().numpy()))
+    q.put((rank, ok, used, tr.model.params.cpu().numpy(), extra))
     dist.destroy_process_group()
 
 
-def _run_two_ranks(exchange, finetune=False):
+def _run_ranks(exchange, finetune=False, world=2, resume_after=0):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange, finetune)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, finetune, resume_after)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=60) for _ in procs], key=lambda r: r[0])
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
     return res
+
+
+def _run_two_ranks(exchange, finetune=False):
+    return [r[:4] for r in _run_ranks(exchange, finetune)]
 
 
 def test_two_ranks_with_flame_finetuning_stay_in_sync():
@@ -73,15 +97,8 @@ def test_two_ranks_with_flame_finetuning_stay_in_sync():
     assert ok0 and ok1 and np.array_equal(p0, p1)
 
 
-@pytest.mark.parametrize("exchange", ["compact", "full", "sharded"])
-def test_two_ranks_match_single_process_gradient_sum(exchange):
-    res = _run_two_ranks(exchange)
-    procs = []
-    (_, ok0, used0, p0), (_, ok1, used1, p1) = res
-    assert ok0 and ok1 and np.array_equal(p0, p1)
-    assert used0 == [0, 2, 0, 2] and used1 == [1, 3, 1, 3]
-
-    # single process: same two views per step, gradients summed locally, Adam with grad_scale 1/2
+def _single_process_sum(world):
+    """One process: the `world` views of every step, gradients summed locally, Adam with grad_scale 1 / world."""
     from omfs_4d_video_gen_amd.engine.trainer import Trainer
     rig, seq, g, views = _scene()
     tr = Trainer(rig, seq, g, views, W, H, start_sh_degree=3)
@@ -90,10 +107,10 @@ def test_two_ranks_match_single_process_gradient_sum(exchange):
     real_step = tr.opt.step
     for s in range(STEPS):
         total.zero_()
-        for r in range(2):
+        for r in range(world):
             tr.step_idx = s
             tr.views_backup = tr.views
-            v = views[(s * 2 + r) % 4]
+            v = views[(s * world + r) % 4]
             tr.views = [v]
             tr.opt.step = lambda grads, scale=1.0: None          # run everything but the optimiser
             tr.step()
@@ -101,12 +118,42 @@ def test_two_ranks_match_single_process_gradient_sum(exchange):
             tr.views = tr.views_backup
         tr.opt.step = real_step
         tr.step_idx = s + 1
-        tr.opt.step(total, 0.5)
+        tr.opt.step(total, 1.0 / world)
     torch.cuda.synchronize()
+    return tr.model.params.cpu().numpy()
+
+
+@pytest.mark.parametrize("exchange", ["compact", "full", "sharded"])
+def test_two_ranks_match_single_process_gradient_sum(exchange):
+    res = _run_two_ranks(exchange)
+    (_, ok0, used0, p0), (_, ok1, used1, p1) = res
+    assert ok0 and ok1 and np.array_equal(p0, p1)
+    assert used0 == [0, 2, 0, 2] and used1 == [1, 3, 1, 3]
     # float atomics in the backward pass order their sums differently from run to run, so the two
     # executions agree to fp32 accumulation noise, not bitwise (the two RANKS are bitwise equal: see above)
-    got = tr.model.params.cpu().numpy()
+    got = _single_process_sum(2)
     assert np.allclose(got, p0, rtol=2e-4, atol=2e-6), np.abs(got - p0).max()
+
+
+@pytest.mark.parametrize("exchange", ["compact", "full", "sharded"])
+def test_four_ranks_on_one_card_match_the_four_view_gradient_sum(exchange):
+    """The widest rehearsal one card allows (the box admits 6 GPU processes; world size 8 itself is covered on CPU tensors in
+    tests/test_distributed_gloo.py and has never run on hardware): 4 gloo ranks, every step consumes all 4 views."""
+    res = _run_ranks(exchange, world=4)
+    assert all(r[1] for r in res) and all(np.array_equal(res[0][3], r[3]) for r in res[1:])
+    assert [r[2] for r in res] == [[k] * STEPS for k in range(4)]
+    got = _single_process_sum(4)
+    assert np.allclose(got, res[0][3], rtol=2e-4, atol=2e-6), np.abs(got - res[0][3]).max()
+
+
+def test_sharded_exchange_resumes_from_whole_moments_like_a_continuous_run():
+    """A rank of the sharded exchange maintains Adam's moments for its own 1/W of the elements only: Trainer.sync_optimizer_state()
+    makes them whole (engine/train.py calls it before a checkpoint, engine/densify.py before a compaction).  A run resumed from
+    rank 0's synced state must go on exactly like the run that was never interrupted."""
+    res = _run_ranks("sharded", resume_after=3)
+    for _, ok, _, p_cont, (whole, p_resumed, in_sync) in res:
+        assert ok and whole and in_sync
+        assert np.allclose(p_resumed, p_cont, rtol=2e-4, atol=2e-6), np.abs(p_resumed - p_cont).max()
 
 
 def _worker_rccl(port, q, exchange):
