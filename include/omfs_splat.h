@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMFS_ABI_VERSION 5
+#define OMFS_ABI_VERSION 6
 #define OMFS_TILE 16
 #define OMFS_SEG 128     /* list entries per backward segment                                          */
 #define OMFS_NPLANES 59
@@ -87,6 +87,15 @@ int omfs_flame_joints_pose(const omfs_flame_rig* rig, const float* expr, const f
 int omfs_flame_lbs(const omfs_flame_rig* rig, const float* coef, const float* joint_xf,
                    const float* translation, const float* dynamic_offset, int n_frames,
                    float* verts, float* v_shaped_out, const int32_t* frame_index, void* stream);
+
+/* ONE frame, omfs_flame_joints(_pose) + omfs_flame_lbs in a single launch (the training step poses one view per iteration):
+ * every 16-vertex wave evaluates the frame's joints itself while its first basis tiles are in flight -- the same code, the
+ * same bits.  expr / rotmats / pose / translation / dynamic_offset point at the FRAME's row, or, with frame_index (device,
+ * one entry), at row 0 of the sequence arrays.  pose == NULL: the joints come from rotmats [45]; otherwise rotmats receives
+ * the frame's five matrices.  joint_xf [60] and coef [k_pad][16] (column 0) are written for the backward pass / inspection. */
+int omfs_flame_pose_lbs(const omfs_flame_rig* rig, const float* expr, float* rotmats, const float* pose,
+                        const float* translation, const float* dynamic_offset, float* joint_xf, float* coef,
+                        float* verts, float* v_shaped_out, const int32_t* frame_index, void* stream);
 
 /* face_xf [n_frames][n_faces][16]: R row-major (columns a0,n,a2) 9, centre 3, scale 1, pad 3 */
 int omfs_face_frames(const float* verts, int v_pad, const int32_t* faces, int n_faces, int n_frames,
@@ -253,6 +262,14 @@ int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, co
  *                          neck, jaw, eyes), d translation [3]; dcoef [n_coef + 1] is scratch whose LAST word is a
  *                          block ticket that must be zero before the first call (the call leaves it zero): the basis^T
  *                          product and the serial front run in ONE launch, the block that finishes last does the front.
+ *   omfs_flame_skin_param_bwd : omfs_flame_skin_bwd + omfs_flame_param_bwd in ONE launch (ABI 6; what the trainer calls): a
+ *                          workgroup owns 32 vertices, forms their dv_shaped in LDS, multiplies it into the TRANSPOSED basis
+ *                          basis_t [3 V][n_coef] (row 3 v + c; contiguous per wave, no cross-lane reduction) and adds its share
+ *                          of dcoef and of the 63 joint / translation sums with float atomics (into one of 16 copies of the
+ *                          accumulators: adds to one cache line serialise); the workgroup that finishes last (ticket) adds
+ *                          the copies up and runs the serial front.  dcoef holds omfs_flame_skin_param_scratch_floats(0)
+ *                          floats, sums omfs_flame_skin_param_scratch_floats(1); both must be ZERO before the first call,
+ *                          every call leaves them zero.
  *   omfs_adam_flat       : torch.optim.Adam step on a flat buffer (the FLAME parameter tensors)
  *   omfs_adam_flat_multi : the same step on up to 4 flat tensors in one launch (host arrays of n_tensors device pointers,
  *                          sizes and learning rates); the gradients are CONSUMED (zeroed once read), so dense gradient
@@ -266,6 +283,10 @@ int omfs_flame_skin_rows(const omfs_flame_rig* rig);
 int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basis_dense, int n_coef, const float* dv_shaped,
                          const float* expr, const float* pose, const float* sums, float* dcoef, float* dexpr, float* dpose,
                          float* dtrans, void* stream);
+int omfs_flame_skin_param_scratch_floats(int which);
+int omfs_flame_skin_param_bwd(const omfs_flame_rig* rig, const float* basis_t, int n_coef, const float* v_shaped,
+                              const float* joint_xf, float* dverts, const float* expr, const float* pose, float* dcoef,
+                              float* sums, float* dexpr, float* dpose, float* dtrans, void* stream);
 int omfs_adam_flat(float* params, const float* grads, float* m, float* v, int n, float lr, float beta1, float beta2,
                    float eps, int step, float grad_scale, void* stream);
 struct omfs_step_state;
@@ -302,9 +323,22 @@ int omfs_sh_rest_grads(const omfs_gaussians* g, const float* face_xf_all, int n_
 
 /* (1-lambda) L1 + lambda (1-SSIM), 11x11 gaussian window, zero padding.
  * Writes dimage [3][H][W] and the scalar loss into loss_out[0].
- * scratch: 3 * 3*H*W floats. */
+ * scratch: 3 * 3*H*W + OMFS_LOSS_TAIL floats (ABI 6): three derivative maps, then one loss partial per 64 x 34 pixel strip
+ * and channel (the backward launch adds them up: no reduction launch between the two passes); images of more than
+ * OMFS_LOSS_TAIL strips are refused. */
+#define OMFS_LOSS_TAIL 16384
 int omfs_loss_l1_ssim(const float* image, const float* target, int width, int height, float lambda_dssim,
                       float* dimage, float* loss_out, float* scratch, void* stream);
+
+/* Image ingress (ABI 6): a decoded 8-bit image src [src_height][src_width][channels] (channels 1, 3 or 4; a fourth channel
+ * is the matte) and an optional separate matte mask [src_height][src_width] become the training target of a view: resized
+ * to width x height by PIL's Image.BOX rule (equal-weight average of the source pixels whose centre falls into the output
+ * pixel's footprint; identity without a resize), rounded to 8-bit levels, composited on bg_host[3] (value * m + (1 - m) *
+ * bg) and written as planar fp32 out_f32 [3][height][width] in [0,1] and / or interleaved out_u8 [height][width][3] (either
+ * may be NULL).  engine/train.py builds its targets with it, engine/render.py the gt/ images an evaluator compares with
+ * (`validation_reporting.py:60-78`).                                                                                  */
+int omfs_prepare_target(const uint8_t* src, int channels, int src_width, int src_height, const uint8_t* mask, int width,
+                        int height, const float* bg_host, float* out_f32, uint8_t* out_u8, void* stream);
 
 typedef struct omfs_adam_params {
   float lr[OMFS_NPLANES]; /* learning rate per plane                                              */
@@ -344,7 +378,7 @@ typedef struct omfs_view_step {
   float* target_scratch;
   float lambda_dssim;
   float* loss_out;             /* [1]                                                                                    */
-  float* loss_scratch;         /* 3 * 3*H*W floats                                                                       */
+  float* loss_scratch;         /* 3*3*H*W + OMFS_LOSS_TAIL floats (omfs_loss_l1_ssim)                                      */
 } omfs_view_step;
 int omfs_view_forward_backward(const omfs_view_step* v, void* stream);
 

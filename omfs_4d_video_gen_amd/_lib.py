@@ -14,7 +14,8 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see module d
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
+LOSS_TAIL = 16384              # OMFS_LOSS_TAIL: loss partials behind the three maps of omfs_loss_l1_ssim's scratch
 RB_FORWARD_ONLY = 1
 NPLANES = 59
 TILE = 16
@@ -140,6 +141,9 @@ SIGNATURES = {
     "omfs_flame_param_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_flame_skin_rows": (C.c_int, [C.POINTER(FlameRigC)]),
+    "omfs_flame_skin_param_scratch_floats": (C.c_int, [C.c_int]),
+    "omfs_flame_skin_param_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, C.c_int] + [c_void_p] * 11),
+    "omfs_flame_pose_lbs": (C.c_int, [C.POINTER(FlameRigC)] + [c_void_p] * 11),
     "omfs_adam_flat": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                  C.c_int, C.c_float, c_void_p]),
     "omfs_simpleflame_fwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 5 + [C.c_int, c_void_p, c_void_p, c_void_p]),
@@ -154,6 +158,8 @@ SIGNATURES = {
     "omfs_image_to_rgb8": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_image_to_png_rows": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_rgb8_to_image": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
+    "omfs_prepare_target": (C.c_int, [c_void_p, C.c_int, C.c_int, C.c_int, c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), c_void_p,
+                                      c_void_p, c_void_p]),
     "omfs_composite_bwd": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), C.POINTER(GradBuffersC), c_void_p]),
     "omfs_project_bwd": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC),
                                    C.POINTER(GradBuffersC), C.POINTER(RegParamsC), c_void_p]),

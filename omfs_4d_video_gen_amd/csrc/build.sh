@@ -14,7 +14,7 @@ objs=()
 # 0.099 ms and composite_bwd 0.237 -> 0.234 ms with max-ilp, project_bwd 0.056 -> 0.052 ms with max-memory-clause; the rest do not care)
 declare -A SCHED=([loss_adam]="-mllvm -amdgpu-sched-strategy=max-ilp" [composite]="-mllvm -amdgpu-sched-strategy=max-ilp"
                   [project_bwd]="-mllvm -amdgpu-sched-strategy=max-memory-clause")
-for src in flame project binning composite project_bwd loss_adam simple_flame densify; do
+for src in flame project binning composite project_bwd loss_adam simple_flame densify image_io; do
   "$HIPCC" $FLAGS ${SCHED[$src]:-} ${EXTRA_HIPCC_FLAGS:-} -c "$here/$src.hip" -o "$here/$src.o" &
   objs+=("$here/$src.o")
 done

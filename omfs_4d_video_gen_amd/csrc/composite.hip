@@ -280,7 +280,10 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
           if (jx[u]) {
             int nsb = 0, nfl = 0;
             for (int sb = 0; sb < 4; ++sb) { nsb += (hb & sbl[sb]) != 0ull; nfl += ((ms[sb] >> (jx[u] - 1)) & 1ull) && (live & sbl[sb]); }
-            OMFS_DBG_ADD(16, 1); OMFS_DBG_ADD(17, nsb); OMFS_DBG_ADD(18, nfl); OMFS_DBG_ADD(19, __popcll(__ballot(ar[u] > 0.f)));
+            OMFS_DBG_ADD(16, 1); OMFS_DBG_ADD(17, nsb); OMFS_DBG_ADD(18, nfl);
+            int nl = 0;
+            for (int sb = 0; sb < 4; ++sb) nl += (live & sbl[sb]) != 0ull;
+            if (nl) OMFS_DBG_ADD(27 + nl, 1);
           } }
 #endif
         const float Tn = T * (1.f - alpha);
@@ -791,6 +794,9 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
         int nsb = 0;
         for (int sb = 0; sb < 4; ++sb) nsb += (hit_bal & __ballot(sidx == sb)) != 0ull;
         OMFS_DBG_ADD(13, nsb);
+        int na = 0;                    // sub-blocks whose deepest last contributor lies at or behind this entry
+        for (int sb = 0; sb < 4; ++sb) na += smax[sb] >= contributor;
+        OMFS_DBG_ADD(19 + na, 1); OMFS_DBG_ADD(23 + na, __popcll(hit_bal));
       }
 #endif
       if (hit_bal == 0ull) return;    // nobody in this quadrant was touched: nothing to reduce

@@ -21,38 +21,35 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the oracle), all lanes write the coefficient column, lane 0 walks the 5-joint kinematic chain.
 __device__ __forceinline__ void rodrigues_fwd(const float* aa, float* R, float* K, float& th);
 
-// pose (may be NULL): axis-angle [*][15]; when given, the frame's five rotation matrices are computed here (the formula of
-// rodrigues_kernel, bit for bit) and stored to rotmats -- FLAME fine-tuning poses from the current parameters without a
-// separate launch.
-__global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
-                                                          const float* __restrict__ expr, float* __restrict__ rotmats,
-                                                          const float* __restrict__ pose,
-                                                          int n_frames, int n_expr, int k_pad, int b_pad,
-                                                          float* __restrict__ joint_xf, float* __restrict__ coef,
-                                                          const int32_t* __restrict__ frame_index) {
-  __shared__ float sJ[15];
-  __shared__ float sR[45];
-  const int b = blockIdx.x, lane = threadIdx.x;
-  if (b >= n_frames) {  // padded frame columns: zero coefficients
-    for (int k = lane; k < k_pad; k += 64) coef[(size_t)k * b_pad + b] = 0.f;
-    return;
-  }
-  const int src = frame_index ? frame_index[b] : b;     // row of the sequence arrays this batch column shows
-  const float* e = expr + (size_t)src * n_expr;
+// One frame's joints by ONE 64-lane workgroup: the joint regression (15 ascending-k fma chains, as the oracle), the five rotation
+// matrices (given, or -- pose != NULL -- from axis-angle poses by the formula of rodrigues_kernel, bit for bit, and stored to
+// rotmats_out when that is not NULL), the blendshape coefficient column (expr, then the 36 pose features R_j - I, then zeros) and
+// the 5-joint kinematic chain.  Outputs go wherever the caller points: coef_out[k * coef_stride] (global column or an LDS
+// array), X_out[60] (global or LDS; written by lane 0).  Ends with a workgroup barrier: the outputs are visible to the block.
+struct JointsLds {
+  float sJ[15];
+  float sR[45];
+  float s_je[15 * 128];
+  float s_e[128];
+};
+__device__ __forceinline__ void joints_frame(JointsLds& L, const float* __restrict__ j_static, const float* __restrict__ j_expr,
+                                             const float* __restrict__ e, const float* __restrict__ rot_in, const float* __restrict__ pose,
+                                             float* __restrict__ rotmats_out, int n_expr, int k_pad, float* coef_out, int coef_stride,
+                                             float* X_out) {
+  const int lane = threadIdx.x;
+  float* sJ = L.sJ; float* sR = L.sR; float* s_je = L.s_je; float* s_e = L.s_e;
   if (pose) {
     if (lane < 5) {
       float Rj[9], Kj[9], th;
-      rodrigues_fwd(pose + (size_t)src * 15 + lane * 3, Rj, Kj, th);
-      for (int i = 0; i < 9; ++i) { sR[lane * 9 + i] = Rj[i]; rotmats[(size_t)src * 45 + lane * 9 + i] = Rj[i]; }
+      rodrigues_fwd(pose + lane * 3, Rj, Kj, th);
+      for (int i = 0; i < 9; ++i) { sR[lane * 9 + i] = Rj[i]; if (rotmats_out) rotmats_out[lane * 9 + i] = Rj[i]; }
     }
   } else if (lane < 45) {
-    sR[lane] = rotmats[(size_t)src * 45 + lane];
+    sR[lane] = rot_in[lane];
   }
   // the joint regressor's expression part (15 x n_expr) and the coefficients go through LDS: all 64 lanes fetch them with
   // independent coalesced loads (one memory round trip), the 15 ascending-k fma chains then run from LDS -- straight from
   // global memory every chain step was its own round trip (14 us alone, 58-81 us beside the Adam pass)
-  __shared__ float s_je[15 * 128];
-  __shared__ float s_e[128];
   // all loads of a pass in flight together (a plain copy loop waits for every load before its LDS store: 24 round trips
   // for the 1500 words of the regressor -- 32 us for this kernel beside the Adam pass, where a round trip takes 3-5x longer)
   const float jst = lane < 15 ? j_static[lane] : 0.f;
@@ -85,31 +82,49 @@ __global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restric
       const int i = (k - n_expr) % 9;
       v = R[9 + (k - n_expr)] - ((i == 0 || i == 4 || i == 8) ? 1.f : 0.f);
     }
-    coef[(size_t)k * b_pad + b] = v;
+    coef_out[(size_t)k * coef_stride] = v;
   }
   __syncthreads();
-  if (lane != 0) return;
-  float J[5][3];
-  for (int jc = 0; jc < 15; ++jc) J[jc / 3][jc % 3] = sJ[jc];
-  // kinematic chain, parents = [-1, 0, 1, 1, 1]
-  float Rw[5][9], tw[5][3];
-  for (int i = 0; i < 9; ++i) Rw[0][i] = R[i];
-  for (int c = 0; c < 3; ++c) tw[0][c] = J[0][c];
-  for (int j = 1; j < 5; ++j) {
-    int p = (j == 1) ? 0 : 1;
-    const float* Rl = R + j * 9;
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c)
-        Rw[j][r * 3 + c] = dot3_(Rw[p][r * 3 + 0], Rw[p][r * 3 + 1], Rw[p][r * 3 + 2], Rl[c], Rl[3 + c], Rl[6 + c]);
-    float dx = J[j][0] - J[p][0], dy = J[j][1] - J[p][1], dz = J[j][2] - J[p][2];
-    for (int r = 0; r < 3; ++r) tw[j][r] = dot3_(Rw[p][r * 3 + 0], Rw[p][r * 3 + 1], Rw[p][r * 3 + 2], dx, dy, dz) + tw[p][r];
+  if (lane == 0) {
+    float J[5][3];
+    for (int jc = 0; jc < 15; ++jc) J[jc / 3][jc % 3] = sJ[jc];
+    // kinematic chain, parents = [-1, 0, 1, 1, 1]
+    float Rw[5][9], tw[5][3];
+    for (int i = 0; i < 9; ++i) Rw[0][i] = R[i];
+    for (int c = 0; c < 3; ++c) tw[0][c] = J[0][c];
+    for (int j = 1; j < 5; ++j) {
+      int p = (j == 1) ? 0 : 1;
+      const float* Rl = R + j * 9;
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+          Rw[j][r * 3 + c] = dot3_(Rw[p][r * 3 + 0], Rw[p][r * 3 + 1], Rw[p][r * 3 + 2], Rl[c], Rl[3 + c], Rl[6 + c]);
+      float dx = J[j][0] - J[p][0], dy = J[j][1] - J[p][1], dz = J[j][2] - J[p][2];
+      for (int r = 0; r < 3; ++r) tw[j][r] = dot3_(Rw[p][r * 3 + 0], Rw[p][r * 3 + 1], Rw[p][r * 3 + 2], dx, dy, dz) + tw[p][r];
+    }
+    for (int j = 0; j < 5; ++j) {
+      for (int i = 0; i < 9; ++i) X_out[j * 12 + i] = Rw[j][i];
+      for (int r = 0; r < 3; ++r)
+        X_out[j * 12 + 9 + r] = tw[j][r] - dot3_(Rw[j][r * 3 + 0], Rw[j][r * 3 + 1], Rw[j][r * 3 + 2], J[j][0], J[j][1], J[j][2]);
+    }
   }
-  float* out = joint_xf + (size_t)b * 60;
-  for (int j = 0; j < 5; ++j) {
-    for (int i = 0; i < 9; ++i) out[j * 12 + i] = Rw[j][i];
-    for (int r = 0; r < 3; ++r)
-      out[j * 12 + 9 + r] = tw[j][r] - dot3_(Rw[j][r * 3 + 0], Rw[j][r * 3 + 1], Rw[j][r * 3 + 2], J[j][0], J[j][1], J[j][2]);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void flame_joints_kernel(const float* __restrict__ j_static, const float* __restrict__ j_expr,
+                                                          const float* __restrict__ expr, float* __restrict__ rotmats,
+                                                          const float* __restrict__ pose,
+                                                          int n_frames, int n_expr, int k_pad, int b_pad,
+                                                          float* __restrict__ joint_xf, float* __restrict__ coef,
+                                                          const int32_t* __restrict__ frame_index) {
+  __shared__ JointsLds L;
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if (b >= n_frames) {  // padded frame columns: zero coefficients
+    for (int k = lane; k < k_pad; k += 64) coef[(size_t)k * b_pad + b] = 0.f;
+    return;
   }
+  const int src = frame_index ? frame_index[b] : b;     // row of the sequence arrays this batch column shows
+  joints_frame(L, j_static, j_expr, expr + (size_t)src * n_expr, rotmats + (size_t)src * 45, pose ? pose + (size_t)src * 15 : nullptr,
+               rotmats + (size_t)src * 45, n_expr, k_pad, coef + b, b_pad, joint_xf + (size_t)b * 60);
 }
 
 // grid = (v_pad/16 strips, b_pad/16 column blocks), block = 64 (one wave per 16 vertices x 16 frames).
@@ -191,6 +206,109 @@ __global__ __launch_bounds__(64) void flame_lbs_kernel(const float* __restrict__
     ox += tx; oy += ty; oz += tz;
     *reinterpret_cast<float4*>(verts + ((size_t)frame * v_pad + v) * 4) = make_float4(ox, oy, oz, 1.f);
   }
+}
+
+// ONE frame, joints and skinning in ONE launch (flame_joints_kernel + flame_lbs_kernel for n_frames = 1: the training step poses
+// one view per iteration, and the joints launch was a 7 us kernel plus a kernel boundary in front of every skinning pass).
+// Every wave (16 vertices) evaluates the frame's joints itself -- joints_frame, the code of flame_joints_kernel, so the same
+// bits -- while its first basis tiles are in flight; the coefficient column and the five transforms stay in LDS (strip 0 also
+// writes them to joint_xf / coef / rotmats for the backward pass and the batched path).  The MFMA B operand holds the
+// coefficients in frame column 0 and zeros in the 15 padded columns, exactly what the coef matrix of a one-frame batch holds.
+// The skinning epilogue runs on 16 lanes, one vertex each (the accumulators go through LDS), instead of 4 lanes x 4 vertices.
+__global__ __launch_bounds__(64) void flame_pose_lbs_kernel(const float* __restrict__ basis_tiled, const float* __restrict__ v_static,
+                                                            const float* __restrict__ lbs_weights, const float* __restrict__ j_static,
+                                                            const float* __restrict__ j_expr, const float* __restrict__ expr,
+                                                            float* __restrict__ rotmats, const float* __restrict__ pose,
+                                                            const float* __restrict__ translation,
+                                                            const float* __restrict__ dynamic_offset, int n_verts, int v_pad, int k_pad,
+                                                            int n_expr, float* __restrict__ verts, float* __restrict__ v_shaped_out,
+                                                            float* __restrict__ joint_xf, float* __restrict__ coef,
+                                                            const int32_t* __restrict__ frame_index) {
+  __shared__ JointsLds L;
+  __shared__ float s_coef[192];       // k_pad <= 176 (n_expr <= 128)
+  __shared__ float sX[60];
+  __shared__ float s_acc[16][4];
+  const int strip = blockIdx.x, lane = threadIdx.x;
+  const int n_strips = v_pad / 16, n_kt = k_pad / 16;
+  const int col = lane & 15, grp = lane >> 4;
+  f32x4 acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float* vs = v_static + (size_t)c * v_pad + strip * 16 + grp * 4;
+    acc[c] = f32x4{vs[0], vs[1], vs[2], vs[3]};
+  }
+  constexpr int KU = 5;
+  f32x4 a[KU][3];
+  auto load_tiles = [&](int kt0) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int kt = kt0 + u < n_kt ? kt0 + u : n_kt - 1;        // clamped: the surplus loads are not used
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        a[u][c] = *reinterpret_cast<const f32x4*>(basis_tiled + ((((size_t)c * n_strips + strip) * n_kt + kt) * 64 + lane) * 4);
+    }
+  };
+  load_tiles(0);                      // in flight during the joints
+  const int src = frame_index ? frame_index[0] : 0;
+  // epilogue operands of this lane's vertex, also in flight now
+  const int ve = strip * 16 + col;
+  float w[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float dyn[3] = {0.f, 0.f, 0.f};
+  const bool eon = grp == 0 && ve < n_verts;
+  if (eon) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w[j] = lbs_weights[(size_t)ve * 8 + j];
+    if (dynamic_offset) {
+      const float* d = dynamic_offset + ((size_t)src * n_verts + ve) * 3;
+      dyn[0] = d[0]; dyn[1] = d[1]; dyn[2] = d[2];
+    }
+  }
+  const float tx = translation[src * 3 + 0], ty = translation[src * 3 + 1], tz = translation[src * 3 + 2];
+  const bool first = strip == 0;
+  joints_frame(L, j_static, j_expr, expr + (size_t)src * n_expr, rotmats + (size_t)src * 45, pose ? pose + (size_t)src * 15 : nullptr,
+               first ? rotmats + (size_t)src * 45 : nullptr, n_expr, k_pad, s_coef, 1, sX);
+  if (first) {
+    for (int k = lane; k < k_pad; k += 64) coef[(size_t)k * 16] = s_coef[k];     // column 0 of the [k_pad][16] matrix; 1..15 stay zero
+    if (lane < 60) joint_xf[lane] = sX[lane];
+  }
+  for (int kt0 = 0; kt0 < n_kt; kt0 += KU) {
+    if (kt0 > 0) load_tiles(kt0);
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      if (kt0 + u >= n_kt) break;
+      const int kt = kt0 + u;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bv = col == 0 ? s_coef[kt * 16 + j * 4 + grp] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][c][j], bv, acc[c], 0, 0, 0);
+      }
+    }
+  }
+  // C/D map of 16x16x4 f32: row = grp*4 + reg (vertex in strip), col = lane&15 (frame): frame 0 lives in the lanes with col == 0
+  if (col == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s_acc[grp * 4 + r][0] = acc[0][r]; s_acc[grp * 4 + r][1] = acc[1][r]; s_acc[grp * 4 + r][2] = acc[2][r]; }
+  }
+  __syncthreads();
+  if (!eon) return;
+  const float* X = sX;
+  float M[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) {
+    float m = w[0] * X[i];
+#pragma unroll
+    for (int j = 1; j < 5; ++j) m = fma_(w[j], X[j * 12 + i], m);
+    M[i] = m;
+  }
+  const float x = s_acc[col][0], y = s_acc[col][1], z = s_acc[col][2];
+  if (v_shaped_out) *reinterpret_cast<float4*>(v_shaped_out + (size_t)ve * 4) = make_float4(x, y, z, 1.f);
+  float ox = dot3_(M[0], M[1], M[2], x, y, z) + M[9];
+  float oy = dot3_(M[3], M[4], M[5], x, y, z) + M[10];
+  float oz = dot3_(M[6], M[7], M[8], x, y, z) + M[11];
+  if (dynamic_offset) { ox += dyn[0]; oy += dyn[1]; oz += dyn[2]; }
+  ox += tx; oy += ty; oz += tz;
+  *reinterpret_cast<float4*>(verts + (size_t)ve * 4) = make_float4(ox, oy, oz, 1.f);
 }
 
 __device__ __forceinline__ void safe_normalize3(float& x, float& y, float& z) {
@@ -371,6 +489,7 @@ __global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __rest
 struct FrontArgs {
   const float* j_static; const float* j_expr; const float* expr; const float* pose; int n_expr; const float* partial; int n_rows;
   float* dexpr; float* dpose; float* dtrans;
+  int totals;     // partial is ONE row of totals (flame_skin_gemv_kernel) instead of n_rows per-wave rows (flame_skin_bwd_kernel)
 };
 __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef);
 
@@ -409,6 +528,119 @@ __global__ __launch_bounds__(GEMV_NT) void basis_t_gemv_kernel(const float* __re
   __threadfence();
   if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(dcoef + gridDim.x) = 0u;
   flame_front_bwd(fa, dcoef);
+}
+
+// Skinning backward + basis^T product + the serial front in ONE launch (flame_skin_bwd_kernel + basis_t_gemv_kernel; their
+// dv_shaped round trip through memory and one kernel boundary are gone).  A workgroup owns SKG_V consecutive vertices:
+//   1. lanes < SKG_V turn dL/d(posed vertex) into dL/d(blend-shaped vertex) dvs = M_v^T dv (M_v = sum_j w_vj X_j) and stage it
+//      with (w, dv, v_shaped) in LDS; the dverts rows are consumed (left zeroed);
+//   2. thread k < n_coef sums basis_t[3 v + c][k] * dvs[v][c] over the workgroup's 3 SKG_V columns -- basis_t is the basis
+//      TRANSPOSED ([3 V][n_coef]), so the wave's loads are contiguous, every column value is an LDS broadcast and NO cross-lane
+//      reduction exists; all loads of a thread are issued before the barrier that publishes dvs; one float atomic per (block, k);
+//   3. thread q < 63 sums its entry of { d joint_xf [5][12], d translation [3] } over the workgroup's vertices from LDS (no wave
+//      reductions: flame_skin_bwd_kernel spent 63 x 7 DPP instructions per wave on them) and adds it with one float atomic;
+//   4. the workgroup that finishes last (ticket) reads the totals, zeroes them for the next call and runs flame_front_bwd.
+// Float atomics on ONE cache line serialise at the memory side (~11 ns each): 161 workgroups adding into the same 136 words took
+// 22 us.  The workgroups therefore add into SKG_G copies of the accumulators (workgroup b into copy b mod SKG_G: a tenth of the
+// adds per line, sixteen times the lines), and the last workgroup adds the copies up while it consumes them.
+constexpr int SKG_V = 32, SKG_NT = 256, SKG_COLS = 3 * SKG_V, SKG_G = 16;
+__global__ __launch_bounds__(SKG_NT) void flame_skin_gemv_kernel(const float* __restrict__ lbs_weights, const float* __restrict__ v_shaped,
+                                                                 const float* __restrict__ joint_xf, float* __restrict__ dverts, int n_verts,
+                                                                 const float* __restrict__ basis_t, int n_coef, float* __restrict__ dcoef,
+                                                                 float* __restrict__ sums, FrontArgs fa) {
+  __shared__ float X[60];
+  __shared__ float s_w[SKG_V][5], s_dv[SKG_V][3], s_vs[SKG_V][4];
+  __shared__ float s_dvs[SKG_COLS];
+  __shared__ uint32_t s_ticket;
+  const int tid = threadIdx.x, v0 = blockIdx.x * SKG_V;
+  const int nv = min(SKG_V, n_verts - v0), ncol = 3 * nv;
+  // the thread's basis column slice: independent of everything else, in flight first
+  float bq[SKG_COLS];
+  const float* bsrc = basis_t + (size_t)3 * v0 * n_coef + tid;
+  const bool kon = tid < n_coef;
+#pragma unroll
+  for (int i = 0; i < SKG_COLS; ++i) bq[i] = (kon && i < ncol) ? bsrc[(size_t)i * n_coef] : 0.f;
+  float w[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  float4 d = make_float4(0.f, 0.f, 0.f, 0.f), a = d;
+  const bool von = tid < nv;
+  if (von) {
+    const int v = v0 + tid;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) w[j] = lbs_weights[(size_t)v * 8 + j];
+    d = reinterpret_cast<const float4*>(dverts)[v];
+    a = reinterpret_cast<const float4*>(v_shaped)[v];
+  }
+  if (tid >= 64 && tid < 124) X[tid - 64] = joint_xf[tid - 64];
+  __syncthreads();
+  if (tid < SKG_V) {
+    float out[3] = {0.f, 0.f, 0.f};
+    const float dv[3] = {d.x, d.y, d.z};
+    if (von) {
+      reinterpret_cast<float4*>(dverts)[v0 + tid] = make_float4(0.f, 0.f, 0.f, 0.f);   // consumed
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) out[c] = fma_(X[j * 12 + r * 3 + c], w[j] * dv[r], out[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s_dvs[3 * tid + c] = out[c]; s_dv[tid][c] = dv[c]; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) s_w[tid][j] = w[j];
+    s_vs[tid][0] = a.x; s_vs[tid][1] = a.y; s_vs[tid][2] = a.z; s_vs[tid][3] = 1.f;
+  }
+  __syncthreads();
+  if (kon) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < SKG_COLS; ++i) acc = fma_(bq[i], s_dvs[i], acc);
+    atomicAdd(&dcoef[(blockIdx.x % SKG_G) * SKG_NT + tid], acc);
+  }
+  if (tid < 63) {
+    float t = 0.f;
+    if (tid < 60) {
+      const int j = tid / 12, i = tid % 12, r = i < 9 ? i / 3 : i - 9, c = i < 9 ? i % 3 : 3;
+      for (int v = 0; v < nv; ++v) t = fma_(s_w[v][j] * s_dv[v][r], s_vs[v][c], t);
+    } else {
+      for (int v = 0; v < nv; ++v) t += s_dv[v][tid - 60];
+    }
+    atomicAdd(&sums[(blockIdx.x % SKG_G) * 64 + tid], t);
+  }
+  // every wave's atomics have been performed (acknowledged by the memory side) before the ticket is drawn; float atomics are
+  // agent-scope operations that bypass the caches, so no release fence -- a `buffer_wbl2` per thread -- is needed for them
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  uint32_t* ticket = reinterpret_cast<uint32_t*>(dcoef + SKG_G * SKG_NT);
+  if (tid == 0) s_ticket = atomicAdd(ticket, 1u);
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1) return;        // uniform over the block
+  if (tid == 0) *ticket = 0u;
+  // the totals are read where the adds were performed and consumed in the same operation: an atomic exchange with zero (the next
+  // call's atomics start from zero) -- no cache between this workgroup and the other workgroups' adds
+  __shared__ float s_tot[SKG_NT + 64];
+  {
+    float part[SKG_G];
+#pragma unroll
+    for (int g = 0; g < SKG_G; ++g) part[g] = tid < n_coef ? atomicExch(&dcoef[g * SKG_NT + tid], 0.f) : 0.f;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < SKG_G; ++g) t += part[g];
+    s_tot[tid] = t;
+  }
+  if (tid < 64) {
+    float part[SKG_G];
+#pragma unroll
+    for (int g = 0; g < SKG_G; ++g) part[g] = tid < 63 ? atomicExch(&sums[g * 64 + tid], 0.f) : 0.f;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < SKG_G; ++g) t += part[g];
+    s_tot[SKG_NT + tid] = t;
+  }
+  __syncthreads();
+  FrontArgs f2 = fa;
+  f2.partial = s_tot + SKG_NT;
+  flame_front_bwd(f2, s_tot);
 }
 
 // axis-angle -> rotation matrix, the formula of flame_fitter.py:133-152: a = aa / (|aa| + 1e-8), R = I + sin K + (1 - cos) K^2
@@ -453,7 +685,10 @@ __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
   const int lane = threadIdx.x;
   if (lane < n_expr + 36 && lane < 256) s_dcoef[lane] = dcoef[lane];
   if (lane < 15) s_pose[lane] = pose[lane];
-  {   // add up the per-wave rows of flame_skin_bwd: thread (w, q) of the 1024 sums value q over the rows r = w (mod 16), in row
+  if (fa.totals) {
+    if (lane < 64) part16[0][lane] = const_cast<const volatile float*>(partial)[lane];
+    for (int i = 64 + lane; i < 16 * 64; i += (int)blockDim.x) part16[0][i] = 0.f;
+  } else {   // add up the per-wave rows of flame_skin_bwd: thread (w, q) of the 1024 sums value q over the rows r = w (mod 16), in row
       // order, eight loads in flight at a time (the 4-way form walked 21 rows per thread one memory round trip after the other)
     const int w = lane >> 6, q = lane & 63;
     float t = 0.f;
@@ -690,6 +925,19 @@ extern "C" int omfs_flame_lbs(const omfs_flame_rig* rig, const float* coef, cons
   return OMFS_OK;
 }
 
+extern "C" int omfs_flame_pose_lbs(const omfs_flame_rig* rig, const float* expr, float* rotmats, const float* pose,
+                                   const float* translation, const float* dynamic_offset, float* joint_xf, float* coef,
+                                   float* verts, float* v_shaped_out, const int32_t* frame_index, void* stream) {
+  OMFS_REQUIRE(rig && expr && rotmats && translation && joint_xf && coef && verts, "null pointer");
+  OMFS_REQUIRE(rig->n_expr > 0 && rig->n_expr <= 128 && rig->k_pad % 16 == 0 && rig->k_pad >= rig->n_expr + 36 && rig->k_pad <= 192 &&
+                   rig->v_pad % 16 == 0 && rig->v_pad >= rig->n_verts, "shape");
+  hipLaunchKernelGGL(flame_pose_lbs_kernel, dim3(rig->v_pad / 16), dim3(64), 0, (hipStream_t)stream, rig->basis_tiled, rig->v_static,
+                     rig->lbs_weights, rig->j_static, rig->j_expr, expr, rotmats, pose, translation, dynamic_offset, rig->n_verts,
+                     rig->v_pad, rig->k_pad, rig->n_expr, verts, v_shaped_out, joint_xf, coef, frame_index);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
 extern "C" int omfs_face_frames(const float* verts, int v_pad, const int32_t* faces, int n_faces, int n_frames,
                                 float* face_xf, void* stream) {
   OMFS_REQUIRE(verts && faces && face_xf, "null pointer");
@@ -735,8 +983,23 @@ extern "C" int omfs_flame_param_bwd(const omfs_flame_rig* rig, const float* basi
   OMFS_REQUIRE(rig && basis_dense && dv_shaped && expr && pose && sums && dcoef && dexpr && dpose && dtrans, "null pointer");
   OMFS_REQUIRE(n_coef == rig->n_expr + 36 && n_coef <= 256 && rig->n_expr <= 128 && rig->j_static && rig->j_expr, "shape");
   hipStream_t s = (hipStream_t)stream;
-  FrontArgs fa{rig->j_static, rig->j_expr, expr, pose, rig->n_expr, sums, cdiv(rig->n_verts, 256) * 4, dexpr, dpose, dtrans};
+  FrontArgs fa{rig->j_static, rig->j_expr, expr, pose, rig->n_expr, sums, cdiv(rig->n_verts, 256) * 4, dexpr, dpose, dtrans, 0};
   hipLaunchKernelGGL(basis_t_gemv_kernel, dim3(n_coef), dim3(GEMV_NT), 0, s, basis_dense, dv_shaped, 3 * rig->n_verts, dcoef, fa);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_flame_skin_param_scratch_floats(int which) { return which == 0 ? SKG_G * SKG_NT + 4 : SKG_G * 64; }
+
+extern "C" int omfs_flame_skin_param_bwd(const omfs_flame_rig* rig, const float* basis_t, int n_coef, const float* v_shaped,
+                                         const float* joint_xf, float* dverts, const float* expr, const float* pose,
+                                         float* dcoef, float* sums, float* dexpr, float* dpose, float* dtrans, void* stream) {
+  OMFS_REQUIRE(rig && basis_t && v_shaped && joint_xf && dverts && expr && pose && dcoef && sums && dexpr && dpose && dtrans, "null pointer");
+  OMFS_REQUIRE(n_coef == rig->n_expr + 36 && n_coef <= SKG_NT && rig->n_expr <= 128 && rig->n_verts > 0 && rig->lbs_weights &&
+                   rig->j_static && rig->j_expr, "shape");
+  FrontArgs fa{rig->j_static, rig->j_expr, expr, pose, rig->n_expr, sums, 1, dexpr, dpose, dtrans, 1};
+  hipLaunchKernelGGL(flame_skin_gemv_kernel, dim3(cdiv(rig->n_verts, SKG_V)), dim3(SKG_NT), 0, (hipStream_t)stream, rig->lbs_weights,
+                     v_shaped, joint_xf, dverts, rig->n_verts, basis_t, n_coef, dcoef, sums, fa);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

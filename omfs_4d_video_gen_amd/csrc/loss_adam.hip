@@ -124,17 +124,36 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
     }
   }
   contrib = wave_sum_all(contrib);
-  // one partial per wave (24k same-address atomics would serialise at ~11 ns each)
+  // one partial per wave (24k same-address atomics would serialise at ~11 ns each), parked behind the three maps; ONE extra wave
+  // of ssim_bwd_kernel adds them up in index order (bitwise reproducible), so the loss needs no launch of its own.  (Letting the
+  // last wave of THIS kernel do it -- ticket, two levels to keep the returning atomics apart -- cost more than it saved: every
+  // wave then waits for its map stores to drain before it may draw, 42 -> 52 us.)
   if (l == 0) partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = contrib;
 }
 
 __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                       int width, int height, float w_l1, float w_ssim, GaussW gw,
                                                       const float* __restrict__ map_mu1, const float* __restrict__ map_xx,
-                                                      const float* __restrict__ map_xy, float* __restrict__ dimage) {
+                                                      const float* __restrict__ map_xy, float* __restrict__ dimage,
+                                                      const float* __restrict__ partials, int n_partials, float constant,
+                                                      float* __restrict__ loss_out) {
   __shared__ f2 s01[SW + 2 * HALO];       // (d/dmu1, d/dE[xx]) of one map row
   __shared__ float s2[SW + 2 * HALO];     // d/dE[xy]
   const int l = threadIdx.x, ch = blockIdx.z;
+  if (ch == 3) {       // the fourth "channel" of the grid: its first wave is the loss reduction, the others leave at once
+    if (blockIdx.x | blockIdx.y) return;
+    float acc = 0.f;
+    for (int i0 = 0; i0 < n_partials; i0 += 64 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 + l; v[u] = i < n_partials ? partials[i] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    acc = wave_sum_all(acc);
+    if (l == 0) loss_out[0] = constant + acc;
+    return;
+  }
   const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH_B;
   const size_t plane = (size_t)width * height;
   const size_t co = ch * plane;
@@ -198,22 +217,6 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ 
         dimage[co + (size_t)yout * width + xo] = w_l1 * sgn - w_ssim * (c0 + 2.f * xv * c1 + yv * c2);
       }
     }
-  }
-}
-
-// one block: loss_out = constant + sum(partials)   (fixed order: bitwise reproducible)
-__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ partials, int n, float constant,
-                                                          float* __restrict__ loss_out) {
-  __shared__ float ws[16];
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) acc += partials[i];
-  acc = wave_sum_all(acc);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.f;
-    for (int w = 0; w < 16; ++w) t += ws[w];
-    loss_out[0] = constant + t;
   }
 }
 
@@ -320,12 +323,15 @@ extern "C" int omfs_loss_l1_ssim(const float* image, const float* target, int wi
   const float w_l1 = (1.f - lambda_dssim) * inv, w_ssim = lambda_dssim * inv;
   float* m0 = scratch; float* m1 = scratch + n; float* m2 = scratch + 2 * n;
   dim3 grid(cdiv(width, SW), cdiv(height, SRH), 3);
-  // per-wave partials are parked at the head of dimage (overwritten by ssim_bwd afterwards)
-  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(64), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
+  // per-wave partials are parked behind the maps; the extra wave (z = 3) of the backward launch reduces them
+  const int n_part = (int)(grid.x * grid.y * grid.z);
+  OMFS_REQUIRE(n_part <= OMFS_LOSS_TAIL, "image too large for the loss partials behind the maps (OMFS_LOSS_TAIL)");
+  float* partials = scratch + 3 * n;
+  hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(64), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, partials);
   OMFS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, dimage, (int)(grid.x * grid.y * grid.z), lambda_dssim, loss_out);
-  dim3 grid_b(cdiv(width, SW), cdiv(height, SRH_B), 3);
-  hipLaunchKernelGGL(ssim_bwd_kernel, grid_b, dim3(64), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage);
+  dim3 grid_b(cdiv(width, SW), cdiv(height, SRH_B), 4);
+  hipLaunchKernelGGL(ssim_bwd_kernel, grid_b, dim3(64), 0, s, image, target, width, height, w_l1, w_ssim, gw, m0, m1, m2, dimage,
+                     (const float*)partials, n_part, lambda_dssim, loss_out);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

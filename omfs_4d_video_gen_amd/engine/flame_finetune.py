@@ -16,6 +16,7 @@ tensors; no host math.  The trainer runs this chain on a second stream underneat
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -61,6 +62,10 @@ class FlameFineTuner:
         self.n_coef = dflame.h_basis.shape[0]
         # dense basis [K][3V] (column 3v+c): blend-shape recompute per vertex and the transpose product
         self.basis = up(dflame.h_basis.transpose(0, 2, 1).reshape(self.n_coef, 3 * V))
+        # ... and transposed, [3V][K] (row 3v+c): what the fused backward reads -- a wave's loads are contiguous in k and no
+        # cross-lane reduction is needed (omfs_flame_skin_param_bwd)
+        self.basis_t = up(dflame.h_basis.transpose(2, 1, 0).reshape(3 * V, self.n_coef))
+        self.fused = os.environ.get("OMFS_FLAME_SPLIT", "0") != "1"
         dflame.keep_v_shaped = True
         dflame.pose = self.pose                              # the joints launch refreshes rotmats from these
         dflame._scratch.clear()
@@ -68,8 +73,11 @@ class FlameFineTuner:
         self._csr_key, self.face_start, self.face_gauss = None, None, None
         self.dverts = torch.zeros(dflame.v_pad, 4, device=dev)
         self.dv_shaped = torch.empty(V, 3, device=dev)
-        self.sums = torch.zeros(int(L.load().omfs_flame_skin_rows(dflame.c_rig)), 64, device=dev)   # one row per wave
-        self.dcoef = torch.zeros(self.n_coef + 1, device=dev)     # + the last-block ticket of omfs_flame_param_bwd (kept zero)
+        lib = L.load()
+        # scratch of the fused backward (accumulator copies + ticket, kept zero by the kernel); the split launches use the head of
+        # the same buffers: one row of sums per wave, n_coef + 1 words of dcoef
+        self.sums = torch.zeros(max(int(lib.omfs_flame_skin_rows(dflame.c_rig)), lib.omfs_flame_skin_param_scratch_floats(1) // 64), 64, device=dev)
+        self.dcoef = torch.zeros(max(self.n_coef + 1, lib.omfs_flame_skin_param_scratch_floats(0)), device=dev)
         self._t = None
         self.refresh_rotmats()
         # host-side argument arrays of the one Adam launch (device pointers of the three tensors, sizes, learning rates)
@@ -116,6 +124,13 @@ class FlameFineTuner:
         # dverts was left zeroed by the last omfs_flame_skin_bwd, the gradient rows by the last Adam launch
         L.check(lib.omfs_face_frames_bwd(L.ptr(verts), df.v_pad, L.ptr(df.faces), df.rig.n_faces, L.ptr(self.dface),
                                          L.ptr(self.face_start), L.ptr(self.face_gauss), L.ptr(self.dverts), s), "omfs_face_frames_bwd")
+        if self.fused:     # skinning backward + basis^T product + serial front: one launch
+            L.check(lib.omfs_flame_skin_param_bwd(df.c_rig, L.ptr(self.basis_t), self.n_coef, L.ptr(v_shaped), L.ptr(joint_xf),
+                                                  L.ptr(self.dverts), L.ptr(self.expr[t]), L.ptr(self.pose[t]), L.ptr(self.dcoef),
+                                                  L.ptr(self.sums), L.ptr(self.grad["expr"][t]), L.ptr(self.grad["pose"][t]),
+                                                  L.ptr(self.grad["translation"][t]), s), "omfs_flame_skin_param_bwd")
+            self._t = None
+            return
         L.check(lib.omfs_flame_skin_bwd(df.c_rig, L.ptr(v_shaped), L.ptr(joint_xf), L.ptr(self.dverts), L.ptr(self.dv_shaped),
                                         L.ptr(self.sums), s), "omfs_flame_skin_bwd")
         L.check(lib.omfs_flame_param_bwd(df.c_rig, L.ptr(self.basis), self.n_coef, L.ptr(self.dv_shaped), L.ptr(self.expr[t]),

@@ -10,6 +10,7 @@ is pinned by the golden vectors generated from the reference.
 """
 from __future__ import annotations
 
+import os
 import pickle
 
 import numpy as np
@@ -321,7 +322,7 @@ class DeviceFlame:
             b_pad = (nb + 15) // 16 * 16
             dev = self.device
             self._scratch[key] = (
-                torch.empty(nb, 60, device=dev), torch.empty(self.k_pad, b_pad, device=dev),
+                torch.empty(nb, 60, device=dev), torch.zeros(self.k_pad, b_pad, device=dev),
                 torch.empty(nb, self.v_pad, 4, device=dev), torch.empty(nb, self.rig.n_faces, 16, device=dev),
                 torch.empty(nb, self.v_pad, 4, device=dev) if self.keep_v_shaped else None)
         return self._scratch[key]
@@ -350,6 +351,13 @@ class DeviceFlame:
         joint_xf, coef, verts, face_xf, v_shaped = self._buffers(nb)
         if out is not None:
             face_xf = out
+        if nb == 1 and os.environ.get("OMFS_FLAME_SPLIT", "0") != "1":
+            # one frame (the training step): joints and skinning in ONE launch, every wave evaluating the joints itself
+            L.check(lib.omfs_flame_pose_lbs(self.c_rig, expr_p, rot_p, pose_p, trans_p, dyn_p, L.ptr(joint_xf), L.ptr(coef), L.ptr(verts),
+                                            L.ptr(v_shaped), index_p, s), "omfs_flame_pose_lbs")
+            L.check(lib.omfs_face_frames(L.ptr(verts), self.v_pad, L.ptr(self.faces), self.rig.n_faces, nb, L.ptr(face_xf), s),
+                    "omfs_face_frames")
+            return verts, face_xf
         if pose_p:     # rotation matrices from the current axis-angle poses, in the same launch
             L.check(lib.omfs_flame_joints_pose(self.c_rig, expr_p, pose_p, rot_p, nb, L.ptr(joint_xf), L.ptr(coef), index_p, s),
                     "omfs_flame_joints_pose")

@@ -159,7 +159,7 @@ class Rasterizer:
             self.dsplat = torch.zeros(self.n_capacity, 16, device=dev)
             self.dimage = torch.zeros(3, self.height, self.width, device=dev)
             self.loss = torch.zeros(1, device=dev)
-            self.loss_scratch = torch.zeros(3, 3, self.height, self.width, device=dev)
+            self.loss_scratch = torch.zeros(3 * 3 * self.height * self.width + L.LOSS_TAIL, device=dev)    # three maps + one loss partial per strip
 
     def loss_l1_ssim(self, target: torch.Tensor, lambda_dssim: float = 0.2) -> torch.Tensor:
         """Writes this view's loss into self.loss (device scalar) and dL/dimage into self.dimage."""

@@ -13,7 +13,6 @@ from __future__ import annotations
 
 import argparse
 import os
-import shutil
 import sys
 import time
 from concurrent.futures import ThreadPoolExecutor
@@ -36,6 +35,7 @@ def parse(argv=None):
     p.add_argument("--skip_val", action="store_true")
     p.add_argument("--skip_test", action="store_true")
     p.add_argument("--white_background", action="store_true")
+    p.add_argument("--resolution", "-r", type=int, default=None, help="default: the resolution the model was trained at (cfg_args.json)")
     p.add_argument("--sh_degree", type=int, default=3)
     p.add_argument("--png_workers", type=int, default=8)
     args, unknown = p.parse_known_args(argv)
@@ -86,12 +86,17 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     from omfs_4d_video_gen_amd.engine.trainer import Renderer, View
     split = IO.load_split(args.source_path, split_name)
     g = IO.load_gaussian_ply(Path(args.model_path) / "point_cloud" / f"iteration_{it}" / "point_cloud.ply")
-    cfg = Path(args.model_path) / "cfg_args.json"
-    white = args.white_background or (cfg.exists() and json.load(open(cfg)).get("white_background", False))
+    from omfs_4d_video_gen_amd.engine import targets as TG
+    cfg_p = Path(args.model_path) / "cfg_args.json"
+    cfg = json.load(open(cfg_p)) if cfg_p.exists() else {}
+    # as upstream merges the model's cfg_args into the render arguments: background and resolution are the training run's
+    white = args.white_background or bool(cfg.get("white_background", False))
+    resolution = args.resolution if args.resolution is not None else int(cfg.get("resolution", -1))
     bg = (1.0, 1.0, 1.0) if white else (0.0, 0.0, 0.0)
     cams = [IO.camera_from_frame(fr, split["top"]) for fr in split["frames"]]
     if not cams:
         return 0
+    cams = [TG.scaled_camera(c, *TG.training_size(c, resolution)) for c in cams]
     w, h = cams[0]["width"], cams[0]["height"]
     out_dir = Path(args.model_path) / split_name / f"ours_{it}"
     (out_dir / "renders").mkdir(parents=True, exist_ok=True)
@@ -99,7 +104,7 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     flame = tuned_flame(Path(args.model_path) / "point_cloud" / f"iteration_{it}", split["flame"])
     r = Renderer(load_rig(), flame, g, w, h, bg=bg, sh_degree=args.sh_degree)
     pool = ThreadPoolExecutor(max_workers=max(1, args.png_workers))
-    pending = []
+    pending, pending_gt = [], []
     mine = range(rank, len(cams), world)
     n_slots = max(4, 2 * args.png_workers)
 
@@ -114,10 +119,13 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
             pending.pop(0).result()
         rows, event = r.render_png_rows_to_host(view, n_slots)   # GPU-side scanlines, asynchronous copy to pinned memory
         pending.append(pool.submit(encode_and_write, out_dir / "renders" / f"{idx:05d}.png", rows, event))
-        src = os.path.join(args.source_path, split["frames"][idx]["file_path"])
-        if os.path.exists(src):
-            shutil.copyfile(src, out_dir / "gt" / f"{idx:05d}.png")
-    for f in pending:
+        # gt/: the target the trainer was shown for this frame -- resized to the training resolution, matted on the run's
+        # background (engine/targets.py) -- so an evaluator compares like with like (validation_reporting.py:60-78)
+        if os.path.exists(os.path.join(args.source_path, split["frames"][idx]["file_path"])):
+            rgb, mask = TG.load_frame_pixels(args.source_path, split["frames"][idx])
+            gt = TG.prepare_target(rgb, mask, w, h, bg, as_u8=True).cpu().numpy()
+            pending_gt.append(pool.submit(IO.write_png, out_dir / "gt" / f"{idx:05d}.png", gt))
+    for f in pending + pending_gt:
         f.result()
     pool.shutdown()
     r.rast.check_status()

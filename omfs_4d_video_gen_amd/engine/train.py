@@ -89,12 +89,6 @@ def initial_gaussians(n: int, n_faces: int, seed: int) -> dict:
             "binding": (np.arange(n) % n_faces).astype(np.int32)}
 
 
-def resize_nearest(img: np.ndarray, w: int, h: int) -> np.ndarray:
-    ys = (np.arange(h) * img.shape[0] / h).astype(np.int64)
-    xs = (np.arange(w) * img.shape[1] / w).astype(np.int64)
-    return img[ys][:, xs]
-
-
 def main(argv=None):
     args = parse(argv)
     from omfs_4d_video_gen_amd.engine import io_formats as IO
@@ -127,25 +121,18 @@ def main(argv=None):
     # those images; the other views contribute their cameras and timesteps (the compact exchange poses every rank's view)
     from omfs_4d_video_gen_amd.engine.distributed import views_of_rank
     mine = set(views_of_rank(len(split["frames"]), rank, world)) if not args.no_shuffle else set(range(len(split["frames"])))
+    from omfs_4d_video_gen_amd.engine import targets as TG
     with ThreadPoolExecutor(max_workers=8) as pool:          # PNG decode releases the interpreter lock
-        loaded = list(pool.map(lambda ifr: IO.load_image_rgba(os.path.join(args.source_path, ifr[1]["file_path"])) if ifr[0] in mine else (None, None),
+        loaded = list(pool.map(lambda ifr: TG.load_frame_pixels(args.source_path, ifr[1]) if ifr[0] in mine else (None, None),
                                enumerate(split["frames"])))
-    images, alphas = [im for im, _ in loaded], [a for _, a in loaded]
-    del loaded
     # fp32 targets are 4x the bytes of the images: kept while they fit comfortably beside the model, 8-bit otherwise
-    n_px = sum(int(im.shape[0]) * int(im.shape[1]) for im in images if im is not None)
+    cam0 = IO.camera_from_frame(split["frames"][0], split["top"])
+    n_px = sum(1 for im, _ in loaded if im is not None) * int(np.prod(TG.training_size(cam0, args.resolution)))
     store_u8 = args.target_storage == "u8" or (args.target_storage == "auto" and n_px * 12 > 64 << 30)
-    for fr, trow, img, alpha in zip(split["frames"], split["timestep_of_frame"], images, alphas):
+    for fr, trow, (img, mask) in zip(split["frames"], split["timestep_of_frame"], loaded):
         cam = IO.camera_from_frame(fr, split["top"])
-        if args.resolution in (1, 2, 4, 8):
-            w, h = cam["width"] // args.resolution, cam["height"] // args.resolution
-        elif args.resolution > 8:
-            w, h = args.resolution, int(round(cam["height"] * args.resolution / cam["width"]))
-        else:
-            w, h = cam["width"], cam["height"]
-        if (w, h) != (cam["width"], cam["height"]):
-            s = w / cam["width"]
-            cam = {**cam, "width": w, "height": h, "fl_x": cam["fl_x"] * s, "fl_y": cam["fl_y"] * s}
+        w, h = TG.training_size(cam, args.resolution)
+        cam = TG.scaled_camera(cam, w, h)
         if size is None:
             size = (w, h)
         elif size != (w, h):
@@ -153,30 +140,11 @@ def main(argv=None):
         if img is None:                         # another rank's view: camera and timestep only
             views.append(View(cam, int(trow), target=None, name=os.path.basename(fr["file_path"])))
             continue
-        if img.shape[:2] != (h, w):
-            img = resize_nearest(img, w, h)
-        mask_rel = fr.get("fg_mask_path")
-        mask = None
-        if mask_rel and os.path.exists(os.path.join(args.source_path, mask_rel)):
-            mask = IO.read_png(os.path.join(args.source_path, mask_rel))[:, :, 0].astype(np.float32) / 255.0
-            if mask.shape != (h, w):
-                mask = resize_nearest(mask, w, h)
-        elif alpha is not None:                 # the matte travels as the image's alpha channel (upstream-style datasets)
-            mask = alpha.astype(np.float32) / 255.0
-            if mask.shape != (h, w):
-                mask = resize_nearest(mask, w, h)
-        if store_u8:
-            # [H][W][3] bytes in HBM, expanded to fp32 one view at a time by omfs_rgb8_to_image; a soft mask edge is
-            # composited before the 8-bit rounding (at most half a level away from the fp32 composite)
-            if mask is not None:
-                img = np.rint(img.astype(np.float32) * mask[:, :, None] + (1.0 - mask[:, :, None]) * (255.0 * np.asarray(bg, np.float32))).astype(np.uint8)
-            rgb = torch.from_numpy(np.ascontiguousarray(img[:, :, :3]))
-        else:
-            rgb = torch.from_numpy(img.astype(np.float32) / 255.0).permute(2, 0, 1).contiguous()
-            if mask is not None:
-                mt = torch.from_numpy(mask)[None]
-                rgb = rgb * mt + (1.0 - mt) * torch.tensor(bg)[:, None, None]
-        views.append(View(cam, int(trow), target=rgb.cuda(), name=os.path.basename(fr["file_path"])))
+        # resize (PIL's BOX rule) + matte on the run's background on the device (engine/targets.py; render.py writes the very
+        # same pixels as gt/): fp32 planes, or [H][W][3] bytes expanded one view at a time by omfs_rgb8_to_image -- a soft
+        # matte edge is composited before the 8-bit rounding (at most half a level away from the fp32 composite)
+        views.append(View(cam, int(trow), target=TG.prepare_target(img, mask, w, h, bg, as_u8=store_u8), name=os.path.basename(fr["file_path"])))
+    del loaded
     n = args.n_gaussians if args.n_gaussians > 0 else 10 * rig.n_faces
     g0 = initial_gaussians(n, rig.n_faces, args.seed)
     ckpt = None

@@ -65,6 +65,45 @@ def test_flame_parameter_gradients_match_autograd(n, width, height):
         assert d <= 5e-3 * scale + 1e-6, f"{name}: max diff {d} vs max ref {scale}"
 
 
+def test_fused_flame_launches_equal_the_split_ones(monkeypatch):
+    """ABI 6: omfs_flame_pose_lbs (joints + skinning, one frame) writes the SAME BITS as omfs_flame_joints_pose + omfs_flame_lbs,
+    and omfs_flame_skin_param_bwd the gradients of omfs_flame_skin_bwd + omfs_flame_param_bwd (sums reordered: float noise);
+    a second call of the fused backward finds its accumulators zeroed by the first."""
+    rig, g, seq, cam, dflame, ft, model, rast, mk = _setup(3000, 128, 96)
+    t = 1
+    ccam = mk(cam, sh_degree=3, bg=(0.0, 0.0, 0.0))
+
+    def run(split):
+        monkeypatch.setenv("OMFS_FLAME_SPLIT", "1" if split else "0")
+        ft.fused = not split
+        out = []
+        for _ in range(2):
+            ft.begin(t, model.binding)
+            verts, face_xf = dflame.face_frames(t, 1)
+            joint_xf, coef, _, _, v_shaped = dflame._buffers(1)
+            rast.forward(model, face_xf[0], ccam)
+            dimage = torch.randn(3, 96, 128, generator=torch.Generator().manual_seed(11)).cuda()
+            grads = torch.zeros(59, model.n_pad, device="cuda")
+            rast.backward(model, face_xf[0], ccam, grads, dimage=dimage, reg=(0.0, 1.0, 0.0, 0.6), dface=ft.dface)
+            ft.backward(verts[0])
+            torch.cuda.synchronize()
+            out.append({"verts": verts.clone(), "face_xf": face_xf.clone(), "joint_xf": joint_xf.clone(), "coef": coef[:, 0].clone(),
+                        "v_shaped": v_shaped.clone(), "rotmats": dflame.rotmats[t].clone(),
+                        "g": torch.cat([ft.grad["expr"][t].flatten(), ft.grad["pose"][t].flatten(), ft.grad["translation"][t].flatten()]).clone()})
+            ft.grad_flat.zero_()
+        return out
+    split = run(True)
+    ft.sums.zero_(); ft.dcoef.zero_()       # the split launches overwrite their scratch; the fused one accumulates into zeroed words
+    fused = run(False)
+    for k in ("verts", "face_xf", "joint_xf", "coef", "v_shaped", "rotmats"):
+        assert torch.equal(fused[0][k], split[0][k]), k
+    scale = float(split[0]["g"].abs().max())
+    assert scale > 0
+    for a in fused:
+        assert float((a["g"] - split[0]["g"]).abs().max()) <= 2e-5 * scale
+    assert float(ft.dcoef.abs().max()) == 0.0 and float(ft.sums.abs().max()) == 0.0 and float(ft.dverts.abs().max()) == 0.0
+
+
 def test_device_rodrigues_matches_the_pinned_host_formula():
     from omfs_4d_video_gen_amd import _lib as L
     from omfs_4d_video_gen_amd.engine.flame_rig import rodrigues

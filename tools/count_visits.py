@@ -28,5 +28,7 @@ print("fwd(F1): visits %.0f, with hit %.0f (%.1f%%), hit lanes per hit-visit %.1
 print("bwd per-step: union %.0f, max_row %.0f (%.3f of union), sum_rows %.0f (k = %.2f sub-blocks per visit); per-wave max row total %.0f (%.3f of union); waves %.0f"
       % (b[8], b[9], b[9] / b[8], b[10], b[10] / b[8], b[11], b[11] / b[8], b[14]))
 print("bwd: geometric hit lanes per visit %.1f, hit lanes per visit %.1f, sub-blocks with a hit per visit %.2f" % (b[12] / b[0], b[2] / b[0], b[13] / b[0]))
-print("fwd: real visits %.0f, sub-blocks with a hit per visit %.2f, flagged live sub-blocks per visit %.2f, geometric hit lanes %.1f, hit lanes %.1f"
-      % (b[16], b[17] / b[16], b[18] / b[16], b[19] / b[16], b[5] / b[16]))
+print("fwd: real visits %.0f, sub-blocks with a hit per visit %.2f, flagged live sub-blocks per visit %.2f, hit lanes %.1f"
+      % (b[16], b[17] / b[16], b[18] / b[16], b[5] / b[16]))
+print("bwd visits by number of sub-blocks still active (1..4): " + ", ".join("%d: %.1f%% (%.1f hit lanes)" % (k, 100 * b[19 + k] / b[0], b[23 + k] / max(b[19 + k], 1)) for k in (1, 2, 3, 4)))
+print("fwd visits by number of live sub-blocks (1..4): " + ", ".join("%d: %.1f%%" % (k, 100 * b[27 + k] / b[16]) for k in (1, 2, 3, 4)))
