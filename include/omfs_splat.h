@@ -208,8 +208,9 @@ int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_c
  *  scatter : (depth bits, id) pairs into their tile's segment of keys; REPLAYS the tile-test outcomes that the
  *            omfs_bin_count of the same view recorded in keys_tmp (one 64-bit ballot per walk step, followed by every
  *            workgroup's list of non-empty (tile, count) pairs, from which the slot ranges are taken) when status[1]
- *            still carries that call's stamp (same g->n, g->params and camera, no omfs_tile_sort in between); in any
- *            other call order the test is re-evaluated and the pairs are counted again (slower, same result)
+ *            still carries that call's stamp (same g->n, g->params and camera, no omfs_tile_sort and no omfs_project_fwd
+ *            in between: a projection writes new records and clears the stamp); in any other call order the test is
+ *            re-evaluated and the pairs are counted again (slower, same result)
  *  sort    : per-tile sort by (depth bits, id) -> sorted_ids (keys_tmp is scratch again from here on)       */
 int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
 int omfs_bin_scan(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream);
@@ -339,6 +340,18 @@ int omfs_loss_l1_ssim(const float* image, const float* target, int width, int he
  * (`validation_reporting.py:60-78`).                                                                                  */
 int omfs_prepare_target(const uint8_t* src, int channels, int src_width, int src_height, const uint8_t* mask, int width,
                         int height, const float* bg_host, float* out_f32, uint8_t* out_u8, void* stream);
+
+/* PNG egress on the device (ABI 6; SURVEY.md section 8f-3, `render_surgery.py:324-362` reads the frames back as PNG files):
+ * the scanlines of omfs_image_to_png_rows (rows [height][1 + 3 width], filter type 0) become a COMPLETE zlib stream -- fixed
+ * Huffman code, run-length matches one RGB pixel back, one deflate block per scanline closed by an empty stored block (byte
+ * aligned: the rows' blocks concatenate bytewise), final empty block, Adler-32 of all scanlines.  The host wraps it into the
+ * IDAT chunk (length, type, CRC-32) between IHDR and IEND; any PNG reader decodes it to the rows' pixels, bit for bit.
+ *   slots  [height * omfs_png_slot_stride(width)] bytes, sizes [height], adler [2 * height] words: scratch;
+ *   stream [stream_capacity >= height * omfs_png_slot_stride(width) + 16] bytes: the zlib stream;
+ *   stream_len [1]: its length in bytes (0: capacity exceeded, which the sizes above rule out).                        */
+int omfs_png_slot_stride(int width);
+int omfs_png_deflate(const uint8_t* rows, int width, int height, uint8_t* slots, uint32_t* sizes, uint32_t* adler,
+                     uint8_t* stream, uint32_t stream_capacity, uint32_t* stream_len, void* stream_hip);
 
 typedef struct omfs_adam_params {
   float lr[OMFS_NPLANES]; /* learning rate per plane                                              */

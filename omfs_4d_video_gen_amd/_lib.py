@@ -158,6 +158,8 @@ SIGNATURES = {
     "omfs_image_to_rgb8": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_image_to_png_rows": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_rgb8_to_image": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
+    "omfs_png_slot_stride": (C.c_int, [C.c_int]),
+    "omfs_png_deflate": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint32, c_void_p, c_void_p]),
     "omfs_prepare_target": (C.c_int, [c_void_p, C.c_int, C.c_int, C.c_int, c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), c_void_p,
                                       c_void_p, c_void_p]),
     "omfs_composite_bwd": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), C.POINTER(GradBuffersC), c_void_p]),

@@ -70,6 +70,178 @@ __global__ void prepare_target_kernel(const uint8_t* __restrict__ src, int chann
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PNG egress on the device (render_surgery is encode-bound once the frames exist,
+// `02_Visual_Engine/render_surgery.py:324-362` reads them back as PNG files).  The scanlines omfs_image_to_png_rows lays
+// out ([H][1 + 3W] bytes, filter type 0) are turned into a complete zlib stream here; the host adds the PNG chunk framing and
+// the chunk CRC and writes the file.
+//
+// Deflate with the FIXED Huffman code and run-length matches at distance 3 (one RGB pixel back: a constant background of
+// any colour is a run; the Z_RLE strategy the host encoder used only sees distance 1).  One wave per scanline:
+//   1. the row is staged in LDS with coalesced 16-byte loads; lane l owns piece l of it (row_bytes / 64 bytes);
+//   2. pass 1 walks the piece greedily (run of >= 4 bytes equal to the byte 3 back -> one length/distance pair, else a
+//      literal) and counts bits; a wave-wide prefix sum gives every lane its bit offset;
+//   3. pass 2 walks again and ORs its codes into the LDS image of the row's block (LDS atomics: neighbouring lanes share words);
+//   4. the block is closed with the end-of-block code and an EMPTY STORED BLOCK, which pads to a byte boundary (the zlib
+//      "sync flush" marker), so the rows' blocks can be concatenated bytewise whatever their bit lengths;
+//   5. the row's Adler-32 terms (sum of bytes, position-weighted sum) are reduced for the stream's checksum.
+// omfs_png_assemble then places row r at 2 + sum(sizes[< r]) (every wave sums the sizes in front of it: no scan launch), and one
+// extra wave writes the zlib header, the final empty block, the Adler-32 of all scanlines and the stream length.
+constexpr uint32_t ADLER_MOD = 65521u;
+
+__device__ __forceinline__ uint32_t bitrev(uint32_t v, int n) { return __brev(v) >> (32 - n); }
+
+// fixed-Huffman code of a literal / length symbol, already bit-reversed for the LSB-first stream: (bits, count)
+__device__ __forceinline__ void lit_code(uint32_t sym, uint32_t& bits, int& n) {
+  if (sym < 144u) { bits = bitrev(0x30u + sym, 8); n = 8; }
+  else if (sym < 256u) { bits = bitrev(0x190u + (sym - 144u), 9); n = 9; }
+  else if (sym < 280u) { bits = bitrev(sym - 256u, 7); n = 7; }
+  else { bits = bitrev(0xC0u + (sym - 280u), 8); n = 8; }
+}
+// length 3..258 -> its length symbol + extra bits, then the distance symbol of distance 3 (code 2, five bits, no extra bits)
+__device__ __forceinline__ void match_code(int len, unsigned long long& bits, int& n) {
+  uint32_t sym, extra = 0;
+  int ebits = 0;
+  if (len == 258) sym = 285u;
+  else if (len <= 10) sym = 254u + (uint32_t)len;
+  else {
+    const int l3 = len - 3;
+    ebits = (31 - __clz(l3)) - 2;                       // 11..18 -> 1, 19..34 -> 2, ... 131..257 -> 5
+    sym = 257u + (uint32_t)(4 * ebits) + (uint32_t)((l3 >> ebits) & 3) + 4u;
+    extra = (uint32_t)l3 & ((1u << ebits) - 1u);
+  }
+  uint32_t cb; int cn;
+  lit_code(sym, cb, cn);
+  bits = (unsigned long long)cb | ((unsigned long long)extra << cn) | ((unsigned long long)bitrev(2u, 5) << (cn + ebits));
+  n = cn + ebits + 5;
+}
+
+// greedy tokenisation of bytes [b, e) of the staged row; `emit(bits, n)` receives every code in stream order
+template <typename Emit>
+__device__ __forceinline__ void deflate_piece(const uint8_t* row, int b, int e, Emit&& emit) {
+  int i = b;
+  while (i < e) {
+    int run = 0;
+    if (i >= 3) {
+      const int lim = min(e - i, 258);
+      while (run < lim && row[i + run] == row[i + run - 3]) ++run;
+    }
+    if (run >= 4) {
+      unsigned long long bits; int n;
+      match_code(run, bits, n);
+      emit(bits, n);
+      i += run;
+    } else {
+      uint32_t bits; int n;
+      lit_code(row[i], bits, n);
+      emit((unsigned long long)bits, n);
+      ++i;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void png_deflate_rows_kernel(const uint8_t* __restrict__ rows, int row_bytes, int height,
+                                                              uint8_t* __restrict__ slots, int slot_stride,
+                                                              uint32_t* __restrict__ sizes, uint32_t* __restrict__ adler) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int row_pad = (row_bytes + 4 + 15) / 16 * 16;
+  uint32_t* s_out = reinterpret_cast<uint32_t*>(lds + row_pad);     // [slot_stride / 4] words of the row's deflate block
+  const uint8_t* src = rows + (size_t)r * row_bytes;
+  // stage: a row starts at an arbitrary byte offset of the scanline buffer -> aligned dword loads of the words that cover it,
+  // the LDS image is shifted by the same 0..3 bytes
+  const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3u);
+  const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src - mis);
+  uint32_t* lds32 = reinterpret_cast<uint32_t*>(lds);
+  for (int i = lane; i < (row_bytes + mis + 3) / 4; i += 64) lds32[i] = src32[i];
+  const uint8_t* s_row = lds + mis;                         // [row_bytes]
+  for (int i = lane; i < slot_stride / 4; i += 64) s_out[i] = 0u;
+  __syncthreads();
+  const int piece = max(64, (row_bytes + 63) / 64);        // short rows use fewer lanes: a run is cut at every piece boundary
+  const int b = min(lane * piece, row_bytes), e = min(b + piece, row_bytes);
+  // pass 1: bits of this lane's piece, Adler terms
+  uint32_t nbits = 0, a_sum = 0, b_sum = 0;
+  deflate_piece(s_row, b, e, [&](unsigned long long, int n) { nbits += (uint32_t)n; });
+  for (int i = b; i < e; ++i) { const uint32_t d = s_row[i]; a_sum += d; b_sum += (uint32_t)(row_bytes - i) * d; }   // < 2^32: 91 * 255 * 11521
+  const uint32_t incl = wave_incl_scan_u32(nbits, lane);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  uint32_t pos = 3u + incl - nbits;                        // behind the 3-bit block header
+  // pass 2: emit
+  unsigned long long acc = 0ull;
+  int nacc = (int)(pos & 31u);
+  uint32_t w = pos >> 5;
+  auto put = [&](unsigned long long bits, int n) {
+    acc |= bits << nacc;
+    nacc += n;
+    if (nacc >= 32) { atomicOr(&s_out[w], (uint32_t)acc); acc >>= 32; nacc -= 32; ++w; }
+  };
+  deflate_piece(s_row, b, e, put);
+  if (nacc) atomicOr(&s_out[w], (uint32_t)acc);
+  uint32_t end_bits = 3u + total;
+  if (lane == 0) {
+    atomicOr(&s_out[0], 2u);                               // BFINAL = 0, BTYPE = 01 (fixed Huffman): bits 0, 1, 0
+    end_bits += 7u;                                        // end of block: seven zero bits (already there)
+    end_bits += 3u;                                        // empty stored block: BFINAL = 0, BTYPE = 00 (zero bits) ...
+    const uint32_t byte0 = (end_bits + 7u) >> 3;           // ... padded to a byte boundary, then LEN = 0, NLEN = 0xFFFF
+    uint8_t* ob = reinterpret_cast<uint8_t*>(s_out);
+    ob[byte0 + 2] = 0xFF; ob[byte0 + 3] = 0xFF;            // nobody else touches bytes behind the block
+    sizes[r] = byte0 + 4u;
+  }
+  // Adler terms of the row, modulo 65521 (lane terms < 2^32, their residues < 2^16: the wave sum fits 32 bits)
+  uint32_t ra = a_sum % ADLER_MOD, rb = b_sum % ADLER_MOD;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { ra += (uint32_t)__shfl_xor((int)ra, d, 64); rb += (uint32_t)__shfl_xor((int)rb, d, 64); }
+  if (lane == 0) { adler[2 * r] = ra % ADLER_MOD; adler[2 * r + 1] = rb % ADLER_MOD; }
+  __syncthreads();
+  const uint32_t n_out = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((3u + total + 7u + 3u + 7u) >> 3) + 4u));
+  uint32_t* dst = reinterpret_cast<uint32_t*>(slots + (size_t)r * slot_stride);
+  for (uint32_t i = lane; i < (n_out + 3u) / 4u; i += 64) dst[i] = s_out[i];
+}
+
+// grid = height + 1 waves.  Wave r < height copies row r's block to its place in the stream; wave `height` writes the frame.
+__global__ __launch_bounds__(64) void png_assemble_kernel(const uint8_t* __restrict__ slots, int slot_stride, const uint32_t* __restrict__ sizes,
+                                                          const uint32_t* __restrict__ adler, int height, int row_bytes,
+                                                          uint8_t* __restrict__ stream, uint32_t stream_capacity,
+                                                          uint32_t* __restrict__ stream_len) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int upto = r < height ? r : height;
+  uint32_t off = 0;
+  for (int j = lane; j < upto; j += 64) off += sizes[j];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) off += (uint32_t)__shfl_xor((int)off, d, 64);
+  off += 2u;                                               // zlib header
+  if (r < height) {
+    const uint32_t n = sizes[r];
+    if (off + n + 9u > stream_capacity) return;            // cannot happen with the capacity the host sizes; never write outside
+    const uint8_t* src = slots + (size_t)r * slot_stride;
+    for (uint32_t i = lane; i < n; i += 64) stream[off + i] = src[i];
+    return;
+  }
+  // Adler-32 of all scanlines from the rows' terms: A = 1 + sum A_r, B = sum B_r + L H + L sum_j (H - 1 - j) A_j  (mod 65521)
+  unsigned long long sa = 0ull, sb = 0ull, sw = 0ull;
+  for (int j = lane; j < height; j += 64) {
+    const unsigned long long aj = adler[2 * j], bj = adler[2 * j + 1];
+    sa += aj; sb += bj; sw += (unsigned long long)(height - 1 - j) * aj;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    sa += ((unsigned long long)(uint32_t)__shfl_xor((int)(sa >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)sa, d, 64);
+    sb += ((unsigned long long)(uint32_t)__shfl_xor((int)(sb >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)sb, d, 64);
+    sw += ((unsigned long long)(uint32_t)__shfl_xor((int)(sw >> 32), d, 64) << 32) | (uint32_t)__shfl_xor((int)sw, d, 64);
+  }
+  if (lane != 0) return;
+  const unsigned long long L = (unsigned long long)row_bytes % ADLER_MOD;
+  const uint32_t A = (uint32_t)((1ull + sa) % ADLER_MOD);
+  const uint32_t B = (uint32_t)((sb % ADLER_MOD + (L * ((unsigned long long)height % ADLER_MOD)) % ADLER_MOD + (L * (sw % ADLER_MOD)) % ADLER_MOD) % ADLER_MOD);
+  if (off + 9u > stream_capacity) { stream_len[0] = 0u; return; }
+  stream[0] = 0x78; stream[1] = 0x01;                      // zlib: deflate, 32 KB window, no dictionary, fastest
+  uint8_t* t = stream + off;
+  t[0] = 0x01; t[1] = 0x00; t[2] = 0x00; t[3] = 0xFF; t[4] = 0xFF;     // final block: stored, empty
+  t[5] = (uint8_t)(B >> 8); t[6] = (uint8_t)B; t[7] = (uint8_t)(A >> 8); t[8] = (uint8_t)A;   // Adler-32, big endian: B << 16 | A
+  stream_len[0] = off + 9u;
+}
+
 }  // namespace omfs
 
 using namespace omfs;
@@ -81,6 +253,27 @@ extern "C" int omfs_prepare_target(const uint8_t* src, int channels, int src_wid
   OMFS_REQUIRE(width <= src_width * 64 && height <= src_height * 64, "upscaling beyond 64x is not an image-loading case");
   hipLaunchKernelGGL(prepare_target_kernel, dim3(cdiv(width * height, 256)), dim3(256), 0, (hipStream_t)stream, src, channels,
                      src_width, src_height, mask, width, height, bg_host[0], bg_host[1], bg_host[2], out_f32, out_u8);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_png_slot_stride(int width) {
+  const int row_bytes = 1 + 3 * width;
+  return ((row_bytes * 9 + 7) / 8 + 32 + 15) / 16 * 16;      // every byte a 9-bit literal, plus block header, end of block, flush marker
+}
+
+extern "C" int omfs_png_deflate(const uint8_t* rows, int width, int height, uint8_t* slots, uint32_t* sizes, uint32_t* adler,
+                                uint8_t* stream, uint32_t stream_capacity, uint32_t* stream_len, void* stream_hip) {
+  OMFS_REQUIRE(rows && slots && sizes && adler && stream && stream_len && width > 0 && height > 0, "args");
+  const int row_bytes = 1 + 3 * width, stride = omfs_png_slot_stride(width);
+  OMFS_REQUIRE((size_t)stream_capacity >= (size_t)height * stride + 16, "stream_capacity < height * omfs_png_slot_stride(width) + 16");
+  const size_t lds = (size_t)((row_bytes + 4 + 15) / 16 * 16) + (size_t)stride;
+  OMFS_REQUIRE(lds <= 64 * 1024, "scanline too long for the LDS image of its deflate block");
+  hipStream_t s = (hipStream_t)stream_hip;
+  hipLaunchKernelGGL(png_deflate_rows_kernel, dim3(height), dim3(64), lds, s, rows, row_bytes, height, slots, stride, sizes, adler);
+  OMFS_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(png_assemble_kernel, dim3(height + 1), dim3(64), 0, s, (const uint8_t*)slots, stride, (const uint32_t*)sizes,
+                     (const uint32_t*)adler, height, row_bytes, stream, stream_capacity, stream_len);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -29,9 +29,13 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(int n, int n_pad, cons
                                                           const int32_t* __restrict__ binding,
                                                           const float* __restrict__ face_xf, ProjCam cam,
                                                           float4* __restrict__ g0, float4* __restrict__ g1,
-                                                          float4* __restrict__ g2, uint32_t* __restrict__ n_visible) {
+                                                          float4* __restrict__ g2, uint32_t* __restrict__ n_visible,
+                                                          uint32_t* __restrict__ status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (n_visible && i == 0) n_visible[0] = 0u;      // accumulated by omfs_bin_count, which runs after this kernel
+  // new projected records: tile-test ballots an earlier omfs_bin_count left for omfs_bin_scatter (replay stamp, status[1]) were
+  // taken from OTHER records -- same parameter pointer and camera, e.g. the previous iteration's -- and must not be replayed
+  if (status && i == 0) status[1] = 0u;
   if (i >= n) return;
   auto P = [&](int plane) { return params[(size_t)plane * n_pad + i]; };
 
@@ -175,7 +179,7 @@ extern "C" int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, c
   ProjCam pc = make_projcam(cam);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(project_fwd_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, g->n_pad, g->params, g->binding,
-                     face_xf, pc, (float4*)rb->g0, (float4*)rb->g1, (float4*)rb->g2, rb->n_visible);
+                     face_xf, pc, (float4*)rb->g0, (float4*)rb->g1, (float4*)rb->g2, rb->n_visible, rb->status);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

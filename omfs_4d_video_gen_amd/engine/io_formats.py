@@ -50,6 +50,13 @@ def encode_png_rows(rows, width: int, height: int, level: int = 1) -> bytes:
         _chunk(b"IDAT", co.compress(memoryview(a).cast("B")) + co.flush()) + _chunk(b"IEND", b"")
 
 
+def png_from_zlib_stream(stream, width: int, height: int) -> bytes:
+    """PNG file bytes around a ready-made zlib stream of the RGB scanlines (`Rasterizer.to_png_stream`: deflated on the
+    device): chunk framing and the IDAT chunk's CRC-32 are all that is left for the host."""
+    data = bytes(stream) if not isinstance(stream, (bytes, bytearray)) else stream
+    return _PNG_SIG + _chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, 2, 0, 0, 0)) + _chunk(b"IDAT", data) + _chunk(b"IEND", b"")
+
+
 def write_png(path, img: np.ndarray, level: int = 1) -> None:
     with open(path, "wb") as f:
         f.write(encode_png(img, level))

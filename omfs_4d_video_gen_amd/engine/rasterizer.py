@@ -116,10 +116,33 @@ class Rasterizer:
                 "omfs_image_to_rgb8")
         return self.rgb8
 
+    def to_png_stream(self, stream: torch.Tensor | None = None, length: torch.Tensor | None = None):
+        """The frame as a complete zlib stream of its PNG scanlines, deflated ON THE DEVICE (omfs_png_deflate): returns
+        (stream uint8 [capacity], length int32 [1]) device tensors -- the first `length` bytes are the payload of the PNG's IDAT
+        chunk (io_formats.png_from_zlib_stream).  `stream` / `length`: caller-owned outputs (a ring of frames in flight)."""
+        rows = self.to_png_rows()
+        lib = L.load()
+        if getattr(self, "_png_scratch", None) is None:
+            stride = int(lib.omfs_png_slot_stride(self.width))
+            z = lambda n, dt: torch.zeros(n, dtype=dt, device=self.device)
+            self._png_scratch = (z(self.height * stride, torch.uint8), z(self.height, torch.int32), z(2 * self.height, torch.int32))
+            self.png_stream_capacity = self.height * stride + 16
+            self._png_stream, self._png_len = z(self.png_stream_capacity, torch.uint8), z(1, torch.int32)
+        slots, sizes, adler = self._png_scratch
+        stream = self._png_stream if stream is None else stream
+        length = self._png_len if length is None else length
+        if stream.numel() < self.png_stream_capacity or stream.dtype != torch.uint8 or not stream.is_contiguous():
+            raise ValueError(f"stream must be a contiguous uint8 tensor of at least {self.png_stream_capacity} bytes")
+        L.check(lib.omfs_png_deflate(L.ptr(rows), self.width, self.height, L.ptr(slots), L.ptr(sizes), L.ptr(adler), L.ptr(stream),
+                                     int(stream.numel()), L.ptr(length), L.stream_ptr()), "omfs_png_deflate")
+        return stream, length
+
     def to_png_rows(self) -> torch.Tensor:
         """[H][1 + 3W] uint8: the frame as PNG scanlines (filter byte 0 per row), ready for io_formats.encode_png_rows."""
         if getattr(self, "png_rows", None) is None:
-            self.png_rows = torch.zeros(self.height, 1 + 3 * self.width, dtype=torch.uint8, device=self.device)
+            # (+16 bytes: the deflate kernel reads the aligned words that cover a scanline)
+            self._png_rows_store = torch.zeros(self.height * (1 + 3 * self.width) + 16, dtype=torch.uint8, device=self.device)
+            self.png_rows = self._png_rows_store[:self.height * (1 + 3 * self.width)].view(self.height, 1 + 3 * self.width)
         L.check(L.load().omfs_image_to_png_rows(L.ptr(self.image), self.width, self.height, L.ptr(self.png_rows), L.stream_ptr()),
                 "omfs_image_to_png_rows")
         return self.png_rows

@@ -108,17 +108,17 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     mine = range(rank, len(cams), world)
     n_slots = max(4, 2 * args.png_workers)
 
-    def encode_and_write(path, rows, event):
-        event.synchronize()                                   # the frame's device-to-host copy has landed
+    def encode_and_write(path, k, event):
+        # the frame was deflated on the device (omfs_png_deflate): fetch the zlib stream, add the PNG framing + chunk CRC, write
         with open(path, "wb") as f:
-            f.write(IO.encode_png_rows(rows, w, h))
+            f.write(IO.png_from_zlib_stream(r.fetch_png_stream(k, event), w, h))
 
     for idx in mine:
         view = View(cams[idx], split["timestep_of_frame"][idx])
         if len(pending) >= n_slots:                           # the pinned ring is reused: keep at most n_slots frames in flight
             pending.pop(0).result()
-        rows, event = r.render_png_rows_to_host(view, n_slots)   # GPU-side scanlines, asynchronous copy to pinned memory
-        pending.append(pool.submit(encode_and_write, out_dir / "renders" / f"{idx:05d}.png", rows, event))
+        k, event = r.render_png_stream(view, n_slots)         # GPU-side scanlines + deflate into ring slot k
+        pending.append(pool.submit(encode_and_write, out_dir / "renders" / f"{idx:05d}.png", k, event))
         # gt/: the target the trainer was shown for this frame -- resized to the training resolution, matted on the run's
         # background (engine/targets.py) -- so an evaluator compares like with like (validation_reporting.py:60-78)
         if os.path.exists(os.path.join(args.source_path, split["frames"][idx]["file_path"])):

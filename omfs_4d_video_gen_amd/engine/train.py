@@ -60,6 +60,7 @@ def parse(argv=None):
     p.add_argument("--flame_pose_lr", type=float, default=1e-5)
     p.add_argument("--flame_trans_lr", type=float, default=1e-6)
     p.add_argument("--start_checkpoint", type=str, default=None)
+    p.add_argument("--dup_capacity", type=int, default=0, help="initial (Gaussian, tile) pair capacity (0 = sized from the cloud and the image; grown on overflow)")
     p.add_argument("--coherent_order", action="store_true",
                    help="store the cloud along a Morton curve over its parent triangles (measured neutral on MI355X: projection kernels "
                         "gain what the atomic-based binning loses; off by default)")
@@ -87,6 +88,57 @@ def initial_gaussians(n: int, n_faces: int, seed: int) -> dict:
     return {"xyz": xyz, "log_scale": np.full((n, 3), np.log(0.5), np.float32), "rot": rot,
             "opacity": np.full(n, float(np.log(0.1 / 0.9)), np.float32), "sh": sh,
             "binding": (np.arange(n) % n_faces).astype(np.int32)}
+
+
+class Rollback:
+    """Device-side snapshot of everything a training iteration changes (Gaussian parameters, their Adam moments, the
+    densification statistics, the tuned FLAME tensors and their moments, the counters), taken at every log interval that found
+    the tile-list capacity sufficient.  An interval that overflowed rendered EMPTY lists from the overflowing iteration on (the
+    scan zeroes them): its Adam steps saw momentum and regularisers only.  It is not kept: the trainer is put back to the
+    snapshot, the capacity grown and the interval redone (the view order is a function of the iteration, so the redo sees the
+    same views).  Cost: three [59][n_pad] device copies per log interval."""
+
+    def __init__(self, trainer):
+        self.t = trainer
+        self.s = None
+
+    def take(self, it: int) -> None:
+        t = self.t
+        m, ft = t.model, t.flame_ft
+        s = self.s
+        if s is None or s["params"].shape != m.params.shape:
+            s = self.s = {"params": torch.empty_like(m.params), "m": torch.empty_like(t.opt.m), "v": torch.empty_like(t.opt.v),
+                          "binding": torch.empty_like(m.binding)}
+        s["params"].copy_(m.params); s["m"].copy_(t.opt.m); s["v"].copy_(t.opt.v); s["binding"].copy_(m.binding)
+        s["stats"] = None if t.densify_stats is None else t.densify_stats.clone()
+        s["flame"] = None if ft is None else ({k: v.clone() for k, v in ft.params.items()}, {k: v.clone() for k, v in ft.m.items()},
+                                              {k: v.clone() for k, v in ft.v.items()}, ft.step_count)
+        s["n"], s["order"] = m.n, m.order
+        s["it"], s["opt_step"], s["step_idx"], s["sh_degree"] = it, t.opt.step_count, t.step_idx, t.sh_degree
+
+    def restore(self) -> int:
+        t, s = self.t, self.s
+        m, ft = t.model, t.flame_ft
+        if s["params"].shape != m.params.shape:            # a densification lies inside the interval: put the old buffers back
+            m.params, m.binding, m.n, m.n_pad = s["params"].clone(), s["binding"].clone(), s["n"], int(s["params"].shape[1])
+            t.opt.m, t.opt.v = s["m"].clone(), s["v"].clone()
+            t.grads = torch.zeros_like(m.params)
+            t.rast.g2[m.n:].zero_()
+        else:
+            m.params.copy_(s["params"]); t.opt.m.copy_(s["m"]); t.opt.v.copy_(s["v"]); m.binding.copy_(s["binding"]); m.n = s["n"]
+        m.order = s["order"]
+        t.densify_stats = None if s["stats"] is None else s["stats"].clone()
+        if ft is not None:
+            p_, m_, v_, n_ = s["flame"]
+            for k in ft.params:
+                ft.params[k].copy_(p_[k]); ft.m[k].copy_(m_[k]); ft.v[k].copy_(v_[k])
+            ft.step_count = n_
+            ft.grad_flat.zero_()
+            ft.refresh_rotmats()
+        t.opt.step_count, t.step_idx, t.sh_degree = s["opt_step"], s["step_idx"], s["sh_degree"]
+        t._prefetch, t._frames_ready, t._state_step = None, None, -1     # frames posed ahead belong to the discarded state
+        t.invalidate_graphs()
+        return s["it"]
 
 
 def main(argv=None):
@@ -158,7 +210,7 @@ def main(argv=None):
     cap = (args.max_gaussians if args.max_gaussians > 0 else 4 * n) if densify else n
     trainer = Trainer(rig, split["flame"], g0, views, size[0], size[1], bg=bg, iterations=args.iterations,
                       sh_degree_max=args.sh_degree, start_sh_degree=0, rank=rank, world_size=world, process_group=pg,
-                      n_capacity=cap, finetune_flame=args.finetune_flame_params, coherent_order=args.coherent_order,
+                      n_capacity=cap, dup_capacity=args.dup_capacity or None, finetune_flame=args.finetune_flame_params, coherent_order=args.coherent_order,
                       shuffle_views=None if args.no_shuffle else args.seed,
                       flame_lr={"expr": args.flame_expr_lr, "pose": args.flame_pose_lr, "translation": args.flame_trans_lr})
     it0 = 0
@@ -193,25 +245,56 @@ def main(argv=None):
             json.dump({**vars(args), "n_gaussians": n, "n_train_views": len(views), "world_size": world}, f, indent=2)
     save_at, ckpt_at = set(args.save_iterations) | {args.iterations}, set(args.checkpoint_iterations)
     t0 = time.time()
-    for it in range(it0 + 1, args.iterations + 1):
+    rollback = Rollback(trainer)
+    rollback.take(it0)
+
+    def overflow_anywhere() -> bool:
+        # ranks render different views and overflow independently, but a rolled-back interval is redone by ALL of them
+        over = trainer.rast.overflowed()
+        if world > 1:
+            import torch.distributed as dist
+            flag = torch.tensor([1.0 if over else 0.0], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            return bool(flag.item() > 0), over
+        return over, over
+
+    def redo_from_snapshot(it_now: int) -> int:
+        anywhere, mine_over = overflow_anywhere()
+        if not anywhere:
+            return -1
+        new_cap = trainer.rast.grow_dup_capacity(2.0) if mine_over else trainer.rast.dup_capacity
+        back = rollback.restore()
+        if controller is not None:
+            controller.log = [e for e in controller.log if e["iteration"] <= back]
+        print(f"[ITER {it_now}] rank {rank}: tile-list capacity exceeded after iteration {back} (those iterations rendered empty "
+              f"lists): capacity {new_cap} pairs, iterations {back + 1}..{it_now} are redone", flush=True)
+        return back
+
+    it = it0
+    while it < args.iterations:
+        it += 1
         trainer.step()
         if controller is not None:
             n_before = trainer.model.n
             controller.after_step(it)
-            if rank == 0 and trainer.model.n != n_before:
-                print(f"[ITER {it}] densify: {controller.log[-1]}", flush=True)
+            if trainer.model.n != n_before:
+                back = redo_from_snapshot(it)          # never snapshot a cloud that was densified on empty renders
+                if back >= 0:
+                    it = back
+                    continue
+                rollback.take(it)
+                if rank == 0:
+                    print(f"[ITER {it}] densify: {controller.log[-1]}", flush=True)
         if it % args.log_every == 0 or it == args.iterations:
             if rank == 0:
                 print(f"Training progress: iteration {it}/{args.iterations} loss={trainer.loss_value():.5f} "
                       f"({(it - it0) / (time.time() - t0):.1f} it/s)", flush=True)
-            # Tile-list capacity: an overflowed iteration rendered the background only (the scan empties every list), so it is
-            # looked for at every log interval -- loss_value() above has synced the host already.  Ranks render different
-            # views and overflow independently; no collective is involved, each rank grows its own buffers.
-            if trainer.rast.overflowed():
-                new_cap = trainer.rast.grow_dup_capacity(2.0)
-                trainer.invalidate_graphs()          # captured iterations (OMFS_STEP_GRAPH=1) hold the old buffers' addresses
-                print(f"[ITER {it}] rank {rank}: tile-list capacity exceeded within the last {args.log_every} iterations "
-                      f"(those rendered empty lists): grown to {new_cap} pairs", flush=True)
+            # Tile-list capacity: looked at once per log interval (loss_value() above has synced the host already)
+            back = redo_from_snapshot(it)
+            if back >= 0:
+                it = back
+                continue
+            rollback.take(it)
         if rank == 0 and it in save_at:
             print(f"\n[ITER {it}] Saving Gaussians", flush=True)
             g = trainer.model.to_dict()

@@ -594,6 +594,49 @@ class Renderer:
         self._host_events[k].record()
         return self._host_ring[k].numpy(), self._host_events[k]
 
+    def render_png_stream(self, view: View, n_slots: int = 4):
+        """Enqueue one frame and its DEVICE-side PNG deflate (`Rasterizer.to_png_stream`) into slot k of a ring of n_slots
+        stream buffers.  Returns (k, event): once the event has fired, `fetch_png_stream(k, event)` -- any thread -- brings the
+        zlib stream to the host.  The slot is reused after n_slots further calls."""
+        self.render(view)
+        r = self.rast
+        if getattr(self, "_png_ring", None) is None or len(self._png_ring) != n_slots:
+            r.to_png_stream()                              # sizes the scratch buffers
+            cap = r.png_stream_capacity
+            self._png_ring = [(torch.zeros(cap, dtype=torch.uint8, device=self.device), torch.zeros(1, dtype=torch.int32, device=self.device))
+                              for _ in range(n_slots)]
+            self._png_host = [(torch.empty(cap, dtype=torch.uint8, pin_memory=True), torch.zeros(1, dtype=torch.int32, pin_memory=True))
+                              for _ in range(n_slots)]
+            self._png_events = [torch.cuda.Event() for _ in range(n_slots)]
+            self._png_next = 0
+            import threading
+            self._png_tls = threading.local()
+        k = self._png_next
+        self._png_next = (k + 1) % n_slots
+        r.to_png_stream(*self._png_ring[k])
+        self._png_events[k].record()
+        return k, self._png_events[k]
+
+    def fetch_png_stream(self, k: int, event) -> memoryview:
+        """The zlib stream of ring slot k on the host (pinned memory, valid until the slot is reused): the length first (4 bytes),
+        then exactly that many bytes -- about a tenth of the raw scanlines for a head on a plain background.  Runs on a copy
+        stream of the calling thread, so encoder threads do not serialise behind the render stream."""
+        tls = self._png_tls
+        if getattr(tls, "stream", None) is None:
+            tls.stream = torch.cuda.Stream(device=self.device)
+        dev_stream, dev_len = self._png_ring[k]
+        host_stream, host_len = self._png_host[k]
+        with torch.cuda.stream(tls.stream):
+            tls.stream.wait_event(event)
+            host_len.copy_(dev_len, non_blocking=True)
+            tls.stream.synchronize()
+            n = int(host_len[0])
+            if n <= 0 or n > host_stream.numel():
+                raise L.OmfsError(f"device PNG deflate reported an impossible stream length {n}")
+            host_stream[:n].copy_(dev_stream[:n], non_blocking=True)
+            tls.stream.synchronize()
+        return memoryview(host_stream.numpy())[:n]
+
     def render(self, view: View, rgb8: bool = False):
         """Enqueue one frame; returns the reused image tensor ([3][H][W] fp32 or [H][W][3] uint8)."""
         key = id(view)

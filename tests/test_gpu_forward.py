@@ -191,6 +191,75 @@ def test_png_scanlines_match_rgb8():
     assert np.array_equal(rows[:, 1:].reshape(52, 100, 3), rgb8)
 
 
+@pytest.mark.parametrize("width,height", [(100, 52), (96, 80), (333, 47), (1920, 1080)])
+def test_device_png_deflate_decodes_to_the_frame(width, height):
+    """omfs_png_deflate: the zlib stream built on the device inflates to exactly the scanlines (so any PNG reader decodes the
+    frame bit for bit), for noise (every byte a literal, half of them 9-bit codes), constant colours (runs one pixel back),
+    a rendered-looking mix, and rows whose start is not word-aligned."""
+    import io
+    import zlib
+    from PIL import Image
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    from omfs_4d_video_gen_amd.engine.rasterizer import Rasterizer
+    rast = Rasterizer(256, width, height)
+    gen = torch.Generator().manual_seed(width)
+    yy, xx = torch.meshgrid(torch.arange(height), torch.arange(width), indexing="ij")
+    blob = ((yy - height / 2) ** 2 + (xx - width / 2) ** 2) < (min(width, height) / 3) ** 2
+    noise = torch.rand(3, height, width, generator=gen)
+    cases = {"noise": noise, "black": torch.zeros(3, height, width), "colour": torch.tensor([0.2, 0.7, 0.45])[:, None, None].expand(3, height, width),
+             "white": torch.ones(3, height, width), "head": torch.where(blob[None], noise, torch.tensor([0.1, 0.9, 0.3])[:, None, None]),
+             "short_runs": (torch.arange(width)[None, None, :] // 2 % 2).float().expand(3, height, width)}
+    for name, img in cases.items():
+        rast.image.copy_(img.contiguous().cuda())
+        want = rast.to_rgb8().cpu().numpy().copy()
+        rows = rast.to_png_rows().cpu().numpy().copy()
+        stream, length = rast.to_png_stream()
+        torch.cuda.synchronize()
+        n = int(length.item())
+        data = stream[:n].cpu().numpy().tobytes()
+        assert 0 < n <= rast.png_stream_capacity, name
+        assert zlib.decompress(data) == rows.tobytes(), name                       # header, every block, final block and Adler-32
+        png = IO.png_from_zlib_stream(data, width, height)
+        assert np.array_equal(np.asarray(Image.open(io.BytesIO(png)).convert("RGB")), want), name
+        if name in ("black", "colour", "white"):
+            assert n < rows.size // 10, (name, n)                                  # a plain background costs next to nothing
+        if name == "noise":
+            assert n < rows.size * 1.08, (name, n)                                 # fixed Huffman: at most 9 bits per byte
+
+
+def test_renderer_png_ring_delivers_every_frame():
+    """Renderer.render_png_stream / fetch_png_stream: frames in flight in a ring, fetched by worker threads on their own copy
+    streams, decode to the frames rendered one by one."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, View
+    rig = synthetic.make_rig(0)
+    seq = synthetic.make_flame_sequence(12, 0)
+    g = synthetic.make_gaussians(6000, rig.faces.shape[0], 0)
+    W, Hh = 200, 152
+    r = Renderer(FlameRig.from_synthetic(rig), seq, g, W, Hh, bg=(1.0, 1.0, 1.0))
+    views = [View(synthetic.make_camera(W, Hh, yaw=0.1 * i - 0.5), i) for i in range(12)]
+    want = [r.render(v, rgb8=True).cpu().numpy().copy() for v in views]
+    def decode(k, ev):
+        return np.asarray(Image.open(io.BytesIO(IO.png_from_zlib_stream(r.fetch_png_stream(k, ev), W, Hh))).convert("RGB"))
+
+    got = {}
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        futs = []
+        for v in views:
+            if len(futs) >= 4:                         # at most n_slots frames in flight: the oldest slot is about to be reused
+                t, f = futs.pop(0)
+                got[t] = f.result()
+            futs.append((v.timestep, pool.submit(decode, *r.render_png_stream(v, 4))))
+        for t, f in futs:
+            got[t] = f.result()
+    for v in views:
+        assert np.array_equal(got[v.timestep], want[v.timestep]), v.timestep
+
+
 def test_rgb8_targets_expand_to_the_host_conversion():
     """omfs_rgb8_to_image: [H][W][3] bytes -> planar fp32, bit-identical to numpy's uint8 / 255 in fp32."""
     from omfs_4d_video_gen_amd import _lib as L
@@ -307,6 +376,24 @@ def test_scatter_recomputes_the_tile_test_when_the_recorded_ballots_are_not_its_
     other = mk(synthetic.make_camera(320, 256, yaw=-0.5))
     L.check(lib.omfs_bin_count(gs, other, rast.rb, s), "omfs_bin_count")
     rast.tile_count.zero_(); rast.keys.zero_(); rast.sorted_ids.zero_(); rast.tile_cursor.zero_()
+    L.check(lib.omfs_bin_scatter(gs, ccam, rast.rb, s), "omfs_bin_scatter")
+    L.check(lib.omfs_tile_sort(ccam, rast.rb, s), "omfs_tile_sort")
+    torch.cuda.synchronize()
+    assert torch.equal(rast.sorted_ids[:D], ids)
+    # a count taken on OTHER projected records (same parameter pointer, same camera: the previous FLAME frame of a training run)
+    # must not be replayed either: omfs_project_fwd clears the stamp
+    fx1 = face_xf[0].clone()                           # the posed buffers are reused by the next face_frames call
+    _, fx2 = dflame.face_frames(2, 1)
+    rast.project(model, fx2[0], ccam)
+    L.check(lib.omfs_bin_count(gs, ccam, rast.rb, s), "omfs_bin_count")
+    torch.cuda.synchronize()
+    assert int(rast.status[1]) != 0
+    rast.project(model, fx1, ccam)                     # back to the first frame's records
+    torch.cuda.synchronize()
+    assert int(rast.status[1]) == 0
+    rast.tile_count.zero_(); rast.keys.zero_(); rast.sorted_ids.zero_(); rast.tile_cursor.zero_()
+    L.check(lib.omfs_bin_count(gs, ccam, rast.rb, s), "omfs_bin_count")
+    L.check(lib.omfs_bin_scan(ccam, rast.rb, s), "omfs_bin_scan")
     L.check(lib.omfs_bin_scatter(gs, ccam, rast.rb, s), "omfs_bin_scatter")
     L.check(lib.omfs_tile_sort(ccam, rast.rb, s), "omfs_tile_sort")
     torch.cuda.synchronize()
