@@ -301,18 +301,20 @@ def main():
     achieved = sb[dom] / (dom_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs): these cannot be
     # collected inside this process, so the figure is the one of the committed profile -- tagged with where it comes from
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_D, traffic_x2 = None, None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get(f"{dom}@{W}x{H}x{N}")
-            traffic_src = tj.get("_source")
+            traffic = tj.get(f"{dom}@{W}x{H}x{N}")            # FETCH_SIZE factor per kernel class (profiles/r03_fetch_calibration.json)
+            traffic_x2 = tj.get(f"{dom}@{W}x{H}x{N}:fetch_x2")
+            traffic_src, traffic_D = tj.get("_source"), tj.get("_D")
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": (traffic_src or "profiles/traffic.json (committed PMC pass of an earlier run of this command, not this run)") if traffic else None,
+                "traffic_D": traffic_D, "traffic_if_fetch_doubled": traffic_x2,
                 "algorithmic_bytes": int(sb[dom]), "avg_ms": round(dom_ms, 4)}
     # what actually bounds that kernel: VALU issue utilisation from the committed PMC pass (profiles/*_pmc_instruction_mix.json)
     try:
