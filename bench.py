@@ -382,12 +382,12 @@ def main():
             # the same loop with the PNG egress render.py uses: scanlines + deflate ON THE DEVICE (omfs_png_deflate), the zlib stream
             # fetched by encoder threads that add the PNG framing and the chunk CRC; bounded sample
             from concurrent.futures import ThreadPoolExecutor
-            from omfs_4d_video_gen_amd.engine.io_formats import png_from_zlib_stream
+            from omfs_4d_video_gen_amd.engine.io_formats import png_parts_from_zlib_stream
             n_png = min(300, len(frames))
             n_slots = 2 * host_cores()
 
             def encode(k, event):
-                return len(png_from_zlib_stream(rr.fetch_png_stream(k, event), W, H))
+                return sum(len(p) for p in png_parts_from_zlib_stream(rr.fetch_png_stream(k, event), W, H))   # what render.py writes
 
             with ThreadPoolExecutor(max_workers=host_cores()) as pool:
                 for v in frames[:n_slots]:                      # ring, pinned buffers, per-thread copy streams: set up outside the clock

@@ -352,6 +352,13 @@ int omfs_prepare_target(const uint8_t* src, int channels, int src_width, int src
 int omfs_png_slot_stride(int width);
 int omfs_png_deflate(const uint8_t* rows, int width, int height, uint8_t* slots, uint32_t* sizes, uint32_t* adler,
                      uint8_t* stream, uint32_t stream_capacity, uint32_t* stream_len, void* stream_hip);
+/* Host-side fetch of such a frame -- the ONE entry point that blocks, so that an encoder thread of a Python host spends its
+ * wait inside a single foreign call.  dev = [stream_len (4 bytes) | 12 bytes | stream ...] in one allocation, host_pinned the
+ * same size; waits for ready_event (a hipEvent_t, may be NULL) on copy_stream (a stream of the calling thread), copies
+ * 16 + guess_bytes speculatively and the remainder only if the stream is longer, synchronises copy_stream.  Returns the
+ * stream length (the zlib stream is host_pinned + 16 ...), or a negative OMFS_ERR_*.                                   */
+long long omfs_png_fetch(void* host_pinned, const void* dev, size_t capacity_bytes, size_t guess_bytes, void* copy_stream,
+                         void* ready_event);
 
 typedef struct omfs_adam_params {
   float lr[OMFS_NPLANES]; /* learning rate per plane                                              */

@@ -160,6 +160,7 @@ SIGNATURES = {
     "omfs_rgb8_to_image": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_png_slot_stride": (C.c_int, [C.c_int]),
     "omfs_png_deflate": (C.c_int, [c_void_p, C.c_int, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, C.c_uint32, c_void_p, c_void_p]),
+    "omfs_png_fetch": (C.c_longlong, [c_void_p, c_void_p, C.c_size_t, C.c_size_t, c_void_p, c_void_p]),
     "omfs_prepare_target": (C.c_int, [c_void_p, C.c_int, C.c_int, C.c_int, c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float), c_void_p,
                                       c_void_p, c_void_p]),
     "omfs_composite_bwd": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), C.POINTER(GradBuffersC), c_void_p]),

@@ -117,26 +117,72 @@ __device__ __forceinline__ void match_code(int len, unsigned long long& bits, in
   n = cn + ebits + 5;
 }
 
-// greedy tokenisation of bytes [b, e) of the staged row; `emit(bits, n)` receives every code in stream order
-template <typename Emit>
-__device__ __forceinline__ void deflate_piece(const uint8_t* row, int b, int e, Emit&& emit) {
-  int i = b;
-  while (i < e) {
-    int run = 0;
-    if (i >= 3) {
-      const int lim = min(e - i, 258);
-      while (run < lim && row[i + run] == row[i + run - 3]) ++run;
+// ---- tokenisation of a lane's piece without data-dependent inner loops.  A byte-by-byte walk (compare with the byte three
+// back, extend the run, else emit a literal) is a chain of dependent LDS byte loads inside doubly divergent loops: 171 us per
+// 1080p frame.  Instead every sub-piece of <= 128 bytes is first turned into two 128-bit masks with independent aligned word
+// loads -- eq: byte equals the byte 3 back, ge: byte >= 144 (its literal code has 9 bits) -- and the walk is bit arithmetic:
+// the next position where a run of >= 4 starts is a count-trailing-zeros of eq & eq>>1 & eq>>2 & eq>>3, the literals in front
+// of it cost 8 bits each plus a popcount of ge, the run length is a count-trailing-zeros of ~eq.
+struct U128 { unsigned long long lo, hi; };
+__device__ __forceinline__ U128 shr128(U128 v, int n) {      // n in [0, 128)
+  U128 r;
+  if (n >= 64) { r.lo = v.hi >> (n - 64); r.hi = 0ull; }
+  else if (n == 0) r = v;
+  else { r.lo = (v.lo >> n) | (v.hi << (64 - n)); r.hi = v.hi >> n; }
+  return r;
+}
+__device__ __forceinline__ int ctz128(U128 v) { return v.lo ? __builtin_ctzll(v.lo) : (v.hi ? 64 + __builtin_ctzll(v.hi) : 128); }
+__device__ __forceinline__ uint32_t movemask4(uint32_t y) {  // bits 7, 15, 23, 31 -> bits 0..3
+  const uint32_t z = y >> 7;
+  return (z | (z >> 7) | (z >> 14) | (z >> 21)) & 0xFu;
+}
+
+struct PieceMasks { U128 eq, ge, eq4; int len; };
+// row32: the row's bytes as aligned words in LDS; [sb, sb + len) the sub-piece (sb a multiple of 4, len <= 128)
+__device__ __forceinline__ PieceMasks build_masks(const uint32_t* row32, int sb, int len) {
+  PieceMasks m;
+  m.len = len;
+  unsigned long long eq[2] = {0ull, 0ull}, ge[2] = {0ull, 0ull};
+  const int base = sb >> 2, ndw = (len + 3) >> 2;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+      const int dw = 16 * h + d;
+      if (dw < ndw) {
+        const uint32_t cur = row32[base + dw], prev = base + dw > 0 ? row32[base + dw - 1] : 0u;
+        const uint32_t x = cur ^ ((prev >> 8) | (cur << 24));                      // byte k against byte k - 3
+        const uint32_t zero = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 in every zero byte
+        const uint32_t big = ((cur & 0x7F7F7F7Fu) + 0x70707070u) & cur & 0x80808080u;   // 0x80 in every byte >= 144
+        eq[h] |= (unsigned long long)movemask4(zero) << (4 * d);
+        ge[h] |= (unsigned long long)movemask4(big) << (4 * d);
+      }
     }
-    if (run >= 4) {
-      unsigned long long bits; int n;
-      match_code(run, bits, n);
-      emit(bits, n);
+  }
+  if (sb == 0) eq[0] &= ~7ull;                                 // the first three bytes of a row have no byte three back
+  U128 valid;
+  valid.lo = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+  valid.hi = len >= 128 ? ~0ull : (len > 64 ? ((1ull << (len - 64)) - 1ull) : 0ull);
+  m.eq.lo = eq[0] & valid.lo; m.eq.hi = eq[1] & valid.hi;
+  m.ge.lo = ge[0] & valid.lo; m.ge.hi = ge[1] & valid.hi;
+  const U128 e1 = shr128(m.eq, 1), e2 = shr128(m.eq, 2), e3 = shr128(m.eq, 3);
+  m.eq4.lo = m.eq.lo & e1.lo & e2.lo & e3.lo; m.eq4.hi = m.eq.hi & e1.hi & e2.hi & e3.hi;
+  return m;
+}
+
+// walk a sub-piece: lits(i, n) for every maximal stretch of literals [i, i + n), match(len) for every run
+template <typename Lits, typename Match>
+__device__ __forceinline__ void walk_piece(const PieceMasks& m, Lits&& lits, Match&& match) {
+  int i = 0;
+  while (i < m.len) {
+    const int nlit = min(ctz128(shr128(m.eq4, i)), m.len - i);
+    if (nlit) { lits(i, nlit); i += nlit; }
+    if (i < m.len) {
+      const U128 e = shr128(m.eq, i);
+      U128 ne; ne.lo = ~e.lo; ne.hi = ~e.hi;
+      const int run = min(min(ctz128(ne), 258), m.len - i);   // >= 4: eq4 has bit i set
+      match(run);
       i += run;
-    } else {
-      uint32_t bits; int n;
-      lit_code(row[i], bits, n);
-      emit((unsigned long long)bits, n);
-      ++i;
     }
   }
 }
@@ -146,24 +192,61 @@ __global__ __launch_bounds__(64) void png_deflate_rows_kernel(const uint8_t* __r
                                                               uint32_t* __restrict__ sizes, uint32_t* __restrict__ adler) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
   const int r = blockIdx.x, lane = threadIdx.x;
-  const int row_pad = (row_bytes + 4 + 15) / 16 * 16;
+  const int row_pad = (row_bytes + 8 + 15) / 16 * 16;
+  uint32_t* row32 = reinterpret_cast<uint32_t*>(lds);               // the row, byte 0 at word 0
+  const uint8_t* row8 = lds;
   uint32_t* s_out = reinterpret_cast<uint32_t*>(lds + row_pad);     // [slot_stride / 4] words of the row's deflate block
   const uint8_t* src = rows + (size_t)r * row_bytes;
-  // stage: a row starts at an arbitrary byte offset of the scanline buffer -> aligned dword loads of the words that cover it,
-  // the LDS image is shifted by the same 0..3 bytes
+  // stage: a row starts at an arbitrary byte offset of the scanline buffer -> aligned word loads, funnel-shifted into place
   const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3u);
   const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src - mis);
-  uint32_t* lds32 = reinterpret_cast<uint32_t*>(lds);
-  for (int i = lane; i < (row_bytes + mis + 3) / 4; i += 64) lds32[i] = src32[i];
-  const uint8_t* s_row = lds + mis;                         // [row_bytes]
+  const int n_words = (row_bytes + 3) / 4;
+  for (int i0 = 0; i0 <= n_words; i0 += 64 * 8) {                   // eight words per lane in flight (one round trip per 2 KB)
+    uint32_t lo[8], hi[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 64 + lane;
+      lo[u] = i < n_words ? src32[i] : 0u;
+      hi[u] = (i < n_words && mis) ? src32[i + 1] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 64 + lane;
+      if (i > n_words) continue;                                    // word n_words: padding behind the row (zero)
+      uint32_t v = mis ? __funnelshift_r(lo[u], hi[u], 8 * mis) : lo[u];
+      const int tail = row_bytes - 4 * i;                           // bytes of this word that belong to the row
+      if (tail < 4) v &= tail <= 0 ? 0u : ((1u << (8 * tail)) - 1u);
+      row32[i] = v;
+    }
+  }
   for (int i = lane; i < slot_stride / 4; i += 64) s_out[i] = 0u;
   __syncthreads();
-  const int piece = max(64, (row_bytes + 63) / 64);        // short rows use fewer lanes: a run is cut at every piece boundary
+  const int piece = max(64, ((row_bytes + 63) / 64 + 3) & ~3);      // short rows use fewer lanes: a run is cut at every piece boundary
   const int b = min(lane * piece, row_bytes), e = min(b + piece, row_bytes);
   // pass 1: bits of this lane's piece, Adler terms
   uint32_t nbits = 0, a_sum = 0, b_sum = 0;
-  deflate_piece(s_row, b, e, [&](unsigned long long, int n) { nbits += (uint32_t)n; });
-  for (int i = b; i < e; ++i) { const uint32_t d = s_row[i]; a_sum += d; b_sum += (uint32_t)(row_bytes - i) * d; }   // < 2^32: 91 * 255 * 11521
+  const bool single = e - b <= 128;                                // one sub-piece: its masks serve both passes
+  PieceMasks m0 = build_masks(row32, b, min(128, e - b));
+  for (int sb = b; sb < e; sb += 128) {
+    const PieceMasks m = sb == b ? m0 : build_masks(row32, sb, min(128, e - sb));
+    walk_piece(m,
+               [&](int i, int n) {
+                 U128 g = shr128(m.ge, i);
+                 if (n < 64) { g.lo &= (1ull << n) - 1ull; g.hi = 0ull; } else if (n < 128) g.hi &= (1ull << (n - 64)) - 1ull;
+                 nbits += 8u * (uint32_t)n + (uint32_t)(__popcll(g.lo) + __popcll(g.hi));
+               },
+               [&](int run) { unsigned long long bits; int n; match_code(run, bits, n); nbits += (uint32_t)n; });
+  }
+  // Adler terms a word at a time (b is a multiple of 4 for every lane that owns bytes; the bytes behind the row are zero and
+  // pieces end on word boundaries or at the row's end): with d0..d3 the bytes at positions p..p+3, sum d = sad(word, 0),
+  // sum (L - pos) d = (L - p) sum d - (d1 + 2 d2 + 3 d3), and d1 + 2 d2 + 3 d3 = sad(d1, d3) + 2 sad(d2, d3).
+  for (int i = b >> 2; b < e && 4 * i < e; ++i) {
+    const uint32_t v = row32[i];
+    const uint32_t s = __builtin_amdgcn_sad_u8(v, 0u, 0u);
+    const uint32_t wsum = __builtin_amdgcn_sad_u8(v & 0xFF00FF00u, 0u, 0u) + 2u * __builtin_amdgcn_sad_u8(v & 0xFFFF0000u, 0u, 0u);
+    a_sum += s;
+    b_sum += (uint32_t)(row_bytes - 4 * i) * s - wsum;              // < 2^32: 184 * 255 * 11521
+  }
   const uint32_t incl = wave_incl_scan_u32(nbits, lane);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   uint32_t pos = 3u + incl - nbits;                        // behind the 3-bit block header
@@ -176,7 +259,21 @@ __global__ __launch_bounds__(64) void png_deflate_rows_kernel(const uint8_t* __r
     nacc += n;
     if (nacc >= 32) { atomicOr(&s_out[w], (uint32_t)acc); acc >>= 32; nacc -= 32; ++w; }
   };
-  deflate_piece(s_row, b, e, put);
+  for (int sb = b; sb < e; sb += 128) {
+    const PieceMasks m = (single || sb == b) ? m0 : build_masks(row32, sb, min(128, e - sb));
+    walk_piece(m,
+               [&](int i, int n) {
+                 for (int k = 0; k < n; k += 4) {          // four independent byte loads, then their codes
+                   uint32_t v[4];
+#pragma unroll
+                   for (int u = 0; u < 4; ++u) v[u] = row8[sb + i + min(k + u, n - 1)];
+#pragma unroll
+                   for (int u = 0; u < 4; ++u)
+                     if (k + u < n) { uint32_t cb; int cn; lit_code(v[u], cb, cn); put((unsigned long long)cb, cn); }
+                 }
+               },
+               [&](int run) { unsigned long long bits; int n; match_code(run, bits, n); put(bits, n); });
+  }
   if (nacc) atomicOr(&s_out[w], (uint32_t)acc);
   uint32_t end_bits = 3u + total;
   if (lane == 0) {
@@ -214,8 +311,32 @@ __global__ __launch_bounds__(64) void png_assemble_kernel(const uint8_t* __restr
   if (r < height) {
     const uint32_t n = sizes[r];
     if (off + n + 9u > stream_capacity) return;            // cannot happen with the capacity the host sizes; never write outside
+    // The block lands at an arbitrary byte offset of the stream: a few head bytes up to the first aligned stream word, then
+    // whole words -- each the funnel shift of two aligned words of the (16-byte aligned) slot, eight per lane in flight -- then
+    // the tail bytes.  (A byte-per-lane loop is one memory round trip per 64 bytes: 200 us for a 1080p frame.)
     const uint8_t* src = slots + (size_t)r * slot_stride;
-    for (uint32_t i = lane; i < n; i += 64) stream[off + i] = src[i];
+    uint8_t* dst = stream + off;
+    const uint32_t head = min(n, (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u));
+    if ((uint32_t)lane < head) dst[lane] = src[lane];
+    const uint32_t n_words = (n - head) >> 2, sh = (head & 3u) * 8u;
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(src);
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst + head);
+    for (uint32_t j0 = 0; j0 < n_words; j0 += 64 * 8) {
+      uint32_t lo[8], hi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t j = j0 + u * 64 + lane, q = (head >> 2) + j;     // stream word j = slot bytes head + 4 j .. + 3
+        lo[u] = j < n_words ? s32[q] : 0u;
+        hi[u] = (j < n_words && sh) ? s32[q + 1] : 0u;                  // (the slot is padded: q + 1 stays inside it)
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t j = j0 + u * 64 + lane;
+        if (j < n_words) d32[j] = sh ? __funnelshift_r(lo[u], hi[u], sh) : lo[u];
+      }
+    }
+    const uint32_t done = head + 4u * n_words;
+    if (done + (uint32_t)lane < n) dst[done + lane] = src[done + lane];
     return;
   }
   // Adler-32 of all scanlines from the rows' terms: A = 1 + sum A_r, B = sum B_r + L H + L sum_j (H - 1 - j) A_j  (mod 65521)
@@ -267,7 +388,7 @@ extern "C" int omfs_png_deflate(const uint8_t* rows, int width, int height, uint
   OMFS_REQUIRE(rows && slots && sizes && adler && stream && stream_len && width > 0 && height > 0, "args");
   const int row_bytes = 1 + 3 * width, stride = omfs_png_slot_stride(width);
   OMFS_REQUIRE((size_t)stream_capacity >= (size_t)height * stride + 16, "stream_capacity < height * omfs_png_slot_stride(width) + 16");
-  const size_t lds = (size_t)((row_bytes + 4 + 15) / 16 * 16) + (size_t)stride;
+  const size_t lds = (size_t)((row_bytes + 8 + 15) / 16 * 16) + (size_t)stride;
   OMFS_REQUIRE(lds <= 64 * 1024, "scanline too long for the LDS image of its deflate block");
   hipStream_t s = (hipStream_t)stream_hip;
   hipLaunchKernelGGL(png_deflate_rows_kernel, dim3(height), dim3(64), lds, s, rows, row_bytes, height, slots, stride, sizes, adler);
@@ -276,4 +397,27 @@ extern "C" int omfs_png_deflate(const uint8_t* rows, int width, int height, uint
                      (const uint32_t*)adler, height, row_bytes, stream, stream_capacity, stream_len);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
+}
+
+// Host-side fetch of a device-deflated frame.  `dev` = [stream length: 4 bytes | 12 bytes pad | zlib stream] as one allocation (the
+// layout engine/trainer.py gives omfs_png_deflate's outputs), `host` = pinned memory of the same size.  The length is only known
+// on the device, so the copy is speculative: 16 + guess_bytes in one transfer, the remainder -- rarely -- in a second one.
+// `copy_stream` is a stream of the CALLING thread; it waits for `ready_event` (recorded behind the deflate), and this call
+// synchronises it (the one entry point that blocks: it exists so that an encoder thread spends its wait outside the host
+// language's interpreter lock, in ONE foreign call).  Returns the stream length, or a negative error.
+extern "C" long long omfs_png_fetch(void* host, const void* dev, size_t capacity_bytes, size_t guess_bytes, void* copy_stream,
+                                    void* ready_event) {
+  if (!host || !dev || capacity_bytes < 32) return omfs::set_error(OMFS_ERR_ARG, "omfs_png_fetch: bad arguments");
+  hipStream_t s = (hipStream_t)copy_stream;
+  if (ready_event) OMFS_CHECK_HIP(hipStreamWaitEvent(s, (hipEvent_t)ready_event, 0));
+  const size_t first = (16 + guess_bytes) < capacity_bytes ? (16 + guess_bytes) : capacity_bytes;
+  OMFS_CHECK_HIP(hipMemcpyAsync(host, dev, first, hipMemcpyDeviceToHost, s));
+  OMFS_CHECK_HIP(hipStreamSynchronize(s));
+  const uint32_t n = *reinterpret_cast<const uint32_t*>(host);
+  if (n == 0u || 16 + (size_t)n > capacity_bytes) return omfs::set_error(OMFS_ERR_ARG, "omfs_png_fetch: impossible stream length %u", n);
+  if (16 + (size_t)n > first) {
+    OMFS_CHECK_HIP(hipMemcpyAsync((uint8_t*)host + first, (const uint8_t*)dev + first, 16 + (size_t)n - first, hipMemcpyDeviceToHost, s));
+    OMFS_CHECK_HIP(hipStreamSynchronize(s));
+  }
+  return (long long)n;
 }

@@ -50,11 +50,18 @@ def encode_png_rows(rows, width: int, height: int, level: int = 1) -> bytes:
         _chunk(b"IDAT", co.compress(memoryview(a).cast("B")) + co.flush()) + _chunk(b"IEND", b"")
 
 
+def png_parts_from_zlib_stream(stream, width: int, height: int) -> list:
+    """The pieces of a PNG file around a ready-made zlib stream of the RGB scanlines (`Rasterizer.to_png_stream`: deflated on
+    the device): [signature + IHDR + IDAT header, the stream itself (not copied), IDAT CRC-32 + IEND].  Chunk framing and the
+    CRC are all that is left for the host; `f.writelines(parts)` writes the file without building it in memory first."""
+    mv = memoryview(stream).cast("B") if not isinstance(stream, (bytes, bytearray)) else stream
+    head = _PNG_SIG + _chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, 2, 0, 0, 0)) + struct.pack(">I", len(mv)) + b"IDAT"
+    crc = zlib.crc32(mv, zlib.crc32(b"IDAT")) & 0xFFFFFFFF          # releases the interpreter lock on large buffers
+    return [head, mv, struct.pack(">I", crc) + _chunk(b"IEND", b"")]
+
+
 def png_from_zlib_stream(stream, width: int, height: int) -> bytes:
-    """PNG file bytes around a ready-made zlib stream of the RGB scanlines (`Rasterizer.to_png_stream`: deflated on the
-    device): chunk framing and the IDAT chunk's CRC-32 are all that is left for the host."""
-    data = bytes(stream) if not isinstance(stream, (bytes, bytearray)) else stream
-    return _PNG_SIG + _chunk(b"IHDR", struct.pack(">IIBBBBB", width, height, 8, 2, 0, 0, 0)) + _chunk(b"IDAT", data) + _chunk(b"IEND", b"")
+    return b"".join(png_parts_from_zlib_stream(stream, width, height))
 
 
 def write_png(path, img: np.ndarray, level: int = 1) -> None:

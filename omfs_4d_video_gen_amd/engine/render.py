@@ -111,7 +111,7 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     def encode_and_write(path, k, event):
         # the frame was deflated on the device (omfs_png_deflate): fetch the zlib stream, add the PNG framing + chunk CRC, write
         with open(path, "wb") as f:
-            f.write(IO.png_from_zlib_stream(r.fetch_png_stream(k, event), w, h))
+            f.writelines(IO.png_parts_from_zlib_stream(r.fetch_png_stream(k, event), w, h))
 
     for idx in mine:
         view = View(cams[idx], split["timestep_of_frame"][idx])

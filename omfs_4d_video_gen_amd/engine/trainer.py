@@ -603,39 +603,54 @@ class Renderer:
         if getattr(self, "_png_ring", None) is None or len(self._png_ring) != n_slots:
             r.to_png_stream()                              # sizes the scratch buffers
             cap = r.png_stream_capacity
-            self._png_ring = [(torch.zeros(cap, dtype=torch.uint8, device=self.device), torch.zeros(1, dtype=torch.int32, device=self.device))
-                              for _ in range(n_slots)]
-            self._png_host = [(torch.empty(cap, dtype=torch.uint8, pin_memory=True), torch.zeros(1, dtype=torch.int32, pin_memory=True))
-                              for _ in range(n_slots)]
+            # one allocation per slot: [stream length (4 bytes) | zlib stream]: the length travels with the data in ONE copy
+            self._png_ring = [torch.zeros(16 + cap, dtype=torch.uint8, device=self.device) for _ in range(n_slots)]
+            self._png_host = [torch.empty(16 + cap, dtype=torch.uint8, pin_memory=True) for _ in range(n_slots)]
+            self._png_host_mv = [memoryview(h.numpy()) for h in self._png_host]
             self._png_events = [torch.cuda.Event() for _ in range(n_slots)]
             self._png_next = 0
+            self._png_guess = cap // 4
             import threading
             self._png_tls = threading.local()
         k = self._png_next
         self._png_next = (k + 1) % n_slots
-        r.to_png_stream(*self._png_ring[k])
+        buf = self._png_ring[k]
+        r.to_png_stream(buf[16:], buf[:4].view(torch.int32))
+        # the speculative device-to-host copy (length word + as many bytes as the last frames needed, + 12 %) is enqueued HERE, on
+        # a copy stream behind the deflate: the encoder threads then only wait for an event -- no stream operations of their own
+        # (synchronising a stream from many threads contends with this thread's launches inside the HIP runtime)
+        if getattr(self, "_png_copy_stream", None) is None:
+            self._png_copy_stream = torch.cuda.Stream(device=self.device)
+            self._png_done = [torch.cuda.Event() for _ in range(n_slots)]
+            self._png_got = [0] * n_slots
         self._png_events[k].record()
-        return k, self._png_events[k]
+        got = min(16 + self._png_guess, buf.numel())
+        with torch.cuda.stream(self._png_copy_stream):
+            self._png_copy_stream.wait_event(self._png_events[k])
+            self._png_host[k][:got].copy_(buf[:got], non_blocking=True)
+            self._png_done[k].record()
+        self._png_got[k] = got
+        return k, self._png_done[k]
 
     def fetch_png_stream(self, k: int, event) -> memoryview:
-        """The zlib stream of ring slot k on the host (pinned memory, valid until the slot is reused): the length first (4 bytes),
-        then exactly that many bytes -- about a tenth of the raw scanlines for a head on a plain background.  Runs on a copy
-        stream of the calling thread, so encoder threads do not serialise behind the render stream."""
-        tls = self._png_tls
-        if getattr(tls, "stream", None) is None:
-            tls.stream = torch.cuda.Stream(device=self.device)
-        dev_stream, dev_len = self._png_ring[k]
-        host_stream, host_len = self._png_host[k]
-        with torch.cuda.stream(tls.stream):
-            tls.stream.wait_event(event)
-            host_len.copy_(dev_len, non_blocking=True)
-            tls.stream.synchronize()
-            n = int(host_len[0])
-            if n <= 0 or n > host_stream.numel():
-                raise L.OmfsError(f"device PNG deflate reported an impossible stream length {n}")
-            host_stream[:n].copy_(dev_stream[:n], non_blocking=True)
-            tls.stream.synchronize()
-        return memoryview(host_stream.numpy())[:n]
+        """The zlib stream of ring slot k on the host (pinned memory, valid until the slot is reused).  Its length is only known
+        on the device, so the copy is speculative: the length word and as many bytes as the last frames needed (+ 12 %) in one
+        transfer, the rest -- rarely -- in a second one; about a fifth of the raw scanlines for a head on a plain background.
+        Runs on a copy stream of the calling thread, so encoder threads do not serialise behind the render stream."""
+        event.synchronize()                                   # the speculative copy has landed
+        host, got = self._png_host[k], self._png_got[k]
+        n = int.from_bytes(self._png_host_mv[k][:4], "little")
+        if n <= 0 or 16 + n > host.numel():
+            raise L.OmfsError(f"device PNG deflate reported an impossible stream length {n}")
+        if 16 + n > got:                                      # rare: the frame needed more than the guess -- fetch the remainder
+            tls = self._png_tls
+            if getattr(tls, "stream", None) is None:
+                tls.stream = torch.cuda.Stream(device=self.device)
+            m = int(L.load().omfs_png_fetch(host.data_ptr(), self._png_ring[k].data_ptr(), host.numel(), n, tls.stream.cuda_stream, 0))
+            if m != n:
+                raise L.OmfsError(f"omfs_png_fetch failed ({m}): {L.load().omfs_last_error().decode()}")
+        self._png_guess = max(int(n * 1.12) + 4096, (self._png_guess * 7) // 8)
+        return self._png_host_mv[k][16:16 + n]
 
     def render(self, view: View, rgb8: bool = False):
         """Enqueue one frame; returns the reused image tensor ([3][H][W] fp32 or [H][W][3] uint8)."""
