@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 # the last case is BASELINE.json's full size: the C oracle renders it in well under a minute on one host core
 @pytest.mark.parametrize("n,width,height,yaw,seed,identity", [(4000, 160, 120, 0.3, 1, False), (20000, 320, 256, -0.7, 2, False),
                                                               (2500, 100, 52, 0.0, 5, False),
+                                                              (8000, 160, 128, 0.4, 21, "closeup"),     # Jacobian clamp + near-plane culls common
                                                               (5000, 256, 256, 0.0, 0, True),             # BASELINE config 1: identity pose
                                                               (100000, 512, 512, 0.0, 3, False),          # BASELINE config 2
                                                               (300000, 1920, 1080, 0.35, 0, False),       # configs 3 / 4
@@ -29,6 +30,10 @@ def test_bitexact_vs_c_oracle(n, width, height, yaw, seed, identity):
         g[k][1:100:2] = g[k][0:100:2]
         # ... and one stack of 400 coincident Gaussians: more equal depths than a sort bucket takes (radix fallback)
         g[k][200:600] = g[k][200]
+    closeup = identity == "closeup"      # the regime of tests/test_oracle_cpu.py::test_rare_projection_branches_...: large splats, camera inside
+    identity = identity is True
+    if closeup:
+        g["log_scale"] += 1.3
     if identity:   # config 1: a single frame with every FLAME parameter zero -- the posed mesh IS the template
         seq = synthetic.make_flame_sequence(1, seed, identity=True)
     else:
@@ -37,7 +42,7 @@ def test_bitexact_vs_c_oracle(n, width, height, yaw, seed, identity):
         # rows are used like every other vertex's
         seq["dynamic_offset"] = (np.random.default_rng(seed + 77).standard_normal((4, 5143, 3)) * 2e-4).astype(np.float32)
     assert rig.v_template.shape[0] == 5143 and seq["static_offset"].shape == (1, 5143, 3)
-    cam = synthetic.make_camera(width, height, yaw=yaw)
+    cam = synthetic.make_camera(width, height, yaw=yaw, fill=3.5, distance=0.27) if closeup else synthetic.make_camera(width, height, yaw=yaw)
     dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq)
     model = GaussianModel(g)
     rast = Rasterizer(n, width, height)

@@ -74,6 +74,41 @@ def test_config1_at_its_stated_size_on_the_cpu(rig_small):
     assert float(t["image"].max()) > 0.05 and len(c["ids"]) > n
 
 
+def test_rare_projection_branches_agree_between_the_two_restatements(rig_small):
+    """The C oracle and the HIP kernels are operation-for-operation twins, so the independence of the bit-exact check rests on
+    the differently formulated PyTorch oracle -- whose robust comparison tolerates 0.5 % of outliers, enough to hide a branch
+    only few Gaussians take.  A close-up camera makes those branches common: the head overfills the image (the Jacobian's
+    1.3 tan(fov/2) clamp is active for a large share of the Gaussians) and reaches in front of the near plane (t_z <= 0.2 culls);
+    on exactly those subsets the two restatements must agree."""
+    rig = rig_small
+    n, W, Hh = 8000, 160, 128
+    g = synthetic.make_gaussians(n, rig.faces.shape[0], 21)
+    g["log_scale"] += 1.3                                         # large splats: many centres beyond the clamp still reach the image
+    seq = synthetic.make_flame_sequence(2, 21)
+    cam = synthetic.make_camera(W, Hh, yaw=0.4, fill=3.5, distance=0.27)
+    dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq, device="cpu")
+    ccam = make_camera_struct(cam, sh_degree=3, bg=(0.0, 0.0, 0.0))
+    c = CO.render(dflame, 1, pack_params(g), g["binding"], n, CO.camera(ccam))
+    t = O.render(H.oracle_rig(rig), H.oracle_gaussians(g), H.oracle_frame(seq, 1), cam, sh_degree=3)
+    mu = t["proj"]["mean3d"].numpy()
+    w2v = np.asarray(cam["world_to_view"], np.float64)
+    tv = mu @ w2v[:3, :3].T + w2v[:3, 3]
+    near = tv[:, 2] <= 0.2
+    safe = np.abs(tv[:, 2] - 0.2) > 1e-4                          # the cull decision itself is not a rounding question there
+    clamped = (~near) & ((np.abs(tv[:, 0] / tv[:, 2]) > 1.3 * cam["tanfovx"]) | (np.abs(tv[:, 1] / tv[:, 2]) > 1.3 * cam["tanfovy"]))
+    assert near.sum() > n // 50 and clamped.sum() > n // 10, (int(near.sum()), int(clamped.sum()))
+    vis_c, vis_t = c["proj"]["radius"] > 0, t["proj"]["visible"].numpy()
+    assert not vis_c[near & safe].any() and not vis_t[near & safe].any()           # culled on both sides
+    assert np.array_equal(vis_c[safe], vis_t[safe])
+    m = clamped & vis_c & vis_t
+    assert m.sum() > n // 40, int(m.sum())
+    conic_c, conic_t = c["proj"]["conic"][m], t["proj"]["conic"].numpy()[m]
+    close = np.abs(conic_c - conic_t) <= 5e-3 * np.abs(conic_t) + 1e-6
+    assert close.all(axis=1).mean() > 0.99, float(close.all(axis=1).mean())
+    assert np.abs(c["proj"]["radius"][m] - t["proj"]["radius"].numpy()[m]).max() <= 1
+    assert np.abs(c["image"] - t["image"].numpy()).mean() < 1e-4
+
+
 def test_tile_culling_does_not_change_the_image(rig_small):
     """The engine drops (Gaussian, tile) pairs that cannot reach alpha >= 1/255 inside the tile.
     The composite of the culled lists must be BIT-IDENTICAL to the composite of the upstream-style
