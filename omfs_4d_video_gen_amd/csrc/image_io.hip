@@ -78,8 +78,8 @@ __global__ void prepare_target_kernel(const uint8_t* __restrict__ src, int chann
 // the chunk CRC and writes the file.
 //
 // Deflate with the FIXED Huffman code and run-length matches at distance 3 (one RGB pixel back: a constant background of
-// any colour is a run; the Z_RLE strategy the host encoder used only sees distance 1).  One wave per scanline:
-//   1. the row is staged in LDS with coalesced 16-byte loads; lane l owns piece l of it (row_bytes / 64 bytes);
+// any colour is a run; the Z_RLE strategy the host encoder used only sees distance 1).  One 256-thread workgroup per scanline:
+//   1. the row is staged in LDS with coalesced word loads; thread t owns piece t of it (row_bytes / 256 bytes, a multiple of 4);
 //   2. pass 1 walks the piece greedily (run of >= 4 bytes equal to the byte 3 back -> one length/distance pair, else a
 //      literal) and counts bits; a wave-wide prefix sum gives every lane its bit offset;
 //   3. pass 2 walks again and ORs its codes into the LDS image of the row's block (LDS atomics: neighbouring lanes share words);
@@ -117,81 +117,80 @@ __device__ __forceinline__ void match_code(int len, unsigned long long& bits, in
   n = cn + ebits + 5;
 }
 
-// ---- tokenisation of a lane's piece without data-dependent inner loops.  A byte-by-byte walk (compare with the byte three
+// ---- tokenisation of a thread's piece without data-dependent inner loops.  A byte-by-byte walk (compare with the byte three
 // back, extend the run, else emit a literal) is a chain of dependent LDS byte loads inside doubly divergent loops: 171 us per
-// 1080p frame.  Instead every sub-piece of <= 128 bytes is first turned into two 128-bit masks with independent aligned word
-// loads -- eq: byte equals the byte 3 back, ge: byte >= 144 (its literal code has 9 bits) -- and the walk is bit arithmetic:
-// the next position where a run of >= 4 starts is a count-trailing-zeros of eq & eq>>1 & eq>>2 & eq>>3, the literals in front
-// of it cost 8 bits each plus a popcount of ge, the run length is a count-trailing-zeros of ~eq.
-struct U128 { unsigned long long lo, hi; };
-__device__ __forceinline__ U128 shr128(U128 v, int n) {      // n in [0, 128)
-  U128 r;
-  if (n >= 64) { r.lo = v.hi >> (n - 64); r.hi = 0ull; }
-  else if (n == 0) r = v;
-  else { r.lo = (v.lo >> n) | (v.hi << (64 - n)); r.hi = v.hi >> n; }
-  return r;
-}
-__device__ __forceinline__ int ctz128(U128 v) { return v.lo ? __builtin_ctzll(v.lo) : (v.hi ? 64 + __builtin_ctzll(v.hi) : 128); }
+// 1080p frame with one wave per scanline.  Instead every piece (<= 64 bytes) is first turned into two 64-bit masks with
+// independent aligned word loads -- eq: byte equals the byte 3 back, ge: byte >= 144 (its literal code has 9 bits) -- and the
+// walk is bit arithmetic: the next position where a run of >= 4 starts is a count-trailing-zeros of eq & eq>>1 & eq>>2 & eq>>3,
+// the literals in front of it cost 8 bits each plus a popcount of ge, the run length is a count-trailing-zeros of ~eq.
+// FOUR waves share a scanline (pieces of 24 bytes at 1080p: the serial work of a wave, which is what the kernel's time is,
+// shrinks accordingly), and pieces that lie wholly inside a run are merged along the wave: the first thread of such a chain
+// emits the whole stretch as 258-byte matches, the others nothing -- a plain background costs ~40 bytes per row.
 __device__ __forceinline__ uint32_t movemask4(uint32_t y) {  // bits 7, 15, 23, 31 -> bits 0..3
   const uint32_t z = y >> 7;
   return (z | (z >> 7) | (z >> 14) | (z >> 21)) & 0xFu;
 }
+__device__ __forceinline__ int ctz64(unsigned long long v) { return v ? __builtin_ctzll(v) : 64; }
 
-struct PieceMasks { U128 eq, ge, eq4; int len; };
-// row32: the row's bytes as aligned words in LDS; [sb, sb + len) the sub-piece (sb a multiple of 4, len <= 128)
+struct PieceMasks { unsigned long long eq, ge, eq4, valid; int len; };
+// row32: the row's bytes as aligned words in LDS; [sb, sb + len) the piece (sb a multiple of 4, len <= 64)
 __device__ __forceinline__ PieceMasks build_masks(const uint32_t* row32, int sb, int len) {
   PieceMasks m;
   m.len = len;
-  unsigned long long eq[2] = {0ull, 0ull}, ge[2] = {0ull, 0ull};
+  unsigned long long eq = 0ull, ge = 0ull;
   const int base = sb >> 2, ndw = (len + 3) >> 2;
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int d = 0; d < 16; ++d) {
-      const int dw = 16 * h + d;
-      if (dw < ndw) {
-        const uint32_t cur = row32[base + dw], prev = base + dw > 0 ? row32[base + dw - 1] : 0u;
-        const uint32_t x = cur ^ ((prev >> 8) | (cur << 24));                      // byte k against byte k - 3
-        const uint32_t zero = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 in every zero byte
-        const uint32_t big = ((cur & 0x7F7F7F7Fu) + 0x70707070u) & cur & 0x80808080u;   // 0x80 in every byte >= 144
-        eq[h] |= (unsigned long long)movemask4(zero) << (4 * d);
-        ge[h] |= (unsigned long long)movemask4(big) << (4 * d);
-      }
+  for (int d = 0; d < 16; ++d) {
+    if (d < ndw) {
+      const uint32_t cur = row32[base + d], prev = base + d > 0 ? row32[base + d - 1] : 0u;
+      const uint32_t x = cur ^ ((prev >> 8) | (cur << 24));                      // byte k against byte k - 3
+      const uint32_t zero = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);   // 0x80 in every zero byte
+      const uint32_t big = ((cur & 0x7F7F7F7Fu) + 0x70707070u) & cur & 0x80808080u;   // 0x80 in every byte >= 144
+      eq |= (unsigned long long)movemask4(zero) << (4 * d);
+      ge |= (unsigned long long)movemask4(big) << (4 * d);
     }
   }
-  if (sb == 0) eq[0] &= ~7ull;                                 // the first three bytes of a row have no byte three back
-  U128 valid;
-  valid.lo = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
-  valid.hi = len >= 128 ? ~0ull : (len > 64 ? ((1ull << (len - 64)) - 1ull) : 0ull);
-  m.eq.lo = eq[0] & valid.lo; m.eq.hi = eq[1] & valid.hi;
-  m.ge.lo = ge[0] & valid.lo; m.ge.hi = ge[1] & valid.hi;
-  const U128 e1 = shr128(m.eq, 1), e2 = shr128(m.eq, 2), e3 = shr128(m.eq, 3);
-  m.eq4.lo = m.eq.lo & e1.lo & e2.lo & e3.lo; m.eq4.hi = m.eq.hi & e1.hi & e2.hi & e3.hi;
+  if (sb == 0) eq &= ~7ull;                                    // the first three bytes of a row have no byte three back
+  m.valid = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+  m.eq = eq & m.valid;
+  m.ge = ge & m.valid;
+  m.eq4 = m.eq & (m.eq >> 1) & (m.eq >> 2) & (m.eq >> 3);
   return m;
 }
 
-// walk a sub-piece: lits(i, n) for every maximal stretch of literals [i, i + n), match(len) for every run
+// walk a piece: lits(i, n) for every maximal stretch of literals [i, i + n), match(len) for every run
 template <typename Lits, typename Match>
 __device__ __forceinline__ void walk_piece(const PieceMasks& m, Lits&& lits, Match&& match) {
   int i = 0;
   while (i < m.len) {
-    const int nlit = min(ctz128(shr128(m.eq4, i)), m.len - i);
+    const int nlit = min(ctz64(m.eq4 >> i), m.len - i);
     if (nlit) { lits(i, nlit); i += nlit; }
     if (i < m.len) {
-      const U128 e = shr128(m.eq, i);
-      U128 ne; ne.lo = ~e.lo; ne.hi = ~e.hi;
-      const int run = min(min(ctz128(ne), 258), m.len - i);   // >= 4: eq4 has bit i set
+      const int run = min(ctz64(~(m.eq >> i)), m.len - i);     // >= 4: eq4 has bit i set; <= 64 < 258
       match(run);
       i += run;
     }
   }
 }
+// a stretch of `total` >= 4 bytes inside a run, as matches of <= 258 bytes none of which is shorter than 3
+template <typename Match>
+__device__ __forceinline__ void emit_long_run(int total, Match&& match) {
+  while (total > 0) {
+    int r = min(total, 258);
+    const int rem = total - r;
+    if (rem > 0 && rem < 3) r -= 3 - rem;
+    match(r);
+    total -= r;
+  }
+}
 
-__global__ __launch_bounds__(64) void png_deflate_rows_kernel(const uint8_t* __restrict__ rows, int row_bytes, int height,
-                                                              uint8_t* __restrict__ slots, int slot_stride,
-                                                              uint32_t* __restrict__ sizes, uint32_t* __restrict__ adler) {
+constexpr int PNG_NT = 256;
+__global__ __launch_bounds__(PNG_NT) void png_deflate_rows_kernel(const uint8_t* __restrict__ rows, int row_bytes, int height,
+                                                                  uint8_t* __restrict__ slots, int slot_stride,
+                                                                  uint32_t* __restrict__ sizes, uint32_t* __restrict__ adler) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-  const int r = blockIdx.x, lane = threadIdx.x;
+  __shared__ uint32_t s_wave[PNG_NT / 64], s_ad[PNG_NT / 64][2], s_misc[4];      // 64 bytes: the dynamic region stays 16-byte aligned
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row_pad = (row_bytes + 8 + 15) / 16 * 16;
   uint32_t* row32 = reinterpret_cast<uint32_t*>(lds);               // the row, byte 0 at word 0
   const uint8_t* row8 = lds;
@@ -201,17 +200,17 @@ __global__ __launch_bounds__(64) void png_deflate_rows_kernel(const uint8_t* __r
   const int mis = (int)(reinterpret_cast<uintptr_t>(src) & 3u);
   const uint32_t* src32 = reinterpret_cast<const uint32_t*>(src - mis);
   const int n_words = (row_bytes + 3) / 4;
-  for (int i0 = 0; i0 <= n_words; i0 += 64 * 8) {                   // eight words per lane in flight (one round trip per 2 KB)
-    uint32_t lo[8], hi[8];
+  for (int i0 = 0; i0 <= n_words; i0 += PNG_NT * 4) {               // four words per thread in flight
+    uint32_t lo[4], hi[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * 64 + lane;
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * PNG_NT + tid;
       lo[u] = i < n_words ? src32[i] : 0u;
       hi[u] = (i < n_words && mis) ? src32[i + 1] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * 64 + lane;
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * PNG_NT + tid;
       if (i > n_words) continue;                                    // word n_words: padding behind the row (zero)
       uint32_t v = mis ? __funnelshift_r(lo[u], hi[u], 8 * mis) : lo[u];
       const int tail = row_bytes - 4 * i;                           // bytes of this word that belong to the row
@@ -219,37 +218,54 @@ __global__ __launch_bounds__(64) void png_deflate_rows_kernel(const uint8_t* __r
       row32[i] = v;
     }
   }
-  for (int i = lane; i < slot_stride / 4; i += 64) s_out[i] = 0u;
+  for (int i = tid; i < slot_stride / 4; i += PNG_NT) s_out[i] = 0u;
   __syncthreads();
-  const int piece = max(64, ((row_bytes + 63) / 64 + 3) & ~3);      // short rows use fewer lanes: a run is cut at every piece boundary
-  const int b = min(lane * piece, row_bytes), e = min(b + piece, row_bytes);
-  // pass 1: bits of this lane's piece, Adler terms
+  // pieces: a multiple of 4 bytes, at least 16 (short rows use fewer threads), at most 64 (one mask word)
+  const int piece = max(16, ((row_bytes + PNG_NT - 1) / PNG_NT + 3) & ~3);
+  const int b = min(tid * piece, row_bytes), e = min(b + piece, row_bytes);
+  const PieceMasks m = build_masks(row32, b, e - b);
+  // threads whose whole piece continues a run: merged along the wave, the first of a chain emits the stretch
+  const bool full = e > b && m.eq == m.valid;
+  const unsigned long long fbal = __ballot(full);
+  const bool chained = full && lane > 0 && ((fbal >> (lane - 1)) & 1ull);
+  int chain_bytes = full && !chained ? min(b + ctz64(~(fbal >> lane)) * piece, row_bytes) - b : 0;
+  // (a chain shorter than a match can be -- the row's last piece, one to three bytes, on its own -- is walked like any other piece)
+  const bool walk = !full || (!chained && chain_bytes < 4);
+  if (chain_bytes < 4) chain_bytes = 0;
+  // pass 1: bits of this thread's tokens, Adler terms
   uint32_t nbits = 0, a_sum = 0, b_sum = 0;
-  const bool single = e - b <= 128;                                // one sub-piece: its masks serve both passes
-  PieceMasks m0 = build_masks(row32, b, min(128, e - b));
-  for (int sb = b; sb < e; sb += 128) {
-    const PieceMasks m = sb == b ? m0 : build_masks(row32, sb, min(128, e - sb));
+  if (chain_bytes) {
+    emit_long_run(chain_bytes, [&](int run) { unsigned long long bits; int n; match_code(run, bits, n); nbits += (uint32_t)n; });
+  } else if (walk) {
     walk_piece(m,
                [&](int i, int n) {
-                 U128 g = shr128(m.ge, i);
-                 if (n < 64) { g.lo &= (1ull << n) - 1ull; g.hi = 0ull; } else if (n < 128) g.hi &= (1ull << (n - 64)) - 1ull;
-                 nbits += 8u * (uint32_t)n + (uint32_t)(__popcll(g.lo) + __popcll(g.hi));
+                 const unsigned long long g = (m.ge >> i) & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+                 nbits += 8u * (uint32_t)n + (uint32_t)__popcll(g);
                },
                [&](int run) { unsigned long long bits; int n; match_code(run, bits, n); nbits += (uint32_t)n; });
   }
-  // Adler terms a word at a time (b is a multiple of 4 for every lane that owns bytes; the bytes behind the row are zero and
+  // Adler terms a word at a time (b is a multiple of 4 for every thread that owns bytes; the bytes behind the row are zero and
   // pieces end on word boundaries or at the row's end): with d0..d3 the bytes at positions p..p+3, sum d = sad(word, 0),
   // sum (L - pos) d = (L - p) sum d - (d1 + 2 d2 + 3 d3), and d1 + 2 d2 + 3 d3 = sad(d1, d3) + 2 sad(d2, d3).
   for (int i = b >> 2; b < e && 4 * i < e; ++i) {
     const uint32_t v = row32[i];
-    const uint32_t s = __builtin_amdgcn_sad_u8(v, 0u, 0u);
+    const uint32_t sd = __builtin_amdgcn_sad_u8(v, 0u, 0u);
     const uint32_t wsum = __builtin_amdgcn_sad_u8(v & 0xFF00FF00u, 0u, 0u) + 2u * __builtin_amdgcn_sad_u8(v & 0xFFFF0000u, 0u, 0u);
-    a_sum += s;
-    b_sum += (uint32_t)(row_bytes - 4 * i) * s - wsum;              // < 2^32: 184 * 255 * 11521
+    a_sum += sd;
+    b_sum += (uint32_t)(row_bytes - 4 * i) * sd - wsum;             // < 2^32: 64 * 255 * 16384
   }
+  // bit offsets: prefix sum over the 256 threads (wave scans + four wave totals through LDS)
   const uint32_t incl = wave_incl_scan_u32(nbits, lane);
-  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  uint32_t pos = 3u + incl - nbits;                        // behind the 3-bit block header
+  if (lane == 63) s_wave[wave] = incl;
+  uint32_t ra = a_sum % ADLER_MOD, rb = b_sum % ADLER_MOD;          // residues < 2^16: the wave sums fit 32 bits
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { ra += (uint32_t)__shfl_xor((int)ra, d, 64); rb += (uint32_t)__shfl_xor((int)rb, d, 64); }
+  if (lane == 0) { s_ad[wave][0] = ra; s_ad[wave][1] = rb; }
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < PNG_NT / 64; ++w) { const uint32_t t = s_wave[w]; if (w < wave) base += t; total += t; }
+  uint32_t pos = 3u + base + incl - nbits;                          // behind the 3-bit block header
   // pass 2: emit
   unsigned long long acc = 0ull;
   int nacc = (int)(pos & 31u);
@@ -259,14 +275,15 @@ __global__ __launch_bounds__(64) void png_deflate_rows_kernel(const uint8_t* __r
     nacc += n;
     if (nacc >= 32) { atomicOr(&s_out[w], (uint32_t)acc); acc >>= 32; nacc -= 32; ++w; }
   };
-  for (int sb = b; sb < e; sb += 128) {
-    const PieceMasks m = (single || sb == b) ? m0 : build_masks(row32, sb, min(128, e - sb));
+  if (chain_bytes) {
+    emit_long_run(chain_bytes, [&](int run) { unsigned long long bits; int n; match_code(run, bits, n); put(bits, n); });
+  } else if (walk) {
     walk_piece(m,
                [&](int i, int n) {
-                 for (int k = 0; k < n; k += 4) {          // four independent byte loads, then their codes
+                 for (int k = 0; k < n; k += 4) {            // four independent byte loads, then their codes
                    uint32_t v[4];
 #pragma unroll
-                   for (int u = 0; u < 4; ++u) v[u] = row8[sb + i + min(k + u, n - 1)];
+                   for (int u = 0; u < 4; ++u) v[u] = row8[b + i + min(k + u, n - 1)];
 #pragma unroll
                    for (int u = 0; u < 4; ++u)
                      if (k + u < n) { uint32_t cb; int cn; lit_code(v[u], cb, cn); put((unsigned long long)cb, cn); }
@@ -275,25 +292,26 @@ __global__ __launch_bounds__(64) void png_deflate_rows_kernel(const uint8_t* __r
                [&](int run) { unsigned long long bits; int n; match_code(run, bits, n); put(bits, n); });
   }
   if (nacc) atomicOr(&s_out[w], (uint32_t)acc);
-  uint32_t end_bits = 3u + total;
-  if (lane == 0) {
+  __syncthreads();                                                  // every wave's codes are in the LDS image
+  if (tid == 0) {
     atomicOr(&s_out[0], 2u);                               // BFINAL = 0, BTYPE = 01 (fixed Huffman): bits 0, 1, 0
+    uint32_t end_bits = 3u + total;
     end_bits += 7u;                                        // end of block: seven zero bits (already there)
     end_bits += 3u;                                        // empty stored block: BFINAL = 0, BTYPE = 00 (zero bits) ...
     const uint32_t byte0 = (end_bits + 7u) >> 3;           // ... padded to a byte boundary, then LEN = 0, NLEN = 0xFFFF
     uint8_t* ob = reinterpret_cast<uint8_t*>(s_out);
-    ob[byte0 + 2] = 0xFF; ob[byte0 + 3] = 0xFF;            // nobody else touches bytes behind the block
+    ob[byte0 + 2] = 0xFF; ob[byte0 + 3] = 0xFF;
+    s_misc[0] = byte0 + 4u;
     sizes[r] = byte0 + 4u;
-  }
-  // Adler terms of the row, modulo 65521 (lane terms < 2^32, their residues < 2^16: the wave sum fits 32 bits)
-  uint32_t ra = a_sum % ADLER_MOD, rb = b_sum % ADLER_MOD;
+    uint32_t ta = 0, tb = 0;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { ra += (uint32_t)__shfl_xor((int)ra, d, 64); rb += (uint32_t)__shfl_xor((int)rb, d, 64); }
-  if (lane == 0) { adler[2 * r] = ra % ADLER_MOD; adler[2 * r + 1] = rb % ADLER_MOD; }
+    for (int k = 0; k < PNG_NT / 64; ++k) { ta += s_ad[k][0] % ADLER_MOD; tb += s_ad[k][1] % ADLER_MOD; }
+    adler[2 * r] = ta % ADLER_MOD; adler[2 * r + 1] = tb % ADLER_MOD;
+  }
   __syncthreads();
-  const uint32_t n_out = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((3u + total + 7u + 3u + 7u) >> 3) + 4u));
+  const uint32_t n_out = s_misc[0];
   uint32_t* dst = reinterpret_cast<uint32_t*>(slots + (size_t)r * slot_stride);
-  for (uint32_t i = lane; i < (n_out + 3u) / 4u; i += 64) dst[i] = s_out[i];
+  for (uint32_t i = tid; i < (n_out + 3u) / 4u; i += PNG_NT) dst[i] = s_out[i];
 }
 
 // grid = height + 1 waves.  Wave r < height copies row r's block to its place in the stream; wave `height` writes the frame.
@@ -391,7 +409,8 @@ extern "C" int omfs_png_deflate(const uint8_t* rows, int width, int height, uint
   const size_t lds = (size_t)((row_bytes + 8 + 15) / 16 * 16) + (size_t)stride;
   OMFS_REQUIRE(lds <= 64 * 1024, "scanline too long for the LDS image of its deflate block");
   hipStream_t s = (hipStream_t)stream_hip;
-  hipLaunchKernelGGL(png_deflate_rows_kernel, dim3(height), dim3(64), lds, s, rows, row_bytes, height, slots, stride, sizes, adler);
+  OMFS_REQUIRE(row_bytes <= 64 * PNG_NT, "scanline longer than 16384 bytes");
+  hipLaunchKernelGGL(png_deflate_rows_kernel, dim3(height), dim3(PNG_NT), lds, s, rows, row_bytes, height, slots, stride, sizes, adler);
   OMFS_CHECK_HIP(hipGetLastError());
   hipLaunchKernelGGL(png_assemble_kernel, dim3(height + 1), dim3(64), 0, s, (const uint8_t*)slots, stride, (const uint32_t*)sizes,
                      (const uint32_t*)adler, height, row_bytes, stream, stream_capacity, stream_len);

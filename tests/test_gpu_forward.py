@@ -208,7 +208,11 @@ def test_device_png_deflate_decodes_to_the_frame(width, height):
     noise = torch.rand(3, height, width, generator=gen)
     cases = {"noise": noise, "black": torch.zeros(3, height, width), "colour": torch.tensor([0.2, 0.7, 0.45])[:, None, None].expand(3, height, width),
              "white": torch.ones(3, height, width), "head": torch.where(blob[None], noise, torch.tensor([0.1, 0.9, 0.3])[:, None, None]),
-             "short_runs": (torch.arange(width)[None, None, :] // 2 % 2).float().expand(3, height, width)}
+             "short_runs": (torch.arange(width)[None, None, :] // 2 % 2).float().expand(3, height, width),
+             # the row's last pixel repeats the one before: a run that starts in the row's last, possibly 1-byte, piece
+             "tail_match": torch.cat([noise[:, :, :-1], noise[:, :, -2:-1]], 2),
+             # long runs inside noise: matches of every length class up to 258 and chains that start and stop mid-row
+             "bars": torch.where((xx % 97 < (yy % 90) + 2)[None], torch.tensor([0.3, 0.6, 0.9])[:, None, None], noise)}
     for name, img in cases.items():
         rast.image.copy_(img.contiguous().cuda())
         want = rast.to_rgb8().cpu().numpy().copy()
