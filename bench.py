@@ -93,6 +93,11 @@ def cpu_baseline_train(snap):
     g, seq, cam, t, target = snap["gaussians"], snap["seq"], snap["camera"], snap["timestep"], snap["target"]
     n_s, (h_s, w_s) = int(g["xyz"].shape[0]), target.shape[1:]
     dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq, device="cpu")   # host arrays for the C oracle (inputs already resident)
+    if snap.get("rotmats") is not None:
+        # rotation matrices are an INPUT of the bit-level stage: with fine-tuning on, the device forms them from
+        # the axis-angle poses with its own sinf / cosf (flame_joints), and an ulp of difference against the host's would move a
+        # pair or two of the 3.4 M across the tile test -- the oracle poses from the matrices the device posed from
+        dflame.h_rotmats = np.ascontiguousarray(snap["rotmats"], np.float32).reshape(dflame.h_rotmats.shape)
     ccam = CO.camera(make_camera_struct(cam, sh_degree=3))
     params = pack_params(g)
     org = {"v_template": torch.from_numpy(rig.v_template), "shapedirs": torch.from_numpy(rig.shapedirs),
@@ -270,7 +275,8 @@ def main():
         sv = views[view_index(trainer.step_idx, rank, world, len(views), trainer.view_seed)]
         snap = {"gaussians": trainer.model.to_dict(),
                 "seq": trainer.flame_ft.to_flame_params(seq) if trainer.flame_ft is not None else seq,
-                "camera": sv.camera, "timestep": sv.timestep, "target": sv.target.float().cpu()}
+                "camera": sv.camera, "timestep": sv.timestep, "target": sv.target.float().cpu(),
+                "rotmats": trainer.dflame.rotmats.cpu().numpy()}
     trainer.step()
     torch.cuda.synchronize()
     D = int(trainer.rast.tile_start[-1].item())
