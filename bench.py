@@ -396,8 +396,12 @@ def main():
                 return sum(len(p) for p in png_parts_from_zlib_stream(rr.fetch_png_stream(k, event), W, H))   # what render.py writes
 
             with ThreadPoolExecutor(max_workers=host_cores()) as pool:
-                for v in frames[:n_slots]:                      # ring, pinned buffers, per-thread copy streams: set up outside the clock
-                    pool.submit(encode, *rr.render_png_stream(v, n_slots)).result()
+                # ring, pinned buffers, the pool's threads and their first call into the HIP runtime: set up outside the clock (a
+                # pool only starts a thread when no idle one exists, so the warm-up keeps a whole ring of frames in flight, twice)
+                for _ in range(2):
+                    warm = [pool.submit(encode, *rr.render_png_stream(v, n_slots)) for v in frames[:n_slots]]
+                    for f in warm:
+                        f.result()
                 torch.cuda.synchronize()
                 t2 = time.perf_counter()
                 futs, png_bytes = [], 0
