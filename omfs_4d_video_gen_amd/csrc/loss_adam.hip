@@ -43,26 +43,31 @@ __device__ __forceinline__ f2 pk_fma(float g, f2 b, f2 c) { return __builtin_ele
 // Streaming separable window: one wave owns a 64-column strip and walks SROWS input rows top to bottom.
 // Each row goes through LDS once for the horizontal taps; the vertical taps read a ring of the last 11
 // horizontally filtered rows that lives in registers (the row loop is unrolled by 11 so every ring index is
-// static). Global loads are issued two rows ahead.
-__global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
-                                                      int width, int height, float w_l1, float w_ssim, GaussW gw,
-                                                      float* __restrict__ map_mu1, float* __restrict__ map_xx,
-                                                      float* __restrict__ map_xy, float* __restrict__ partials) {
-  __shared__ f2 sxy[SW + 2 * HALO];       // (image, target) of one input row
-  const int l = threadIdx.x, ch = blockIdx.z;
-  const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH;
-  const size_t plane = (size_t)width * height;
-  const float* ip = img + ch * plane;
-  const float* gp = gt + ch * plane;
-  const int xa = ox - HALO + l, xb = ox + SW - HALO + l, xo = ox + l;
-  const bool ina = xa >= 0 && xa < width, inb = l < 2 * HALO && xb < width, ino = xo < width;
+// static). Global loads are issued SSIM_PF rows ahead.
+//   Two instantiations.  These kernels run at < 3 waves per SIMD, so a wave's time is the sum of ALL its instructions -- and a
+// third of them were scalar: per row, the bounds of the image (row inside? column inside? output row inside?) as 64-bit mask
+// arithmetic with an execution-mask branch each, and 64-bit row addresses (r03_b: 4.6 M scalar next to 16.0 M vector instructions
+// in the forward, 5.4 M next to 9.3 M in the backward).  Seven strips of eight touch no border: for them (EDGE = false) every
+// load and store is unconditional, the halo columns are loaded by all lanes (lanes >= 10 repeat lane 9's address), offsets are
+// 32-bit, and what is left per row are two wave-uniform tests on "first / last block of 11 rows".  Same arithmetic, same bits.
+template <bool EDGE>
+__device__ __forceinline__ float ssim_fwd_strip(const float* __restrict__ ip, const float* __restrict__ gp, int width, int height,
+                                                int ox, int oy, int l, float w_l1, float w_ssim, const GaussW& gw,
+                                                float* __restrict__ m_mu1, float* __restrict__ m_xx, float* __restrict__ m_xy, f2* sxy) {
+  const int xa = ox - HALO + l, xb = ox + SW - HALO + (EDGE ? l : min(l, 2 * HALO - 1)), xo = ox + l;
+  const bool ina = !EDGE || (xa >= 0 && xa < width), inb = !EDGE || (l < 2 * HALO && xb < width), ino = !EDGE || xo < width;
   auto load_row = [&](int iy, float (&v)[4]) {
     const int y = oy - HALO + iy;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (iy < SROWS && y >= 0 && y < height) {
-      const size_t ro = (size_t)y * width;
-      if (ina) { v[0] = ip[ro + xa]; v[1] = gp[ro + xa]; }
-      if (inb) { v[2] = ip[ro + xb]; v[3] = gp[ro + xb]; }
+    if (EDGE) {
+      v[0] = v[1] = v[2] = v[3] = 0.f;
+      if (iy < SROWS && y >= 0 && y < height) {
+        const size_t ro = (size_t)y * width;
+        if (ina) { v[0] = ip[ro + xa]; v[1] = gp[ro + xa]; }
+        if (inb) { v[2] = ip[ro + xb]; v[3] = gp[ro + xb]; }
+      }
+    } else {
+      const int ro = y * width;
+      v[0] = ip[ro + xa]; v[1] = gp[ro + xa]; v[2] = ip[ro + xb]; v[3] = gp[ro + xb];
     }
   };
   f2 ring_m[11], ring_q[11];      // horizontally filtered (x, y) and (x^2, y^2) of the last 11 rows
@@ -72,12 +77,16 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
 #pragma unroll
   for (int k = 0; k < SSIM_PF; ++k) load_row(1 + k, pre[k]);
   float contrib = 0.f;
-  for (int base = 0; base < SROWS; base += 11) {
+  constexpr int NBLK = SROWS / 11;
+  for (int blk = 0; blk < NBLK; ++blk) {
+    const int base = blk * 11;
+    const bool first = blk == 0, last = blk == NBLK - 1;
 #pragma unroll
     for (int r = 0; r < 11; ++r) {
       const int iy = base + r;
       sxy[l] = (f2){cur[0], cur[1]};
-      if (l < 2 * HALO) sxy[SW + l] = (f2){cur[2], cur[3]};
+      if (EDGE) { if (l < 2 * HALO) sxy[SW + l] = (f2){cur[2], cur[3]}; }
+      else sxy[SW + l] = (f2){cur[2], cur[3]};            // lanes >= 10 fill slots nobody reads
       __syncthreads();
 #pragma unroll
       for (int k = 0; k < 4; ++k) cur[k] = pre[0][k];
@@ -85,7 +94,8 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
       for (int q = 0; q + 1 < SSIM_PF; ++q)
 #pragma unroll
         for (int k = 0; k < 4; ++k) pre[q][k] = pre[q + 1][k];
-      load_row(iy + 1 + SSIM_PF, pre[SSIM_PF - 1]);
+      if (EDGE) load_row(iy + 1 + SSIM_PF, pre[SSIM_PF - 1]);
+      else if (r + 1 + SSIM_PF < 11 || !last) load_row(iy + 1 + SSIM_PF, pre[SSIM_PF - 1]);      // rows behind the strip are not needed
       f2 am = {0.f, 0.f}, aq = {0.f, 0.f};
       float ac = 0.f;
 #pragma unroll
@@ -95,10 +105,17 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
         am = pk_fma(g, v, am); aq = pk_fma(g, v * v, aq); ac = fma_(g, v.x * v.y, ac);
       }
       ring_m[r] = am; ring_q[r] = aq; ring_c[r] = ac;
-      const int yin = oy - HALO + iy;
-      if (iy >= HALO && iy < HALO + SRH && yin < height && ino) { const f2 c = sxy[l + HALO]; contrib += w_l1 * fabsf(c.x - c.y); }
+      if (EDGE) {
+        const int yin = oy - HALO + iy;
+        if (iy >= HALO && iy < HALO + SRH && yin < height && ino) { const f2 c = sxy[l + HALO]; contrib += w_l1 * fabsf(c.x - c.y); }
+      } else {
+        // rows HALO .. HALO + SRH - 1 of the strip are its own: a wave-uniform weight instead of a branch (+ 0 leaves the sum as it is)
+        const bool own = (r >= HALO || !first) && (r < HALO + SRH - (SROWS - 11) || !last);
+        const f2 c = sxy[l + HALO];
+        contrib += (own ? w_l1 : 0.f) * fabsf(c.x - c.y);
+      }
       const int yout = oy + iy - 2 * HALO;
-      if (iy >= 2 * HALO && yout < height && ino) {
+      if (EDGE ? (iy >= 2 * HALO && yout < height && ino) : (r >= 2 * HALO || !first)) {
         f2 mu = {0.f, 0.f}, ee = {0.f, 0.f};
         float exy = 0.f;
 #pragma unroll
@@ -115,14 +132,36 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
         const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
         const float iB = iB1 * iB2;
         const float ssim = A1 * A2 * iB;
-        const size_t o = ch * plane + (size_t)yout * width + xo;
-        map_mu1[o] = (2.f * mu2 * (A2 - A1)) * iB - 2.f * mu1 * ssim * iB1 + 2.f * mu1 * ssim * iB2;
-        map_xx[o] = -ssim * iB2;
-        map_xy[o] = 2.f * A1 * iB;
+        const float o_mu1 = (2.f * mu2 * (A2 - A1)) * iB - 2.f * mu1 * ssim * iB1 + 2.f * mu1 * ssim * iB2;
+        if (EDGE) {
+          const size_t o = (size_t)yout * width + xo;
+          m_mu1[o] = o_mu1; m_xx[o] = -ssim * iB2; m_xy[o] = 2.f * A1 * iB;
+        } else {
+          const int o = yout * width + xo;
+          m_mu1[o] = o_mu1; m_xx[o] = -ssim * iB2; m_xy[o] = 2.f * A1 * iB;
+        }
         contrib -= w_ssim * ssim;
       }
     }
   }
+  return contrib;
+}
+
+__global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+                                                      int width, int height, float w_l1, float w_ssim, GaussW gw,
+                                                      float* __restrict__ map_mu1, float* __restrict__ map_xx,
+                                                      float* __restrict__ map_xy, float* __restrict__ partials) {
+  __shared__ f2 sxy[2 * SW];       // (image, target) of one input row: 64 + 10 columns (the interior form writes 128)
+  const int l = threadIdx.x, ch = blockIdx.z;
+  const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH;
+  const size_t plane = (size_t)width * height;
+  const float* ip = img + ch * plane;
+  const float* gp = gt + ch * plane;
+  float* m0 = map_mu1 + ch * plane; float* m1 = map_xx + ch * plane; float* m2 = map_xy + ch * plane;
+  // a strip that touches no border of the image (and whose plane fits 32-bit offsets): nothing to test per row
+  const bool interior = ox >= HALO && ox + SW + HALO <= width && oy >= HALO && oy + SRH + HALO <= height && plane < (size_t)(1u << 30);
+  float contrib = interior ? ssim_fwd_strip<false>(ip, gp, width, height, ox, oy, l, w_l1, w_ssim, gw, m0, m1, m2, sxy)
+                           : ssim_fwd_strip<true>(ip, gp, width, height, ox, oy, l, w_l1, w_ssim, gw, m0, m1, m2, sxy);
   contrib = wave_sum_all(contrib);
   // one partial per wave (24k same-address atomics would serialise at ~11 ns each), parked behind the three maps; ONE extra wave
   // of ssim_bwd_kernel adds them up in index order (bitwise reproducible), so the loss needs no launch of its own.  (Letting the
@@ -131,14 +170,106 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
   if (l == 0) partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = contrib;
 }
 
+// The backward strip: convolves the three derivative maps back (same ring structure) and adds the L1 sign term.  EDGE as above.
+template <bool EDGE>
+__device__ __forceinline__ void ssim_bwd_strip(const float* __restrict__ ip, const float* __restrict__ gp, int width, int height,
+                                               int ox, int oy, int l, float w_l1, float w_ssim, const GaussW& gw,
+                                               const float* __restrict__ m_mu1, const float* __restrict__ m_xx,
+                                               const float* __restrict__ m_xy, float* __restrict__ dimg, f2* s01, float* s2) {
+  const int xa = ox - HALO + l, xb = ox + SW - HALO + (EDGE ? l : min(l, 2 * HALO - 1)), xo = ox + l;
+  const bool ina = !EDGE || (xa >= 0 && xa < width), inb = !EDGE || (l < 2 * HALO && xb < width), ino = !EDGE || xo < width;
+  auto load_row = [&](int iy, float (&v)[8], bool maps, bool pix) {
+    const int y = oy - HALO + iy;
+    // the pixel pair of the output row this input row completes two iterations later (row iy - 10)
+    const int yo = oy + iy - 2 * HALO;
+    if (EDGE) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = 0.f;
+      if (iy < SROWS_B && y >= 0 && y < height) {
+        const size_t ro = (size_t)y * width;
+        if (ina) { v[0] = m_mu1[ro + xa]; v[1] = m_xx[ro + xa]; v[2] = m_xy[ro + xa]; }
+        if (inb) { v[3] = m_mu1[ro + xb]; v[4] = m_xx[ro + xb]; v[5] = m_xy[ro + xb]; }
+      }
+      if (iy >= 2 * HALO && iy < SROWS_B && yo < height && ino) { v[6] = ip[(size_t)yo * width + xo]; v[7] = gp[(size_t)yo * width + xo]; }
+    } else {
+      if (maps) {
+        const int ro = y * width;
+        v[0] = m_mu1[ro + xa]; v[1] = m_xx[ro + xa]; v[2] = m_xy[ro + xa];
+        v[3] = m_mu1[ro + xb]; v[4] = m_xx[ro + xb]; v[5] = m_xy[ro + xb];
+      }
+      if (pix) { v[6] = ip[yo * width + xo]; v[7] = gp[yo * width + xo]; }
+    }
+  };
+  f2 ring01[11];
+  float ring2[11];
+  float cur[8], pre[SSIM_PF][8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) cur[k] = 0.f;
+#pragma unroll
+  for (int q = 0; q < SSIM_PF; ++q)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pre[q][k] = 0.f;
+  load_row(0, cur, true, false);
+#pragma unroll
+  for (int k = 0; k < SSIM_PF; ++k) load_row(1 + k, pre[k], true, 1 + k >= 2 * HALO);
+  constexpr int NBLK = SROWS_B / 11;
+  for (int blk = 0; blk < NBLK; ++blk) {
+    const int base = blk * 11;
+    const bool first = blk == 0, last = blk == NBLK - 1;
+#pragma unroll
+    for (int r = 0; r < 11; ++r) {
+      const int iy = base + r;
+      s01[l] = (f2){cur[0], cur[1]}; s2[l] = cur[2];
+      if (EDGE) { if (l < 2 * HALO) { s01[SW + l] = (f2){cur[3], cur[4]}; s2[SW + l] = cur[5]; } }
+      else { s01[SW + l] = (f2){cur[3], cur[4]}; s2[SW + l] = cur[5]; }          // lanes >= 10 fill slots nobody reads
+      __syncthreads();
+      const float xv = cur[6], yv = cur[7];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cur[k] = pre[0][k];
+#pragma unroll
+      for (int q = 0; q + 1 < SSIM_PF; ++q)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pre[q][k] = pre[q + 1][k];
+      if (EDGE) load_row(iy + 1 + SSIM_PF, pre[SSIM_PF - 1], true, true);
+      else if (r + 1 + SSIM_PF < 11 || !last)       // rows behind the strip are not needed; the pixel pair from input row 10 on
+        load_row(iy + 1 + SSIM_PF, pre[SSIM_PF - 1], true, r + 1 + SSIM_PF >= 2 * HALO || !first);
+      f2 a01 = {0.f, 0.f};
+      float a2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 11; ++t) {
+        const float g = gw.g[t];
+        a01 = pk_fma(g, s01[l + t], a01); a2 = fma_(g, s2[l + t], a2);
+      }
+      ring01[r] = a01; ring2[r] = a2;
+      const int yout = oy + iy - 2 * HALO;
+      if (EDGE ? (iy >= 2 * HALO && yout < height && ino) : (r >= 2 * HALO || !first)) {
+        f2 c01 = {0.f, 0.f};
+        float c2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 11; ++t) {
+          const float g = gw.g[t];
+          const int q = (r + 1 + t) % 11;
+          c01 = pk_fma(g, ring01[q], c01); c2 = fma_(g, ring2[q], c2);
+        }
+        const float c0 = c01.x, c1 = c01.y;
+        const float d = xv - yv;
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float out = w_l1 * sgn - w_ssim * (c0 + 2.f * xv * c1 + yv * c2);
+        if (EDGE) dimg[(size_t)yout * width + xo] = out;
+        else dimg[yout * width + xo] = out;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                       int width, int height, float w_l1, float w_ssim, GaussW gw,
                                                       const float* __restrict__ map_mu1, const float* __restrict__ map_xx,
                                                       const float* __restrict__ map_xy, float* __restrict__ dimage,
                                                       const float* __restrict__ partials, int n_partials, float constant,
                                                       float* __restrict__ loss_out) {
-  __shared__ f2 s01[SW + 2 * HALO];       // (d/dmu1, d/dE[xx]) of one map row
-  __shared__ float s2[SW + 2 * HALO];     // d/dE[xy]
+  __shared__ f2 s01[2 * SW];       // (d/dmu1, d/dE[xx]) of one map row: 64 + 10 columns (the interior form writes 128)
+  __shared__ float s2[2 * SW];     // d/dE[xy]
   const int l = threadIdx.x, ch = blockIdx.z;
   if (ch == 3) {       // the fourth "channel" of the grid: its first wave is the loss reduction, the others leave at once
     if (blockIdx.x | blockIdx.y) return;
@@ -157,67 +288,11 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ 
   const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH_B;
   const size_t plane = (size_t)width * height;
   const size_t co = ch * plane;
-  const int xa = ox - HALO + l, xb = ox + SW - HALO + l, xo = ox + l;
-  const bool ina = xa >= 0 && xa < width, inb = l < 2 * HALO && xb < width, ino = xo < width;
-  auto load_row = [&](int iy, float (&v)[8]) {
-    const int y = oy - HALO + iy;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = 0.f;
-    if (iy < SROWS_B && y >= 0 && y < height) {
-      const size_t ro = co + (size_t)y * width;
-      if (ina) { v[0] = map_mu1[ro + xa]; v[1] = map_xx[ro + xa]; v[2] = map_xy[ro + xa]; }
-      if (inb) { v[3] = map_mu1[ro + xb]; v[4] = map_xx[ro + xb]; v[5] = map_xy[ro + xb]; }
-    }
-    // the pixel pair of the output row this input row completes two iterations later (row iy - 10)
-    const int yo = oy + iy - 2 * HALO;
-    if (iy >= 2 * HALO && iy < SROWS_B && yo < height && ino) { v[6] = img[co + (size_t)yo * width + xo]; v[7] = gt[co + (size_t)yo * width + xo]; }
-  };
-  f2 ring01[11];
-  float ring2[11];
-  float cur[8], pre[SSIM_PF][8];
-  load_row(0, cur);
-#pragma unroll
-  for (int k = 0; k < SSIM_PF; ++k) load_row(1 + k, pre[k]);
-  for (int base = 0; base < SROWS_B; base += 11) {
-#pragma unroll
-    for (int r = 0; r < 11; ++r) {
-      const int iy = base + r;
-      s01[l] = (f2){cur[0], cur[1]}; s2[l] = cur[2];
-      if (l < 2 * HALO) { s01[SW + l] = (f2){cur[3], cur[4]}; s2[SW + l] = cur[5]; }
-      __syncthreads();
-      const float xv = cur[6], yv = cur[7];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) cur[k] = pre[0][k];
-#pragma unroll
-      for (int q = 0; q + 1 < SSIM_PF; ++q)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) pre[q][k] = pre[q + 1][k];
-      load_row(iy + 1 + SSIM_PF, pre[SSIM_PF - 1]);
-      f2 a01 = {0.f, 0.f};
-      float a2 = 0.f;
-#pragma unroll
-      for (int t = 0; t < 11; ++t) {
-        const float g = gw.g[t];
-        a01 = pk_fma(g, s01[l + t], a01); a2 = fma_(g, s2[l + t], a2);
-      }
-      ring01[r] = a01; ring2[r] = a2;
-      const int yout = oy + iy - 2 * HALO;
-      if (iy >= 2 * HALO && yout < height && ino) {
-        f2 c01 = {0.f, 0.f};
-        float c2 = 0.f;
-#pragma unroll
-        for (int t = 0; t < 11; ++t) {
-          const float g = gw.g[t];
-          const int q = (r + 1 + t) % 11;
-          c01 = pk_fma(g, ring01[q], c01); c2 = fma_(g, ring2[q], c2);
-        }
-        const float c0 = c01.x, c1 = c01.y;
-        const float d = xv - yv;
-        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-        dimage[co + (size_t)yout * width + xo] = w_l1 * sgn - w_ssim * (c0 + 2.f * xv * c1 + yv * c2);
-      }
-    }
-  }
+  const bool interior = ox >= HALO && ox + SW + HALO <= width && oy >= HALO && oy + SRH_B + HALO <= height && plane < (size_t)(1u << 30);
+  if (interior)
+    ssim_bwd_strip<false>(img + co, gt + co, width, height, ox, oy, l, w_l1, w_ssim, gw, map_mu1 + co, map_xx + co, map_xy + co, dimage + co, s01, s2);
+  else
+    ssim_bwd_strip<true>(img + co, gt + co, width, height, ox, oy, l, w_l1, w_ssim, gw, map_mu1 + co, map_xx + co, map_xy + co, dimage + co, s01, s2);
 }
 
 struct AdamK {
