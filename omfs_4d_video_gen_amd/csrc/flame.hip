@@ -491,7 +491,22 @@ struct FrontArgs {
   float* dexpr; float* dpose; float* dtrans;
   int totals;     // partial is ONE row of totals (flame_skin_gemv_kernel) instead of n_rows per-wave rows (flame_skin_bwd_kernel)
 };
-__device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef);
+// LDS of the front: what its forward half leaves for its backward half
+struct FrontLds {
+  float sJ[15], sdJ[15], sums[64], part16[16][64], s_dcoef[256], s_pose[15];
+  float s_je[15 * 128];   // joint regressor's expression part and the coefficients: one coalesced round trip
+  float s_e[128];
+  float sR[5][9], sK[5][9], sth[5];
+};
+// forward half (joint regression, the five Rodrigues maps): depends on nothing the backward pass produces, so a kernel may run it
+// early, in the shadow of its own loads; called by all threads of a block, ends on a barrier
+__device__ void flame_front_prepare(FrontLds& F, const FrontArgs& fa);
+// backward half: totals -> chain -> axis-angle maps -> d expr; called by all threads of the block that ran flame_front_prepare
+__device__ void flame_front_finish(FrontLds& F, const FrontArgs& fa, const float* dcoef);
+__device__ __forceinline__ void flame_front_bwd(FrontLds& F, const FrontArgs& fa, const float* dcoef) {
+  flame_front_prepare(F, fa);
+  flame_front_finish(F, fa, dcoef);
+}
 
 // The block that finishes last (ticket in dcoef[gridDim.x], reset for the next call) goes on with flame_front_bwd: the
 // basis^T product and the small serial front share one launch.
@@ -527,7 +542,8 @@ __global__ __launch_bounds__(GEMV_NT) void basis_t_gemv_kernel(const float* __re
   if (s_ticket != gridDim.x - 1) return;        // uniform over the block
   __threadfence();
   if (threadIdx.x == 0) *reinterpret_cast<uint32_t*>(dcoef + gridDim.x) = 0u;
-  flame_front_bwd(fa, dcoef);
+  __shared__ FrontLds F;
+  flame_front_bwd(F, fa, dcoef);
 }
 
 // Skinning backward + basis^T product + the serial front in ONE launch (flame_skin_bwd_kernel + basis_t_gemv_kernel; their
@@ -571,7 +587,11 @@ __global__ __launch_bounds__(SKG_NT) void flame_skin_gemv_kernel(const float* __
     a = reinterpret_cast<const float4*>(v_shaped)[v];
   }
   if (tid >= 64 && tid < 124) X[tid - 64] = joint_xf[tid - 64];
-  __syncthreads();
+  // the forward half of the serial front, by EVERY workgroup in the shadow of the loads above (a few KB from L2, ~200 instructions
+  // per thread): the workgroup that turns out to be the last then starts its chain backward at once instead of first regressing
+  // the joints and evaluating five Rodrigues maps behind two more memory round trips
+  __shared__ FrontLds F;
+  flame_front_prepare(F, fa);              // (ends on a barrier: X and the staged loads are published as well)
   if (tid < SKG_V) {
     float out[3] = {0.f, 0.f, 0.f};
     const float dv[3] = {d.x, d.y, d.z};
@@ -640,7 +660,7 @@ __global__ __launch_bounds__(SKG_NT) void flame_skin_gemv_kernel(const float* __
   __syncthreads();
   FrontArgs f2 = fa;
   f2.partial = s_tot + SKG_NT;
-  flame_front_bwd(f2, s_tot);
+  flame_front_finish(F, f2, s_tot);
 }
 
 // axis-angle -> rotation matrix, the formula of flame_fitter.py:133-152: a = aa / (|aa| + 1e-8), R = I + sin K + (1 - cos) K^2
@@ -671,20 +691,39 @@ __global__ void rodrigues_kernel(const float* __restrict__ aa, int n, float* __r
 // One wave; lane 0 walks the 5-joint chain and the axis-angle maps backwards, all lanes finish d expr.
 // Called by all threads of one block (barriers inside); dcoef was written by other blocks: read through volatile,
 // once, into LDS (n_expr + 36 <= 256).
-__device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
-  const volatile float* dcoef = dcoef_;
+__device__ void flame_front_prepare(FrontLds& F, const FrontArgs& fa) {
   const float* j_static = fa.j_static; const float* j_expr = fa.j_expr; const float* expr = fa.expr; const float* pose = fa.pose;
+  const int n_expr = fa.n_expr;
+  const int lane = threadIdx.x;
+  if (lane < 15) F.s_pose[lane] = pose[lane];
+  for (int k = lane; k < 15 * n_expr; k += (int)blockDim.x) F.s_je[k] = j_expr[k];
+  for (int k = lane; k < n_expr; k += (int)blockDim.x) F.s_e[k] = expr[k];
+  __syncthreads();
+  if (lane < 15) {
+    float a = j_static[lane];
+    const float* row = F.s_je + lane * n_expr;
+    for (int k = 0; k < n_expr; ++k) a = fma_(row[k], F.s_e[k], a);
+    F.sJ[lane] = a;
+  }
+  if (lane >= 64 && lane < 69) {       // the five joint rotations (and their generators), one lane each
+    float Rj[9], Kj[9], t;
+    rodrigues_fwd(F.s_pose + (lane - 64) * 3, Rj, Kj, t);
+    for (int i = 0; i < 9; ++i) { F.sR[lane - 64][i] = Rj[i]; F.sK[lane - 64][i] = Kj[i]; }
+    F.sth[lane - 64] = t;
+  }
+  __syncthreads();
+}
+
+__device__ void flame_front_finish(FrontLds& F, const FrontArgs& fa, const float* dcoef_) {
+  const volatile float* dcoef = dcoef_;
   const int n_expr = fa.n_expr, n_rows = fa.n_rows;
   const float* partial = fa.partial;
   float* dexpr = fa.dexpr; float* dpose = fa.dpose; float* dtrans = fa.dtrans;
-  __shared__ float sJ[15], sdJ[15];
-  __shared__ float sums[64];
-  __shared__ float part16[16][64];
-  __shared__ float s_dcoef[256];     // dcoef was written by the other blocks: fetched once, by all threads in parallel
-  __shared__ float s_pose[15];
+  float (&sJ)[15] = F.sJ; float (&sdJ)[15] = F.sdJ; float (&sums)[64] = F.sums; float (&part16)[16][64] = F.part16;
+  float (&s_dcoef)[256] = F.s_dcoef; float (&s_pose)[15] = F.s_pose; float (&s_je)[15 * 128] = F.s_je;
+  float (&sR)[5][9] = F.sR; float (&sK)[5][9] = F.sK; float (&sth)[5] = F.sth;
   const int lane = threadIdx.x;
   if (lane < n_expr + 36 && lane < 256) s_dcoef[lane] = dcoef[lane];
-  if (lane < 15) s_pose[lane] = pose[lane];
   if (fa.totals) {
     if (lane < 64) part16[0][lane] = const_cast<const volatile float*>(partial)[lane];
     for (int i = 64 + lane; i < 16 * 64; i += (int)blockDim.x) part16[0][i] = 0.f;
@@ -700,24 +739,6 @@ __device__ void flame_front_bwd(const FrontArgs& fa, const float* dcoef_) {
       for (int u = 0; u < 8; ++u) t += pv[u];
     }
     part16[w][q] = t;
-  }
-  __shared__ float s_je[15 * 128];   // joint regressor's expression part and the coefficients: one coalesced round trip
-  __shared__ float s_e[128];
-  __shared__ float sR[5][9], sK[5][9], sth[5];
-  for (int k = lane; k < 15 * n_expr; k += (int)blockDim.x) s_je[k] = j_expr[k];
-  for (int k = lane; k < n_expr; k += (int)blockDim.x) s_e[k] = expr[k];
-  __syncthreads();
-  if (lane < 15) {
-    float a = j_static[lane];
-    const float* row = s_je + lane * n_expr;
-    for (int k = 0; k < n_expr; ++k) a = fma_(row[k], s_e[k], a);
-    sJ[lane] = a;
-  }
-  if (lane >= 64 && lane < 69) {       // the five joint rotations (and their generators), one lane each
-    float Rj[9], Kj[9], t;
-    rodrigues_fwd(s_pose + (lane - 64) * 3, Rj, Kj, t);
-    for (int i = 0; i < 9; ++i) { sR[lane - 64][i] = Rj[i]; sK[lane - 64][i] = Kj[i]; }
-    sth[lane - 64] = t;
   }
   __syncthreads();
   if (lane < 64) {
