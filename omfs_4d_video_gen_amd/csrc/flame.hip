@@ -559,7 +559,10 @@ __global__ __launch_bounds__(GEMV_NT) void basis_t_gemv_kernel(const float* __re
 // Float atomics on ONE cache line serialise at the memory side (~11 ns each): 161 workgroups adding into the same 136 words took
 // 22 us.  The workgroups therefore add into SKG_G copies of the accumulators (workgroup b into copy b mod SKG_G: a tenth of the
 // adds per line, sixteen times the lines), and the last workgroup adds the copies up while it consumes them.
-constexpr int SKG_V = 32, SKG_NT = 256, SKG_COLS = 3 * SKG_V, SKG_G = 16;
+#ifndef OMFS_SKG_V
+#define OMFS_SKG_V 32
+#endif
+constexpr int SKG_V = OMFS_SKG_V, SKG_NT = 256, SKG_COLS = 3 * SKG_V, SKG_G = 16;
 __global__ __launch_bounds__(SKG_NT) void flame_skin_gemv_kernel(const float* __restrict__ lbs_weights, const float* __restrict__ v_shaped,
                                                                  const float* __restrict__ joint_xf, float* __restrict__ dverts, int n_verts,
                                                                  const float* __restrict__ basis_t, int n_coef, float* __restrict__ dcoef,
