@@ -653,12 +653,33 @@ __device__ unsigned long long omfs_dbg_sort[2][3][16384];
 #define OMFS_DBG_SORT_END(path) do { } while (0)
 #endif
 
+// One list by the first NT threads of the workgroup (the others have left): bucket sort, or the counting passes when depths cluster.
+template <int NT>
+__device__ __forceinline__ int sort_one_list(uint2* __restrict__ keys_s, uint2* __restrict__ tmp_s, uint32_t* __restrict__ out, int n,
+                                             int lds_cap, uint2* bufB, volatile uint32_t* hist, volatile uint32_t* misc) {
+  if (bucket_sort_to_ids<NT>(keys_s, n <= lds_cap ? bufB : tmp_s, n, hist, misc, out)) return n <= lds_cap ? 1 : 2;
+  // clustered depths: counting passes through keys / keys_tmp (uniform over the workgroup)
+  uint2* res = radix_sort_pairs<NT>(keys_s, tmp_s, n, hist, misc);
+  __syncthreads();
+  fix_ties<NT>(res, n);
+  __syncthreads();
+  for (int k = threadIdx.x; k < n; k += NT) out[k] = res[k].y;
+  return 3;
+}
+
+// `small_n` (the 1024-thread instantiation): lists of up to small_n pairs are sorted by the first 512 threads -- the other eight
+// waves leave at once (S_BARRIER waits for the waves of the workgroup that have not ended) -- so ONE launch serves every length
+// class: the shorter lists follow the long ones in the heavy-first order and fill the slots the long lists' tail leaves empty,
+// instead of waiting in a launch of their own behind a kernel boundary.  Rounds 1-2 ran two launches (1024 threads above 2048
+// pairs, 512 threads and 24 KB of LDS below: 43 + 18 us); one launch with the split at 2048 / 4096 / 6144 pairs: 56 / 52 / 52 us;
+// 256 threads for lists below 256 ... 2048 pairs changed nothing or lost, and launching 512-thread workgroups for everything
+// (the lists beyond the LDS copy then sort with 512 threads through global memory) took 75 us.  0: every list by all NT threads.
 template <int NT>
 __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restrict__ tile_order,
                                                        const uint32_t* __restrict__ tile_start,
                                                        uint2* __restrict__ keys, uint2* __restrict__ keys_tmp,
                                                        uint32_t* __restrict__ sorted_ids, int lds_cap, int n_lo, int n_hi,
-                                                       uint32_t* __restrict__ status) {
+                                                       uint32_t* __restrict__ status, int small_n) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NW = NT / 64;
   uint2* bufB = reinterpret_cast<uint2*>(smem);
@@ -675,26 +696,21 @@ __global__ __launch_bounds__(NT) void tile_sort_kernel(const uint32_t* __restric
     if (tid == 0) sorted_ids[s] = keys[s].y;
     return;
   }
-  if (bucket_sort_to_ids<NT>(keys + s, n <= lds_cap ? bufB : keys_tmp + s, n, hist, misc, sorted_ids + s)) {
-    OMFS_DBG_SORT_END(n <= lds_cap ? 1 : 2);
-    return;
+  int path;
+  if (NT == 1024 && n <= small_n) {
+    if (tid >= 512) return;
+    path = sort_one_list<512>(keys + s, keys_tmp + s, sorted_ids + s, n, lds_cap, bufB, hist, misc);
+  } else {
+    path = sort_one_list<NT>(keys + s, keys_tmp + s, sorted_ids + s, n, lds_cap, bufB, hist, misc);
   }
-  // clustered depths: counting passes through keys / keys_tmp (uniform over the workgroup)
-  uint2* res = radix_sort_pairs<NT>(keys + s, keys_tmp + s, n, hist, misc);
-  __syncthreads();
-  fix_ties<NT>(res, n);
-  __syncthreads();
-  for (int k = tid; k < n; k += NT) sorted_ids[s + k] = res[k].y;
-  OMFS_DBG_SORT_END(3);
+  OMFS_DBG_SORT_END(path);
+  (void)path;
 }
 
-#ifndef OMFS_SORT_SMALL_NT
-#define OMFS_SORT_SMALL_NT 512
-#endif
 #ifndef OMFS_SORT_SMALL_CAP
-#define OMFS_SORT_SMALL_CAP 2048
+#define OMFS_SORT_SMALL_CAP 4096     // = the 8 keys per thread the 512-thread sort keeps in registers (one pass over memory)
 #endif
-constexpr int SORT_SMALL_NT = OMFS_SORT_SMALL_NT, SORT_SMALL_CAP = OMFS_SORT_SMALL_CAP;
+constexpr int SORT_SMALL_CAP = OMFS_SORT_SMALL_CAP;
 constexpr int SORT_LARGE_NT = 1024, SORT_LARGE_CAP_DEFAULT = 7936;   // 78 KB of LDS: two workgroups per CU
 constexpr size_t sort_lds_bytes(int cap, int nt) { return (size_t)cap * 8 + ((nt / 64) * 256 + 8) * 4; }
 
@@ -807,21 +823,18 @@ extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam,
 extern "C" int omfs_tile_sort(const omfs_camera* cam, const omfs_raster_buffers* rb, void* stream) {
   if (int rc = check_bin_args(cam, rb)) return rc;
   const int n_tiles = cdiv(cam->width, OMFS_TILE) * cdiv(cam->height, OMFS_TILE);
-  // short lists: 512 threads, 2048 pairs in LDS (24 KB);
-  // long lists : 1024 threads, sort_lds_pairs pairs in LDS (default 7936 = 78 KB, two workgroups per CU)
+  // 1024-thread workgroups with sort_lds_pairs pairs of LDS (default 7936 = 78 KB, two workgroups per CU); lists of up to
+  // SORT_SMALL_CAP pairs use the first 512 threads only
   const int cap_large = rb->sort_lds_pairs ? (int)rb->sort_lds_pairs : SORT_LARGE_CAP_DEFAULT;
   OMFS_REQUIRE(cap_large >= 256 && sort_lds_bytes(cap_large, SORT_LARGE_NT) <= 160 * 1024, "sort_lds_pairs");
   const int cap_small = cap_large < SORT_SMALL_CAP ? cap_large : SORT_SMALL_CAP;
   static std::atomic<unsigned long long> attr_done{0};
   if (int rc = ensure_max_lds((const void*)tile_sort_kernel<SORT_LARGE_NT>, 160 * 1024, attr_done)) return rc;
   hipStream_t s = (hipStream_t)stream;
+  // ONE launch of 1024-thread workgroups; lists of up to cap_small pairs are sorted by the first 512 threads of theirs
   hipLaunchKernelGGL(tile_sort_kernel<SORT_LARGE_NT>, dim3(n_tiles), dim3(SORT_LARGE_NT), sort_lds_bytes(cap_large, SORT_LARGE_NT), s,
                      rb->tile_order, rb->tile_start, (uint2*)rb->keys, (uint2*)rb->keys_tmp, rb->sorted_ids, cap_large,
-                     cap_small, 0x7fffffff, rb->status);
-  OMFS_CHECK_HIP(hipGetLastError());
-  hipLaunchKernelGGL(tile_sort_kernel<SORT_SMALL_NT>, dim3(n_tiles), dim3(SORT_SMALL_NT), sort_lds_bytes(cap_small, SORT_SMALL_NT), s,
-                     rb->tile_order, rb->tile_start, (uint2*)rb->keys, (uint2*)rb->keys_tmp, rb->sorted_ids, cap_small,
-                     0, cap_small, (uint32_t*)nullptr);
+                     0, 0x7fffffff, rb->status, cap_small);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
