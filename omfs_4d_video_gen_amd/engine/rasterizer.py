@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -71,7 +73,7 @@ class Rasterizer:
         self.rb = L.RasterBuffersC(L.ptr(self.g0), L.ptr(self.g1), L.ptr(self.g2), L.ptr(self.tile_count),
                                    L.ptr(self.tile_start), L.ptr(self.tile_cursor), L.ptr(self.tile_order),
                                    L.ptr(self.keys), L.ptr(self.keys_tmp), L.ptr(self.sorted_ids),
-                                   self.dup_capacity, int(sort_lds_pairs), L.ptr(self.status),
+                                   self.dup_capacity, int(sort_lds_pairs or os.environ.get("OMFS_SORT_LDS_PAIRS", 0)), L.ptr(self.status),
                                    L.ptr(self.seg_ckpt), L.ptr(self.order_seg0), self.seg_capacity, L.ptr(self.image),
                                    L.ptr(self.final_T), L.ptr(self.n_contrib), 0, 0)
         # backward-side buffers are created on first use
