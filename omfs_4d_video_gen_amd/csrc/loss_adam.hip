@@ -32,6 +32,21 @@ static_assert(SROWS_B % 11 == 0, "the register ring is unrolled by the 11 window
 constexpr int SSIM_PF = OMFS_SSIM_PF;   // input rows in flight per wave
 struct GaussW { float g[11]; };  // normalised 11-tap window, passed by value (scalar registers)
 
+// Which strip a workgroup takes.  Workgroups go round-robin to the 8 XCDs (linear id mod 8), each with an L2 of its own; strips
+// that are neighbours in the image share their halo columns and rows, so XCD k takes a contiguous run of the strip order
+// (x fastest, then y, then channel): neighbours then meet in ONE L2 instead of fetching the shared bytes twice from memory.
+__device__ __forceinline__ void ssim_strip_of_block(int& bx, int& by, int& bz, uint32_t nz = 3) {
+#ifndef OMFS_SSIM_NO_XCD_ORDER
+  const uint32_t gx = gridDim.x, gy = gridDim.y, n = gx * gy * nz;      // (layers z >= nz, if any, follow in the linear order)
+  const uint32_t lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+  const uint32_t xcd = lin & 7u, idx = lin >> 3, chunk = n >> 3, rem = n & 7u;
+  const uint32_t s = xcd * chunk + min(xcd, rem) + idx;
+  bx = (int)(s % gx); by = (int)((s / gx) % gy); bz = (int)(s / (gx * gy));
+#else
+  bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+#endif
+}
+
 // Packed fp32: one v_pk_fma_f32 / v_pk_mul_f32 does two IEEE operations for ~1.2x the issue time of one (4.7 against 2.7-4
 // cycles per wave-instruction, tools/micro/valu_rate.hip), and these kernels are bound by instruction issue, not by HBM
 // (17.1 M + 11.0 M VALU wave-instructions per launch at 2.5 TB/s).  The five moment maps of the forward pass and the three
@@ -152,8 +167,10 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
                                                       float* __restrict__ map_mu1, float* __restrict__ map_xx,
                                                       float* __restrict__ map_xy, float* __restrict__ partials) {
   __shared__ f2 sxy[2 * SW];       // (image, target) of one input row: 64 + 10 columns (the interior form writes 128)
-  const int l = threadIdx.x, ch = blockIdx.z;
-  const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH;
+  int bx, by, ch;
+  ssim_strip_of_block(bx, by, ch);
+  const int l = threadIdx.x;
+  const int ox = bx * SW, oy = by * SRH;
   const size_t plane = (size_t)width * height;
   const float* ip = img + ch * plane;
   const float* gp = gt + ch * plane;
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ 
   // of ssim_bwd_kernel adds them up in index order (bitwise reproducible), so the loss needs no launch of its own.  (Letting the
   // last wave of THIS kernel do it -- ticket, two levels to keep the returning atomics apart -- cost more than it saved: every
   // wave then waits for its map stores to drain before it may draw, 42 -> 52 us.)
-  if (l == 0) partials[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = contrib;
+  if (l == 0) partials[(ch * gridDim.y + by) * gridDim.x + bx] = contrib;
 }
 
 // The backward strip: convolves the three derivative maps back (same ring structure) and adds the L1 sign term.  EDGE as above.
@@ -270,8 +287,8 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ 
                                                       float* __restrict__ loss_out) {
   __shared__ f2 s01[2 * SW];       // (d/dmu1, d/dE[xx]) of one map row: 64 + 10 columns (the interior form writes 128)
   __shared__ float s2[2 * SW];     // d/dE[xy]
-  const int l = threadIdx.x, ch = blockIdx.z;
-  if (ch == 3) {       // the fourth "channel" of the grid: its first wave is the loss reduction, the others leave at once
+  const int l = threadIdx.x;
+  if (blockIdx.z == 3) {       // the fourth "channel" of the grid: its first wave is the loss reduction, the others leave at once
     if (blockIdx.x | blockIdx.y) return;
     float acc = 0.f;
     for (int i0 = 0; i0 < n_partials; i0 += 64 * 8) {
@@ -285,7 +302,9 @@ __global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ 
     if (l == 0) loss_out[0] = constant + acc;
     return;
   }
-  const int ox = blockIdx.x * SW, oy = blockIdx.y * SRH_B;
+  int bx, by, ch;
+  ssim_strip_of_block(bx, by, ch);
+  const int ox = bx * SW, oy = by * SRH_B;
   const size_t plane = (size_t)width * height;
   const size_t co = ch * plane;
   const bool interior = ox >= HALO && ox + SW + HALO <= width && oy >= HALO && oy + SRH_B + HALO <= height && plane < (size_t)(1u << 30);
