@@ -121,6 +121,29 @@ __device__ uint32_t omfs_dbg_step[2][8][OMFS_DBG_TL];
 #define OMFS_DBG_STEP(s) do { } while (0)
 #define OMFS_DBG_WAIT_VM() do { } while (0)
 #endif
+// Which (unit, quadrant) a workgroup takes, unit = tile position or list segment.  Workgroups go round-robin to the 8 XCDs
+// (linear id mod 8), each with its own L2, and the four quadrants of a unit gather the SAME list entries and records: with
+// (unit, quadrant) = (id / 4, id % 4) the four land on four XCDs and every record is fetched into four L2s.  Here a group of
+// 32 R consecutive workgroups takes 8 R consecutive units, XCD k the run of R units k R .. k R + R - 1 of the group with all
+// four quadrants of each (the grid is a multiple of 4; a last partial group keeps the plain form: a bijection either way).
+#ifndef OMFS_XCD_RUN
+#define OMFS_XCD_RUN 1
+#endif
+__device__ __forceinline__ void unit_quadrant_of_block(uint32_t& unit, int& quad) {
+#ifndef OMFS_NO_XCD_ORDER
+  constexpr uint32_t R = OMFS_XCD_RUN, G = 32u * R;
+  const uint32_t lin = blockIdx.x, group = lin / G;
+  if ((group + 1) * G <= gridDim.x) {
+    const uint32_t in = lin - group * G, k = in & 7u, a = in >> 3;       // a = 0 .. 4 R - 1 on XCD k
+    unit = (group * 8u + k) * R + (a >> 2);
+    quad = (int)(a & 3u);
+    return;
+  }
+#endif
+  unit = blockIdx.x >> 2;
+  quad = (int)(blockIdx.x & 3u);
+}
+
 constexpr int WB = 64;   // splats staged per wave and step
 #ifndef OMFS_FWD_SEQ_SEGS
 #define OMFS_FWD_SEQ_SEGS 4
@@ -169,8 +192,10 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
   __shared__ float4 s2[WB + 1];   // .x = blue (one address register serves the three reads of an entry)
   OMFS_DBG_SPAN(0);
   OMFS_DBG_PHASES();
-  const uint32_t tile = tile_order[blockIdx.x >> 2];
-  const int quad = blockIdx.x & 3, lane = threadIdx.x;
+  uint32_t upos; int quad;
+  unit_quadrant_of_block(upos, quad);
+  const uint32_t tile = tile_order[upos];
+  const int lane = threadIdx.x;
   const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const bool inside = px < cam.width && py < cam.height;
@@ -360,10 +385,12 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
   __shared__ float4 res[64];                  // exactly resolved pixels: (T, C.rgb)
   __shared__ uint32_t res_last[64];           // last contributor | terminated << 31
   OMFS_DBG_SPAN(1);
-  const uint32_t tile = tile_order[blockIdx.x >> 2];
+  uint32_t upos; int quad;
+  unit_quadrant_of_block(upos, quad);
+  const uint32_t tile = tile_order[upos];
   const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
   if (tend - tbeg <= (uint32_t)(FWD_SEQ_SEGS * OMFS_SEG)) return;
-  const int quad = blockIdx.x & 3, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     pg0[wave][0] = make_float4(0.f, 0.f, 0.f, 0.f);
     pg1[wave][0] = make_float4(0.f, -1e30f, 0.f, 0.f);
@@ -640,7 +667,8 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
   __shared__ float red[PEND][NGRP][9];    // [pending slot][lane group][value]
   __shared__ uint32_t pend_id[PEND];      // Gaussian id of each pending slot
   OMFS_DBG_SPAN(2);
-  const uint32_t seg = blockIdx.x >> 2;
+  uint32_t seg; int quad;
+  unit_quadrant_of_block(seg, quad);
   if (seg >= order_seg0[n_tiles]) return;
   // launch-order position p with order_seg0[p] <= seg < order_seg0[p+1] (bisection, ~13 L2-resident loads)
   int lo = 0, hi = n_tiles;
@@ -649,7 +677,7 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
     if (order_seg0[mid] <= seg) lo = mid; else hi = mid;
   }
   const uint32_t tile = tile_order[lo], kseg = seg - order_seg0[lo];
-  const int quad = blockIdx.x & 3, lane = threadIdx.x;
+  const int lane = threadIdx.x;
   const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
   const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
