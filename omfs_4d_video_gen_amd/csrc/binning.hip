@@ -234,9 +234,20 @@ __device__ __forceinline__ int bin_gaussian(int l) {
   return ((q * waves + (int)blockIdx.x * BIN_WAVES + w) << 2) + (l & 3);
 #else
   const int stripe = q >> 1, run = ((q & 1) << 3) | w;          // run q * 8 + w of the workgroup's 128
-  return ((stripe * (int)gridDim.x + (int)blockIdx.x) << 6) + (run << 2) + (l & 3);
+#ifndef OMFS_BIN_NO_XCD_ORDER
+  // which logical workgroup this one is: the grid is a multiple of 32 (bin_blocks) and workgroups go to XCD (id mod 8); logical
+  // workgroup 32 a + 4 k + c runs as id 32 a + 8 c + k, i.e. on XCD k -- and every one of its stripes (chunks stripe * grid + B
+  // of 64 Gaussians) was written by a project_fwd workgroup (256 Gaussians, id mod 8) of XCD k too: the records it reads
+  // are still in THAT L2
+  const int lin = (int)blockIdx.x, B = (lin & ~31) | ((lin & 7) << 2) | ((lin >> 3) & 3);
+#else
+  const int B = (int)blockIdx.x;
+#endif
+  return ((stripe * (int)gridDim.x + B) << 6) + (run << 2) + (l & 3);
 #endif
 }
+// workgroups of the count / scatter launches: a multiple of 32 (see bin_gaussian; surplus workgroups own no Gaussian)
+static inline int bin_blocks(int n) { return ((cdiv(n, BIN_THREADS) + 31) / 32) * 32; }
 
 // calls f(tile) for every tile of Gaussian i's rectangle that passes the test (lane-per-Gaussian form, fallback kernels)
 template <typename F>
@@ -731,13 +742,13 @@ static constexpr size_t BIN_LDS_LIMIT = 150 * 1024;
 // The tile-test ballots recorded by omfs_bin_count for omfs_bin_scatter live in keys_tmp (8 B per pair of capacity,
 // idle until the sort): HITS_PER_WAVE words for each wave of 64 Gaussians; NULL (recompute) when it is too small.
 static unsigned long long* hits_buffer(int n, const omfs_raster_buffers* rb) {
-  const size_t need = (size_t)cdiv(n, BIN_THREADS) * BIN_WAVES * HITS_PER_WAVE;
+  const size_t need = (size_t)bin_blocks(n) * BIN_WAVES * HITS_PER_WAVE;
   return need <= (size_t)rb->dup_capacity ? reinterpret_cast<unsigned long long*>(rb->keys_tmp) : nullptr;
 }
 // ... followed by one list of (tile, count) pairs per workgroup of the count kernel (n_tiles + 1 entries each); NULL when
 // keys_tmp cannot hold them (the scatter then counts for itself)
 static uint2* lists_buffer(int n, int n_tiles, const omfs_raster_buffers* rb) {
-  const size_t blocks = (size_t)cdiv(n, BIN_THREADS), hits = blocks * BIN_WAVES * HITS_PER_WAVE;
+  const size_t blocks = (size_t)bin_blocks(n), hits = blocks * BIN_WAVES * HITS_PER_WAVE;
   const size_t need = hits + blocks * (size_t)(n_tiles + 1);
   return need <= (size_t)rb->dup_capacity ? reinterpret_cast<uint2*>(rb->keys_tmp) + hits : nullptr;
 }
@@ -776,7 +787,7 @@ extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, c
   if (lds <= BIN_LDS_LIMIT) {
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = ensure_max_lds((const void*)bin_count_kernel, 159 * 1024, attr_done)) return rc;   // + a static word
-    hipLaunchKernelGGL(bin_count_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles, rb->tile_count,
+    hipLaunchKernelGGL(bin_count_kernel, dim3(bin_blocks(g->n)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles, rb->tile_count,
                        hits_buffer(g->n, rb), lists_buffer(g->n, n_tiles, rb), rb->n_visible, rb->status, hits_stamp(g, cam));
   } else {
     hipLaunchKernelGGL(bin_count_direct_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, ps, gx, rb->tile_count, rb->n_visible);
@@ -809,7 +820,7 @@ extern "C" int omfs_bin_scatter(const omfs_gaussians* g, const omfs_camera* cam,
   if (lds <= BIN_LDS_LIMIT) {
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = ensure_max_lds((const void*)bin_scatter_kernel, 160 * 1024, attr_done)) return rc;
-    hipLaunchKernelGGL(bin_scatter_kernel, dim3(cdiv(g->n, BIN_THREADS)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles,
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(bin_blocks(g->n)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles,
                        rb->tile_start, rb->tile_cursor, (uint2*)rb->keys, hits_buffer(g->n, rb), lists_buffer(g->n, n_tiles, rb), rb->status,
                        hits_stamp(g, cam));
   } else {
