@@ -402,3 +402,38 @@ def test_scatter_recomputes_the_tile_test_when_the_recorded_ballots_are_not_its_
     L.check(lib.omfs_tile_sort(ccam, rast.rb, s), "omfs_tile_sort")
     torch.cuda.synchronize()
     assert torch.equal(rast.sorted_ids[:D], ids)
+
+
+@pytest.mark.parametrize("clustered", [False, True])
+def test_tile_sort_at_the_boundaries_of_its_length_classes(clustered):
+    """omfs_tile_sort alone on hand-made lists: one launch serves every length -- up to 4096 pairs by the first 512 threads of a
+    workgroup (the other waves end at once), up to 7936 by all 1024 with the bucket-ordered copy in LDS, longer ones through
+    keys_tmp; `clustered` packs many equal depth bits into each list (the counting-pass fallback + the tie rule: equal depths
+    by ascending Gaussian id).  Every list must come out as numpy's lexsort of (id, depth bits)."""
+    from omfs_4d_video_gen_amd import _lib as L
+    from omfs_4d_video_gen_amd.engine.rasterizer import Rasterizer, make_camera_struct
+    lens = [0, 1, 2, 3, 63, 64, 65, 511, 512, 513, 1024, 2048, 2049, 4095, 4096, 4097, 6000, 7935, 7936, 7937, 9001, 0, 700]
+    width, height = 16 * 8, 16 * 3                      # 24 tiles
+    assert len(lens) <= 24
+    lens = lens + [0] * (24 - len(lens))
+    rast = Rasterizer(1000, width, height, dup_capacity=1 << 17)
+    rng = np.random.default_rng(5)
+    ts = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    D = int(ts[-1])
+    depth = rng.random(D, dtype=np.float32) * 5 + 0.2
+    if clustered:
+        depth = np.round(depth * 3) / 3                  # ~15 distinct depths per list: buckets overflow, ties everywhere
+    ids = np.concatenate([rng.permutation(1 << 16)[:n] for n in lens]).astype(np.uint32)
+    keys = np.stack([depth.view(np.uint32), ids], 1)
+    rast.keys[:D].copy_(torch.from_numpy(keys.view(np.int32)))
+    rast.tile_start.copy_(torch.from_numpy(ts))
+    order = np.argsort(-np.asarray(lens), kind="stable").astype(np.int32)       # heavy first, as the scan leaves it
+    rast.tile_order.copy_(torch.from_numpy(order))
+    cam = make_camera_struct(synthetic.make_camera(width, height))
+    L.check(L.load().omfs_tile_sort(cam, rast.rb, L.stream_ptr()), "omfs_tile_sort")
+    torch.cuda.synchronize()
+    got = rast.sorted_ids[:D].cpu().numpy().view(np.uint32)
+    for t, n in enumerate(lens):
+        a, b = int(ts[t]), int(ts[t + 1])
+        want = ids[a:b][np.lexsort((ids[a:b], depth[a:b].view(np.uint32)))]
+        assert np.array_equal(got[a:b], want), (t, n)
