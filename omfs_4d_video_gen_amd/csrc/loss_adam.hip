@@ -162,7 +162,12 @@ __device__ __forceinline__ float ssim_fwd_strip(const float* __restrict__ ip, co
   return contrib;
 }
 
-__global__ __launch_bounds__(64) void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+#ifdef OMFS_SSIM_WPE
+#define OMFS_SSIM_ATTR __attribute__((amdgpu_waves_per_eu(OMFS_SSIM_WPE, 8)))
+#else
+#define OMFS_SSIM_ATTR
+#endif
+__global__ __launch_bounds__(64) OMFS_SSIM_ATTR void ssim_fwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                       int width, int height, float w_l1, float w_ssim, GaussW gw,
                                                       float* __restrict__ map_mu1, float* __restrict__ map_xx,
                                                       float* __restrict__ map_xy, float* __restrict__ partials) {
@@ -279,7 +284,7 @@ __device__ __forceinline__ void ssim_bwd_strip(const float* __restrict__ ip, con
   }
 }
 
-__global__ __launch_bounds__(64) void ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
+__global__ __launch_bounds__(64) OMFS_SSIM_ATTR void ssim_bwd_kernel(const float* __restrict__ img, const float* __restrict__ gt,
                                                       int width, int height, float w_l1, float w_ssim, GaussW gw,
                                                       const float* __restrict__ map_mu1, const float* __restrict__ map_xx,
                                                       const float* __restrict__ map_xy, float* __restrict__ dimage,
