@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--views", type=int, default=16)
     ap.add_argument("--render_frames", type=int, default=300)
+    ap.add_argument("--render_streams", type=int, default=3, help="HIP streams the render aux deals its frames to (engine/render.py: 3)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_aux", action="store_true")
     ap.add_argument("--profile_steps", type=int, default=40)
@@ -365,14 +366,15 @@ def main():
     if not args.no_aux:
         # config 3: a render_frames-timestep FLAME sequence (every frame its own pose), cameras cycling over the arc
         seq_r = synthetic.make_flame_sequence(args.render_frames, 0)
-        rr = Renderer(rig, seq_r, g_init, W, H, coherent_order=args.coherent_order)
+        # as engine/render.py does: consecutive frames go to three HIP streams with raster buffers of their own (independent frames)
+        rr = Renderer(rig, seq_r, g_init, W, H, coherent_order=args.coherent_order, n_streams=args.render_streams)
         frames = [View(cams[i % len(cams)], timestep=i) for i in range(rank, args.render_frames, world)]
-        for v in frames[:5]:
-            rr.render(v, rgb8=True)
+        for v in frames[:2 * args.render_streams + 2]:
+            rr.render_async(v, rgb8=True)
         torch.cuda.synchronize(); barrier()
         t1 = time.perf_counter()
         for v in frames:
-            rr.render(v, rgb8=True)
+            rr.render_async(v, rgb8=True)
         torch.cuda.synchronize(); barrier()
         dtr = time.perf_counter() - t1
         if world > 1:
@@ -383,7 +385,9 @@ def main():
         log("render aux done")
         out["aux"] = {"render_surgery_fps": round(args.render_frames / dtr, 2),
                       "render_note": f"{args.render_frames} frames of a {args.render_frames}-timestep FLAME sequence, {W}x{H}, {N} Gaussians, "
-                                     f"FLAME posed {rr.flame_batch} timesteps per pass, GPU-resident rgb8 output, PNG encode excluded"}
+                                     f"FLAME posed {rr.flame_batch} timesteps per pass, frames dealt to {rr.n_streams} HIP streams, "
+                                     f"GPU-resident rgb8 output, PNG encode excluded"}
+        rr.check_status()
         if world == 1:
             # the same loop with the PNG egress render.py uses: scanlines + deflate ON THE DEVICE (omfs_png_deflate), the zlib stream
             # fetched by encoder threads that add the PNG framing and the chunk CRC; bounded sample

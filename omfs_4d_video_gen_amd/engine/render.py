@@ -102,7 +102,8 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     (out_dir / "renders").mkdir(parents=True, exist_ok=True)
     (out_dir / "gt").mkdir(parents=True, exist_ok=True)
     flame = tuned_flame(Path(args.model_path) / "point_cloud" / f"iteration_{it}", split["flame"])
-    r = Renderer(load_rig(), flame, g, w, h, bg=bg, sh_degree=args.sh_degree)
+    # the frames of a sequence are independent: three streams with raster buffers of their own (see Renderer)
+    r = Renderer(load_rig(), flame, g, w, h, bg=bg, sh_degree=args.sh_degree, n_streams=int(os.environ.get("OMFS_RENDER_STREAMS", "3")))
     pool = ThreadPoolExecutor(max_workers=max(1, args.png_workers))
     pending, pending_gt = [], []
     mine = range(rank, len(cams), world)
@@ -128,7 +129,7 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     for f in pending + pending_gt:
         f.result()
     pool.shutdown()
-    r.rast.check_status()
+    r.check_status()
     return len(mine)
 
 

@@ -562,7 +562,11 @@ class Renderer:
 
     def __init__(self, rig: FlameRig, flame_params: dict, gaussians: dict, width: int, height: int,
                  bg=(0.0, 0.0, 0.0), device="cuda", sh_degree: int = 3, dup_capacity: int | None = None,
-                 flame_batch: int = 16, coherent_order: bool = False):
+                 flame_batch: int = 16, coherent_order: bool = False, n_streams: int = 1):
+        """n_streams > 1: `render_async` / `render_png_stream` deal consecutive frames to that many HIP streams, each with
+        raster buffers of its own -- the frames of a sequence are independent, so the latency-bound kernels of one frame
+        (binning chain, the deep forward's tail) run under the instruction-bound ones of its neighbours (2303 -> 2840 -> 3053
+        frames/s with 1 / 2 / 3 streams at 1080p, 300 k Gaussians).  `render` stays on the caller's stream with the first set."""
         self.device = torch.device(device)
         self.dflame = DeviceFlame(rig, flame_params, device=device)
         order = None
@@ -570,8 +574,14 @@ class Renderer:
             from .gaussians import coherent_order as _order
             order = _order(gaussians["binding"], rig.v_template[rig.faces].mean(1))
         self.model = GaussianModel(gaussians, device=device, order=order)
-        self.rast = Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity)
-        self.rast.rb.flags = L.RB_FORWARD_ONLY     # no backward pass follows: the forward skips the segment checkpoints
+        self.n_streams = max(1, int(n_streams))
+        self.rasts = [Rasterizer(self.model.n, width, height, device=device, dup_capacity=dup_capacity) for _ in range(self.n_streams)]
+        for r in self.rasts:
+            r.rb.flags = L.RB_FORWARD_ONLY     # no backward pass follows: the forward skips the segment checkpoints
+        self.rast = self.rasts[0]
+        self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_streams)] if self.n_streams > 1 else []
+        self._slot_done = [None] * self.n_streams      # event behind the last frame of each stream
+        self._next_slot = 0
         self.bg, self.sh_degree = tuple(bg), sh_degree
         self.timer = StageTimer(False)
         self._cams = {}
@@ -598,8 +608,23 @@ class Renderer:
         """Enqueue one frame and its DEVICE-side PNG deflate (`Rasterizer.to_png_stream`) into slot k of a ring of n_slots
         stream buffers.  Returns (k, event): once the event has fired, `fetch_png_stream(k, event)` -- any thread -- brings the
         zlib stream to the host.  The slot is reused after n_slots further calls."""
+        if self.n_streams > 1:
+            return self._render_png_stream_pipelined(view, n_slots)
         self.render(view)
         r = self.rast
+        return self._png_stream_of_frame(r, n_slots)
+
+    def _render_png_stream_pipelined(self, view: View, n_slots: int):
+        slot, stream = self._begin_async(view)
+        with torch.cuda.stream(stream):
+            r = self.rasts[slot]
+            self._enqueue_frame(view, r)
+            out = self._png_stream_of_frame(r, n_slots)
+            self._end_async(slot)
+        return out
+
+    def _png_stream_of_frame(self, r, n_slots: int):
+        """Device deflate of the frame in `r` into the next ring slot + its speculative copy to the host (current stream)."""
         if getattr(self, "_png_ring", None) is None or len(self._png_ring) != n_slots:
             r.to_png_stream()                              # sizes the scratch buffers
             cap = r.png_stream_capacity
@@ -653,21 +678,88 @@ class Renderer:
         return self._png_host_mv[k][16:16 + n]
 
     def render(self, view: View, rgb8: bool = False):
-        """Enqueue one frame; returns the reused image tensor ([3][H][W] fp32 or [H][W][3] uint8)."""
+        """Enqueue one frame on the current stream; returns the reused image tensor ([3][H][W] fp32 or [H][W][3] uint8)."""
+        if self.n_streams > 1 and any(e is not None for e in self._slot_done):
+            for e in self._slot_done:                      # frames of render_async still in flight share the posed FLAME batch
+                if e is not None:
+                    torch.cuda.current_stream().wait_event(e)
+        self._enqueue_frame(view, self.rast)
+        return self.rast.to_rgb8() if rgb8 else self.rast.image
+
+    def render_async(self, view: View, rgb8: bool = True):
+        """Enqueue one frame on the next of the renderer's streams (n_streams > 1).  Returns (tensor, event): the tensor -- that
+        stream's own output buffer -- is valid once the event has fired and until the n_streams-th next call."""
+        if self.n_streams == 1:
+            out = self.render(view, rgb8)
+            ev = torch.cuda.Event(); ev.record()
+            return out, ev
+        slot, stream = self._begin_async(view)
+        with torch.cuda.stream(stream):
+            r = self.rasts[slot]
+            self._enqueue_frame(view, r)
+            out = r.to_rgb8() if rgb8 else r.image
+            ev = self._end_async(slot)
+        return out, ev
+
+    def _begin_async(self, view: View):
+        slot = self._next_slot
+        self._next_slot = (slot + 1) % self.n_streams
+        stream = self._streams[slot]
+        t = view.timestep
+        fr = self._frames
+        if fr is None or not (fr[0] <= t < fr[0] + fr[1]):
+            # the next FLAME batch is posed on this frame's stream, once every stream has finished with the previous batch's
+            # triangle frames (the buffers are reused); the other streams wait for the event recorded behind the pose
+            for e in self._slot_done:
+                if e is not None:
+                    stream.wait_event(e)
+            with torch.cuda.stream(stream):
+                self._pose_batch(t)
+        elif fr[3] is not None:
+            stream.wait_event(fr[3])
+        return slot, stream
+
+    def _end_async(self, slot: int):
+        ev = torch.cuda.Event()
+        ev.record()
+        self._slot_done[slot] = ev
+        return ev
+
+    def synchronize(self):
+        """Host sync: every stream of the renderer has drained."""
+        for st in self._streams:
+            st.synchronize()
+        torch.cuda.current_stream().synchronize()
+
+    def check_status(self):
+        for r in self.rasts:
+            r.check_status()
+
+    def _pose_batch(self, t: int):
+        nb = max(1, min(self.flame_batch, self.dflame.n_frames - t))
+        fxf = self.dflame.face_frames(t, nb)[1]
+        ev = None
+        if self.n_streams > 1:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._frames = (t, nb, fxf, ev)
+        return self._frames
+
+    def _enqueue_frame(self, view: View, r):
+        """Project, bin, sort and composite one frame into the raster buffers `r` on the current stream."""
         key = id(view)
         cam = self._cams.get(key)
         if cam is None:
             cam = make_camera_struct(view.camera, sh_degree=self.sh_degree, bg=self.bg)
             self._cams[key] = cam
-        r, tm = self.rast, self.timer
+        tm = self.timer
         tm.begin()
         # a sequence is rendered in order: FLAME is posed for `flame_batch` consecutive timesteps at once (the pass reads
         # the whole basis whatever the batch), later frames of the batch find their triangle frames ready
         t = view.timestep
         fr = self._frames
         if fr is None or not (fr[0] <= t < fr[0] + fr[1]):
-            nb = max(1, min(self.flame_batch, self.dflame.n_frames - t))
-            fr = self._frames = (t, nb, self.dflame.face_frames(t, nb)[1])
+            fr = self._pose_batch(t)
         fxf = fr[2][t - fr[0]]
         tm.mark("flame")
         lib = L.load()
@@ -679,7 +771,3 @@ class Renderer:
         L.check(lib.omfs_bin_scatter(g, cam, r.rb, s), "omfs_bin_scatter"); tm.mark("bin_scatter")
         L.check(lib.omfs_tile_sort(cam, r.rb, s), "omfs_tile_sort"); tm.mark("tile_sort")
         r.composite(cam); tm.mark("composite_fwd")
-        if rgb8:
-            out = r.to_rgb8(); tm.mark("rgb8")
-            return out
-        return r.image

@@ -231,9 +231,12 @@ def test_device_png_deflate_decodes_to_the_frame(width, height):
             assert n < rows.size * 1.08, (name, n)                                 # fixed Huffman: at most 9 bits per byte
 
 
-def test_renderer_png_ring_delivers_every_frame():
+@pytest.mark.parametrize("n_streams", [1, 3])
+def test_renderer_png_ring_delivers_every_frame(n_streams):
     """Renderer.render_png_stream / fetch_png_stream: frames in flight in a ring, fetched by worker threads on their own copy
-    streams, decode to the frames rendered one by one."""
+    streams, decode to the frames rendered one by one -- also when consecutive frames are dealt to three HIP streams with raster
+    buffers of their own (FLAME batches of 5 timesteps: posed on one stream, awaited by the others, reposed only when every
+    stream has finished with the previous batch), and `render_async` hands out the same frames."""
     import io
     from concurrent.futures import ThreadPoolExecutor
     from PIL import Image
@@ -244,9 +247,20 @@ def test_renderer_png_ring_delivers_every_frame():
     seq = synthetic.make_flame_sequence(12, 0)
     g = synthetic.make_gaussians(6000, rig.faces.shape[0], 0)
     W, Hh = 200, 152
-    r = Renderer(FlameRig.from_synthetic(rig), seq, g, W, Hh, bg=(1.0, 1.0, 1.0))
+    r = Renderer(FlameRig.from_synthetic(rig), seq, g, W, Hh, bg=(1.0, 1.0, 1.0), n_streams=n_streams, flame_batch=5)
     views = [View(synthetic.make_camera(W, Hh, yaw=0.1 * i - 0.5), i) for i in range(12)]
     want = [r.render(v, rgb8=True).cpu().numpy().copy() for v in views]
+    pending = []
+    for v in views:                                    # the asynchronous form: a frame is valid from its event until its stream's next use
+        if len(pending) >= n_streams:
+            t, out, ev = pending.pop(0)
+            ev.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want[t]), t
+        pending.append((v.timestep,) + tuple(r.render_async(v, rgb8=True)))
+    for t, out, ev in pending:
+        ev.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want[t]), t
+
     def decode(k, ev):
         return np.asarray(Image.open(io.BytesIO(IO.png_from_zlib_stream(r.fetch_png_stream(k, ev), W, Hh))).convert("RGB"))
 
