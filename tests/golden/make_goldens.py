@@ -11,7 +11,15 @@ What is captured: outputs of the reference's own pure functions
     argv / save-iteration rule / manifest schema of train()
   * 02_Visual_Engine/flame_fitter.py   : SimpleFLAME._axis_angle_to_matrix, SimpleFLAME.forward,
     estimate_head_pose_from_landmarks, 1-, 3- and default-length (200) fit_flame_to_landmarks on the synthetic rig
+  * 02_Visual_Engine/validation_reporting.py : psnr, ssim_global, _bucket, generate_report (strict_scores.json, checklist, refusals)
+  * 02_Visual_Engine/head_recon/*.py   : the four scaffold outputs on a 4-directory capture root, refusals, coverage CLI
+  * 02_Visual_Engine/render_surgery.py : render_with_gaussians with the child process stubbed (argv, stale-render clearing,
+    iteration choice, renders-dir discovery, both error messages), stitch_video with ffmpeg stubbed (argv, staging), load_deformation_map
+  * 02_Visual_Engine/single_frame_experiment.py : build_single_frame_dataset (file list, rewritten transforms, batched npz)
+    -- the scenarios of these four live in tests/golden/scenarios.py and are run AGAIN by the tests on the drop-in modules.
 Only DATA is written (npz / json); no reference source text is stored.
+
+  python tests/golden/make_goldens.py [section ...]     # sections: preprocess render_surgery train_ghost flame_fitter surface
 
 flame_fitter imports cv2 and mediapipe at module level; neither is used by the functions
 captured here, so two empty placeholder modules are registered before the import.
@@ -320,15 +328,72 @@ def golden_preprocess(out):
     shutil.rmtree(tmp, ignore_errors=True)
 
 
+class _Monkey:
+    """setattr with restore (what pytest's monkeypatch does for the tests that replay the scenarios)."""
+
+    def __init__(self):
+        self.undo = []
+
+    def __call__(self, obj, name, value):
+        self.undo.append((obj, name, getattr(obj, name)))
+        setattr(obj, name, value)
+
+    def restore(self):
+        for obj, name, old in reversed(self.undo):
+            setattr(obj, name, old)
+        self.undo.clear()
+
+
+def golden_surface(out):
+    """The rest of the importable call surface (Missing 1), through the shared scenario drivers."""
+    sys.path.insert(0, str(HERE))
+    import scenarios as SC
+    vr = importlib.import_module("validation_reporting")
+    rs = importlib.import_module("render_surgery")
+    sfe = importlib.import_module("single_frame_experiment")
+    hr = {n: importlib.import_module(f"head_recon.{n}") for n in ("ingest_sequences", "register_sequences", "build_canonical_head", "eval_head_coverage")}
+    for m in (vr, rs, sfe, *hr.values()):
+        assert str(REF) in os.path.abspath(m.__file__), m.__file__       # the REFERENCE's modules, not the drop-ins
+    tmp = Path(tempfile.mkdtemp())
+    monkey = _Monkey()
+    try:
+        surf = {"validation_metrics": SC.validation_metrics(vr), "validation_report": SC.validation_report(vr, tmp / "vr")}
+        (tmp / "hr").mkdir()
+        surf["head_recon"] = SC.head_recon(hr["ingest_sequences"], hr["register_sequences"], hr["build_canonical_head"], hr["eval_head_coverage"], tmp / "hr")
+        (tmp / "launch").mkdir()
+        surf["render_launch"] = SC.render_launch(rs, tmp / "launch", monkey)
+        monkey.restore()
+        (tmp / "stitch").mkdir()
+        surf["stitch_video"] = SC.stitch(rs, tmp / "stitch", monkey)
+        monkey.restore()
+        (tmp / "dmap").mkdir()
+        surf["load_deformation_map"] = SC.deformation_map(rs, tmp / "dmap")
+
+        def build(src, dst):
+            monkey(sfe, "DATA_CONDA", src)
+            monkey(sfe, "DATA_SINGLE", dst)
+            return sfe.build_single_frame_dataset()
+        (tmp / "sf").mkdir()
+        surf["single_frame_dataset"] = SC.single_frame_dataset(build, make_fixture_dataset, tmp / "sf")
+    finally:
+        monkey.restore()
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["surface"] = surf
+
+
+SECTIONS = {"preprocess": golden_preprocess, "render_surgery": golden_render_surgery, "train_ghost": golden_train_ghost,
+            "flame_fitter": golden_flame_fitter, "surface": golden_surface}
+
+
 def main():
-    out = {}
-    golden_preprocess(out)
-    golden_render_surgery(out)
-    golden_train_ghost(out)
-    golden_flame_fitter(out)
-    with open(HERE / "reference_goldens.json", "w") as f:
+    target = HERE / "reference_goldens.json"
+    wanted = sys.argv[1:] or list(SECTIONS)
+    out = json.loads(target.read_text()) if target.exists() and sys.argv[1:] else {}
+    for name in wanted:
+        SECTIONS[name](out)
+    with open(target, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    print("goldens written to", HERE)
+    print("goldens written to", HERE, "sections:", wanted)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,390 @@
+"""Scenario drivers shared by `make_goldens.py` (which hands them the REFERENCE's modules, imported from
+/root/reference in the build container) and `tests/test_reference_goldens.py` (which hands them this
+repo's drop-in modules): the same seeded inputs, the same stubs for the child processes, the same
+normalisation of temporary paths -- so a golden is "what the reference did in this scenario" and the test
+is "the drop-in does the same".  Test infrastructure only; nothing here reads /root/reference.
+
+Every driver returns JSON-serialisable data (floats as Python floats: json round-trips them exactly).
+"""
+from __future__ import annotations
+
+import io
+import json
+import os
+import struct
+import subprocess
+import sys
+import zlib
+from contextlib import redirect_stdout
+from pathlib import Path
+
+import numpy as np
+
+
+# ------------------------------------------------------------------ small helpers
+def _png_bytes(img: np.ndarray) -> bytes:
+    """8-bit gray / RGB / RGBA PNG without any imaging dependency (filter 0, zlib level 6): byte-stable."""
+    a = np.ascontiguousarray(img, np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    h, w, c = a.shape
+    raw = np.zeros((h, 1 + w * c), np.uint8)
+    raw[:, 1:] = a.reshape(h, w * c)
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, {1: 0, 3: 2, 4: 6}[c], 0, 0, 0))
+            + chunk(b"IDAT", zlib.compress(raw.tobytes(), 6)) + chunk(b"IEND", b""))
+
+
+def put_png(path: Path, img: np.ndarray) -> None:
+    Path(path).write_bytes(_png_bytes(img))
+
+
+def _norm(text: str, subs: dict) -> str:
+    """Replace temporary paths by stable tokens, longest path first."""
+    for real in sorted(subs, key=len, reverse=True):
+        text = text.replace(real, subs[real])
+    return text
+
+
+def _call(fn, *a, subs=None, **kw):
+    """Run fn, capture stdout and the exception (type + message), normalise paths."""
+    subs = subs or {}
+    buf = io.StringIO()
+    rec = {}
+    try:
+        with redirect_stdout(buf):
+            rec["returned"] = fn(*a, **kw)
+    except Exception as e:  # noqa: BLE001 -- the exception IS the datum
+        rec["raised"] = [type(e).__name__, _norm(str(e), subs)]
+    rec["stdout"] = [_norm(l, subs) for l in buf.getvalue().splitlines()]
+    return rec
+
+
+def _tree(root: Path) -> list:
+    root = Path(root)
+    if not root.exists():
+        return []
+    return sorted(str(p.relative_to(root)) + ("/" if p.is_dir() else "") for p in root.rglob("*"))
+
+
+# ------------------------------------------------------------------ validation_reporting (reference validation_reporting.py:16-123)
+def validation_metrics(vr) -> dict:
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 256, (14, 11, 3)).astype(np.float32)
+    noisy = np.clip(a + rng.normal(0, 9, a.shape), 0, 255).astype(np.float32)
+    grey = np.full((14, 11, 3), 128.0, np.float32)
+    grey2 = np.full((14, 11, 3), 131.0, np.float32)
+    a2d, n2d = a[:, :, 0].copy(), noisy[:, :, 1].copy()
+    u8a, u8b = a.astype(np.uint8), noisy.astype(np.uint8)             # uint8 inputs wrap in (a - b): captured as the reference does it
+    pairs = {"identical": (a, a), "noisy": (a, noisy), "grey_equal": (grey, grey), "grey_offset": (grey, grey2),
+             "two_dim": (a2d, n2d), "inverted": (a, 255.0 - a), "float64": (a.astype(np.float64), noisy.astype(np.float64)),
+             "uint8": (u8a, u8b), "black_white": (np.zeros((6, 5, 3), np.float32), np.full((6, 5, 3), 255.0, np.float32))}
+    out = {"psnr": {}, "ssim_global": {}}
+    for name, (x, y) in pairs.items():
+        out["psnr"][name] = vr.psnr(x, y)
+        out["ssim_global"][name] = vr.ssim_global(x, y)
+    grid = [-0.1, 0.0, 0.1, 0.19999, 0.2, 0.20001, 0.3, 0.34999, 0.35, 0.5, 0.65, 0.65001, 0.7, 0.79999, 0.8, 0.80001, 1.0, 1.5]
+    out["bucket"] = [[p, vr._bucket(p)] for p in grid]
+    return out
+
+
+def make_report_tree(root: Path) -> dict:
+    """<root>/model/train/ours_{7,30,100}/{renders,gt} + <root>/det/deterministic_indices_manifest.json; byte-stable."""
+    rng = np.random.default_rng(123)
+    model, det = root / "model", root / "det"
+    for it in (7, 30, 100):
+        for sub in ("renders", "gt"):
+            (model / "train" / f"ours_{it}" / sub).mkdir(parents=True, exist_ok=True)
+    (model / "train" / "not_ours_999").mkdir()
+    (model / "train" / "ours_note.txt").write_text("a file, not a run directory")
+    names = [f"{i:05d}.png" for i in range(12)]
+    for i, name in enumerate(names):
+        gt = rng.integers(0, 256, (10, 12, 3)).astype(np.uint8)
+        rd = np.clip(gt.astype(np.int32) + rng.integers(-20, 21, gt.shape), 0, 255).astype(np.uint8)
+        if i == 2:
+            rd = gt.copy()                                             # identical pair: PSNR 99
+        if i == 4:                                                     # RGBA render, gray ground truth
+            rd = np.concatenate([rd, np.full((10, 12, 1), 77, np.uint8)], 2)
+            gt = gt[:, :, 0]
+        for it, shift in ((100, 0), (30, 40)):                         # the older run holds different pixels
+            put_png(model / "train" / f"ours_{it}" / "renders" / name, np.clip(rd.astype(np.int32) + shift, 0, 255).astype(np.uint8))
+            put_png(model / "train" / f"ours_{it}" / "gt" / name, gt)
+    (model / "train" / "ours_100" / "renders" / names[9]).unlink()     # a render that is missing: row skipped
+    (model / "train" / "ours_100" / "gt" / names[10]).unlink()         # a ground truth that is missing: row skipped
+    det.mkdir(parents=True, exist_ok=True)
+    rows = [{"index": i, "source": names[i], "exported": f"idx_{i:05d}.png"} for i in (0, 2, 3, 4, 5, 7, 8, 9, 10, 11)]
+    (det / "deterministic_indices_manifest.json").write_text(json.dumps(
+        {"source_frames_dir": "<renders>", "selected_indices": [r["index"] for r in rows], "exports": rows}, indent=2))
+    return {"model": model, "det": det}
+
+
+def validation_report(vr, tmp: Path) -> dict:
+    tmp = Path(tmp)
+    t = make_report_tree(tmp / "tree")
+    subs = {str(tmp): "<TMP>"}
+    out = {}
+    rec = _call(vr.generate_report, t["model"], t["det"], tmp / "rep", subs=subs)
+    rec.pop("returned", None)
+    out["ok"] = {**rec, "strict_scores": json.loads((tmp / "rep" / "strict_scores.json").read_text()),
+                 "checklist": (tmp / "rep" / "human_review_checklist.md").read_text(), "files": _tree(tmp / "rep")}
+    # an empty export list, and a manifest without the key
+    (tmp / "det_empty").mkdir()
+    (tmp / "det_empty" / "deterministic_indices_manifest.json").write_text(json.dumps({"exports": []}))
+    _call(vr.generate_report, t["model"], tmp / "det_empty", tmp / "rep_empty", subs=subs)
+    out["empty_exports"] = json.loads((tmp / "rep_empty" / "strict_scores.json").read_text())
+    (tmp / "det_one").mkdir()
+    (tmp / "det_one" / "deterministic_indices_manifest.json").write_text(json.dumps(
+        {"exports": [{"index": 0, "source": "00000.png", "exported": "idx_00000.png"}]}))
+    _call(vr.generate_report, t["model"], tmp / "det_one", tmp / "rep_one", subs=subs)
+    out["single_row_index0"] = json.loads((tmp / "rep_one" / "strict_scores.json").read_text())
+    # the four refusals
+    errs = {}
+    errs["no_train_dir"] = _call(vr.generate_report, tmp / "nowhere", t["det"], tmp / "r1", subs=subs)
+    (tmp / "bare" / "train" / "other").mkdir(parents=True)
+    errs["no_ours_dirs"] = _call(vr.generate_report, tmp / "bare", t["det"], tmp / "r2", subs=subs)
+    (tmp / "nogt" / "train" / "ours_5" / "renders").mkdir(parents=True)
+    errs["no_gt"] = _call(vr.generate_report, tmp / "nogt", t["det"], tmp / "r3", subs=subs)
+    (tmp / "det_missing").mkdir()
+    errs["no_manifest"] = _call(vr.generate_report, t["model"], tmp / "det_missing", tmp / "r4", subs=subs)
+    for v in errs.values():
+        v.pop("returned", None)
+    out["errors"] = errs
+    return out
+
+
+# ------------------------------------------------------------------ head_recon (reference head_recon/*.py)
+def make_capture_root(root: Path) -> Path:
+    cap = root / "captures"
+    layout = {"seq_b_front": (["0.png", "1.PNG", "2.jpg", "3.JPG", "notes.txt", "4.jpeg"], True),
+              "seq_a_left": (["a.png", "b.png"], False), "seq_c_transforms_only": (None, True), "seq_d_empty": (None, False)}
+    for name, (images, transforms) in layout.items():
+        (cap / name).mkdir(parents=True)
+        if images is not None:
+            (cap / name / "images").mkdir()
+            for f in images:
+                (cap / name / "images" / f).write_bytes(b"x")
+        if transforms:
+            (cap / name / "transforms_train.json").write_text(json.dumps({"frames": [{}] * 3}))
+    (cap / "stray_file.json").write_text("{}")
+    return cap
+
+
+def head_recon(ingest, register, build, coverage, tmp: Path) -> dict:
+    """ingest / register / build / coverage: the four modules (reference's or the drop-in's)."""
+    tmp = Path(tmp)
+    subs = {str(tmp.resolve()): "<TMP>", str(tmp): "<TMP>"}
+    cap = make_capture_root(tmp)
+    out_dir = tmp / "out" / "head_recon"
+    out = {}
+    r = _call(ingest.ingest_sequences, cap, out_dir, subs=subs)
+    r["returned"] = _norm(str(r["returned"]), subs)
+    out["ingest"] = {**r, "manifest_text": _norm((out_dir / "sequence_manifest.json").read_text(), subs)}
+    r = _call(register.register_sequences, out_dir / "sequence_manifest.json", out_dir, subs=subs)
+    r["returned"] = _norm(str(r["returned"]), subs)
+    out["register"] = {**r, "registration_text": _norm((out_dir / "registration.json").read_text(), subs)}
+    r = _call(build.build_canonical_head, out_dir / "registration.json", out_dir, subs=subs)
+    r["returned"] = [_norm(str(p), subs) for p in r["returned"]]
+    asset = np.load(out_dir / "canonical_head_asset.npz")
+    out["build"] = {**r, "manifest_text": _norm((out_dir / "canonical_head_asset_manifest.json").read_text(), subs),
+                    "asset": {k: {"dtype": str(asset[k].dtype), "value": asset[k].tolist()} for k in sorted(asset.files)}}
+    out["files"] = _tree(out_dir)
+    # a registration file without the optional keys
+    (tmp / "reg_bare.json").write_text("{}")
+    r = _call(build.build_canonical_head, tmp / "reg_bare.json", tmp / "out_bare", subs=subs)
+    a2 = np.load(tmp / "out_bare" / "canonical_head_asset.npz")
+    out["build_bare"] = {"asset": {k: a2[k].tolist() for k in sorted(a2.files)},
+                         "manifest_text": _norm((tmp / "out_bare" / "canonical_head_asset_manifest.json").read_text(), subs)}
+    # refusals
+    (tmp / "empty_manifest.json").write_text(json.dumps({"sequences": []}))
+    (tmp / "no_key_manifest.json").write_text("{}")
+    out["register_empty"] = _call(register.register_sequences, tmp / "empty_manifest.json", tmp / "o2", subs=subs)
+    out["register_no_key"] = _call(register.register_sequences, tmp / "no_key_manifest.json", tmp / "o3", subs=subs)
+    out["register_wrote_nothing"] = not (tmp / "o2").exists() and not (tmp / "o3").exists()
+    out["coverage"] = {str(n): coverage.evaluate_head_coverage(n) for n in (-3, 0, 1, 2, 3, 5, 6, 10, 21, 100, 101, 300)}
+    # the coverage CLI
+    (tmp / "cov_transforms.json").write_text(json.dumps({"frames": [{"i": i} for i in range(17)]}))
+    argv = sys.argv
+    sys.argv = ["eval_head_coverage", "--transforms", str(tmp / "cov_transforms.json"), "--output", str(tmp / "cov" / "deep" / "head_coverage.json")]
+    try:
+        r = _call(coverage.main, subs=subs)
+    finally:
+        sys.argv = argv
+    r.pop("returned", None)
+    out["coverage_cli"] = {**r, "text": (tmp / "cov" / "deep" / "head_coverage.json").read_text()}
+    return out
+
+
+# ------------------------------------------------------------------ render_surgery: engine launch, discovery, ffmpeg (reference :58-71, :245-362, :412-449)
+class _Result:
+    def __init__(self, returncode=0, stdout="", stderr=""):
+        self.returncode, self.stdout, self.stderr = returncode, stdout, stderr
+
+
+def _model_dir(root: Path, point_clouds, stale) -> Path:
+    model = root / "model"
+    model.mkdir(parents=True)
+    for name in point_clouds:
+        (model / "point_cloud" / name).mkdir(parents=True)
+    for it, sub in stale:
+        (model / "train" / f"ours_{it}" / sub).mkdir(parents=True)
+        put_png(model / "train" / f"ours_{it}" / sub / "00000.png", np.zeros((2, 2, 3), np.uint8))
+    return model
+
+
+def render_launch(rs, tmp: Path, monkey) -> dict:
+    """`monkey(obj, name, value)` sets an attribute for the duration of the scenario (pytest's monkeypatch.setattr or a
+    plain setattr with restore)."""
+    tmp = Path(tmp)
+    engine = tmp / "engine"
+    engine.mkdir()
+    (engine / "render.py").write_text("# placeholder engine entry point\n")
+    monkey(rs, "REPO_DIR", engine)
+    monkey(rs, "RENDER_SCRIPT", engine / "render.py")
+    data = tmp / "data"
+    data.mkdir()
+    out = {}
+    cases = {
+        # name: (iteration, clear_old, point-cloud dirs, stale (iteration, subdir) pairs, what the child writes, child rc)
+        "auto_no_point_clouds": (-1, True, [], [(5, "renders"), (30, "renders"), (99, "gt")], {12: 3}, 0),
+        "auto_with_point_clouds": (-1, True, ["iteration_5", "iteration_30", "iteration_x", "iteration_", "other_40", "iteration_7_b"],
+                                   [(5, "renders"), (40, "renders")], {30: 4}, 0),
+        "zero_means_auto": (0, True, ["iteration_5"], [], {5: 1}, 0),
+        "pinned_7_no_point_clouds": (7, True, [], [(30, "renders")], {7: 2}, 0),
+        "pinned_7_with_point_clouds": (7, True, ["iteration_5", "iteration_30"], [(30, "renders"), (7, "renders")], {7: 2}, 0),
+        "pinned_7_child_wrote_9_and_30": (7, True, ["iteration_30"], [], {9: 2, 30: 5}, 0),
+        "keep_old_renders": (-1, False, ["iteration_5"], [(50, "renders")], {5: 2}, 0),
+        "child_wrote_nothing": (-1, True, ["iteration_5"], [(50, "renders")], {}, 0),
+        "no_train_dir_at_all": (3, True, [], [], {}, 0),
+        "child_failed": (-1, True, ["iteration_5"], [(50, "renders")], {}, 2),
+    }
+    for name, (iteration, clear_old, pcs, stale, writes, rc) in cases.items():
+        root = tmp / name
+        model = _model_dir(root, pcs, stale)
+        subs = {str(model.resolve()): "<MODEL>", str(model): "<MODEL>", str(data.resolve()): "<DATA>", str(data): "<DATA>",
+                str(engine): "<ENGINE>", str(tmp): "<TMP>", sys.executable: "<PYTHON>"}
+        seen = {}
+
+        def fake_run(cmd, _model=model, _writes=writes, _rc=rc, _seen=seen, **kw):
+            _seen["argv"] = ["<PYTHON>" if c == sys.executable else c for c in cmd]
+            _seen["kw"] = {"cwd": kw.get("cwd"), "pythonpath_head": kw.get("env", {}).get("PYTHONPATH", "").split(os.pathsep)[0],
+                           "capture_output": kw.get("capture_output"), "text": kw.get("text"), "other": sorted(set(kw) - {"cwd", "env", "capture_output", "text"})}
+            _seen["train_tree_at_launch"] = _tree(_model / "train")
+            for it, n in _writes.items():
+                d = _model / "train" / f"ours_{it}" / "renders"
+                d.mkdir(parents=True, exist_ok=True)
+                for i in range(n):
+                    put_png(d / f"{i:05d}.png", np.zeros((2, 2, 3), np.uint8))
+                (d / "not_a_frame.txt").write_text("x")
+            return _Result(_rc, stdout="o" * 2500 + "<stdout tail>", stderr="e" * 2500 + "<stderr tail>")
+        monkey(subprocess, "run", fake_run)
+        rec = _call(rs.render_with_gaussians, str(model), str(data), iteration=iteration, clear_old_renders=clear_old, subs=subs)
+        if "returned" in rec:
+            rec["returned"] = _norm(rec["returned"], subs)
+        seen["argv"] = [_norm(c, subs) for c in seen.get("argv", [])]
+        if "kw" in seen:
+            seen["kw"]["cwd"] = _norm(str(seen["kw"]["cwd"]), subs)
+            seen["kw"]["pythonpath_head"] = _norm(seen["kw"]["pythonpath_head"], subs)
+        out[name] = {**rec, "launch": seen, "train_tree_after": _tree(model / "train")}
+    # the launcher refuses to start without the engine's entry point
+    monkey(rs, "RENDER_SCRIPT", engine / "absent.py")
+    out["no_render_script"] = _call(rs.render_with_gaussians, str(tmp / "m"), str(data), subs={str(engine): "<ENGINE>"})
+    monkey(rs, "RENDER_SCRIPT", engine / "render.py")
+    # relative paths are made absolute in the argv
+    model = _model_dir(tmp / "rel", ["iteration_2"], [])
+    seen = {}
+
+    def fake_run_rel(cmd, **kw):
+        seen["argv"] = list(cmd[2:])
+        (model / "train" / "ours_2" / "renders").mkdir(parents=True)
+        return _Result(0)
+    monkey(subprocess, "run", fake_run_rel)
+    cwd = os.getcwd()
+    os.chdir(tmp / "rel")
+    try:
+        rec = _call(rs.render_with_gaussians, "model", "../data", subs={})
+    finally:
+        os.chdir(cwd)
+    subs = {str((tmp / "rel").resolve()): "<CWD>", str(tmp.resolve()): "<TMP>", str(tmp / "rel"): "<CWD>", str(tmp): "<TMP>"}
+    out["relative_paths"] = {"returned": rec.get("returned"), "argv": [_norm(c, subs) for c in seen["argv"]]}
+    return out
+
+
+def stitch(rs, tmp: Path, monkey) -> dict:
+    tmp = Path(tmp)
+    frames = tmp / "frames"
+    frames.mkdir()
+    for name in ("00010.png", "00002.png", "b.png", "00001.PNG", "notes.txt", "a.png"):
+        put_png(frames / name, np.zeros((2, 2, 3), np.uint8))
+    monkey(rs, "_get_ffmpeg_path", lambda: "/opt/fake/ffmpeg")
+    out = {}
+    for name, rc, fps, target in (("ok", 0, 30, tmp / "videos" / "deep" / "out.mp4"), ("fps_24_bare_name", 0, 24, Path("bare.mp4")),
+                                  ("failed", 1, 30, tmp / "v2" / "out.mp4")):
+        seen = {}
+
+        def fake_run(cmd, _seen=seen, _rc=rc, **kw):
+            staging = os.path.dirname(cmd[cmd.index("-i") + 1])
+            _seen["staging_listing"] = sorted(os.listdir(staging))
+            _seen["staging_prefix"] = os.path.basename(staging)[:7]
+            _seen["staging"] = staging
+            _seen["argv"] = [c.replace(staging, "<STAGING>") for c in cmd]
+            _seen["kw"] = {k: kw[k] for k in sorted(kw)}
+            return _Result(_rc, stderr="ffmpeg says no")
+        monkey(subprocess, "run", fake_run)
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            rec = _call(rs.stitch_video, str(frames), str(target), fps=fps, subs={str(tmp): "<TMP>"})
+        finally:
+            os.chdir(cwd)
+        rec.pop("returned", None)
+        seen["argv"] = [_norm(c, {str(tmp): "<TMP>"}) for c in seen["argv"]]
+        seen["staging_removed"] = not os.path.exists(seen.pop("staging"))
+        out[name] = {**rec, "launch": seen, "parent_created": target.parent.exists() if target.is_absolute() else None}
+    (tmp / "empty").mkdir()
+    (tmp / "empty" / "x.txt").write_text("x")
+    monkey(subprocess, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("ffmpeg must not be launched")))
+    out["no_frames"] = _call(rs.stitch_video, str(tmp / "empty"), str(tmp / "v3" / "o.mp4"), subs={str(tmp): "<TMP>"})
+    out["no_frames"]["parent_created_before_refusal"] = (tmp / "v3").exists()
+    return out
+
+
+def deformation_map(rs, tmp: Path) -> dict:
+    tmp = Path(tmp)
+    subs = {str(tmp): "<TMP>"}
+    (tmp / "list.json").write_text("[1, 2]")
+    (tmp / "scalar.json").write_text("3")
+    (tmp / "ok.json").write_text(json.dumps({"jaw_axis": 2, "lefort_scale": 1.5, "extra": [1]}))
+    (tmp / "broken.json").write_text("{not json")
+    out = {"none": _call(rs.load_deformation_map, None), "empty": _call(rs.load_deformation_map, ""),
+           "missing": _call(rs.load_deformation_map, str(tmp / "absent.json"), subs=subs),
+           "list": _call(rs.load_deformation_map, str(tmp / "list.json"), subs=subs),
+           "scalar": _call(rs.load_deformation_map, str(tmp / "scalar.json"), subs=subs),
+           "ok": _call(rs.load_deformation_map, str(tmp / "ok.json"), subs=subs)}
+    broken = _call(rs.load_deformation_map, str(tmp / "broken.json"), subs=subs)
+    out["broken_raises"] = broken["raised"][0]
+    return out
+
+
+# ------------------------------------------------------------------ single_frame_experiment.build_single_frame_dataset (reference :32-81)
+def single_frame_dataset(build, make_fixture_dataset, tmp: Path) -> dict:
+    """`build(data_conda, data_single)` builds the one-frame dataset the way the module under test does."""
+    tmp = Path(tmp)
+    src, dst = tmp / "data_conda", tmp / "data_single_frame"
+    make_fixture_dataset(src, n_frames=5, with_masks=True)
+    dst.mkdir()
+    (dst / "left_over_from_last_time.txt").write_text("stale")          # an existing target is wiped first
+    subs = {str(tmp): "<TMP>"}
+    rec = _call(build, src, dst, subs=subs)
+    rec["returned"] = _norm(str(rec["returned"]), subs)
+    out = {**rec, "files": _tree(dst)}
+    for name in ("transforms_train.json", "transforms_test.json", "transforms_val.json"):
+        out[name] = (dst / name).read_text()
+    b = np.load(dst / "flame_param.npz")
+    out["batched"] = {k: {"shape": list(b[k].shape), "dtype": str(b[k].dtype),
+                          "equals_frame0": bool(np.array_equal(b[k].reshape(-1), np.load(src / "flame_param" / "00000.npz")[k].reshape(-1)))}
+                      for k in sorted(b.files)}
+    out["copies_are_bytewise"] = {rel: (dst / rel).read_bytes() == (src / rel).read_bytes()
+                                  for rel in ("images/00000_00.png", "flame_param/00000.npz", "fg_masks/00000_00.png", "canonical_flame_param.npz")}
+    return out
