@@ -106,7 +106,9 @@ class Rollback:
         t = self.t
         m, ft = t.model, t.flame_ft
         s = self.s
-        if s is None or s["params"].shape != m.params.shape:
+        # binding is [n], the planes are [59][n_pad] with n_pad = n rounded up to 256: a densification can change n and keep
+        # n_pad (100100 -> 100200 Gaussians are both 100352 columns), so the snapshot is keyed on BOTH shapes
+        if s is None or s["params"].shape != m.params.shape or s["binding"].shape != m.binding.shape:
             s = self.s = {"params": torch.empty_like(m.params), "m": torch.empty_like(t.opt.m), "v": torch.empty_like(t.opt.v),
                           "binding": torch.empty_like(m.binding)}
         s["params"].copy_(m.params); s["m"].copy_(t.opt.m); s["v"].copy_(t.opt.v); s["binding"].copy_(m.binding)
@@ -119,7 +121,8 @@ class Rollback:
     def restore(self) -> int:
         t, s = self.t, self.s
         m, ft = t.model, t.flame_ft
-        if s["params"].shape != m.params.shape:            # a densification lies inside the interval: put the old buffers back
+        if s["params"].shape != m.params.shape or s["binding"].shape != m.binding.shape or s["n"] != m.n:
+            # a densification lies inside the interval (it may have kept n_pad and changed only n): put the old buffers back
             m.params, m.binding, m.n, m.n_pad = s["params"].clone(), s["binding"].clone(), s["n"], int(s["params"].shape[1])
             t.opt.m, t.opt.v = s["m"].clone(), s["v"].clone()
             t.grads = torch.zeros_like(m.params)
@@ -248,7 +251,8 @@ def main(argv=None):
     rollback = Rollback(trainer)
     rollback.take(it0)
 
-    def overflow_anywhere() -> bool:
+    def overflow_anywhere() -> tuple:
+        """(some rank's tile lists overflowed, this rank's did)."""
         # ranks render different views and overflow independently, but a rolled-back interval is redone by ALL of them
         over = trainer.rast.overflowed()
         if world > 1:
@@ -290,6 +294,15 @@ def main(argv=None):
                 print(f"Training progress: iteration {it}/{args.iterations} loss={trainer.loss_value():.5f} "
                       f"({(it - it0) / (time.time() - t0):.1f} it/s)", flush=True)
             # Tile-list capacity: looked at once per log interval (loss_value() above has synced the host already)
+            back = redo_from_snapshot(it)
+            if back >= 0:
+                it = back
+                continue
+            rollback.take(it)
+        if (it in save_at or it in ckpt_at) and not (it % args.log_every == 0 or it == args.iterations):
+            # a save inside a log interval: the interval's overflow check has not run yet, and a file written now would hold
+            # parameters stepped on empty renders if the interval is rolled back later (and stay on disk if the run stops
+            # before the redo reaches this iteration again) -- so the check (and the redo) come first
             back = redo_from_snapshot(it)
             if back >= 0:
                 it = back

@@ -72,6 +72,17 @@ def expon_lr(step, lr_init, lr_final, max_steps, delay_mult=0.01, delay_steps=0)
     return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
+def _cached_camera(cache: dict, camera: dict, sh_degree: int, bg):
+    """omfs_camera struct of a camera dict, built once.  Keyed on the identity of the DICT and holding a reference to it, so
+    the address cannot be handed to another object while the entry lives (a key on id(view) is not safe: callers build a
+    short-lived View per frame and CPython reuses the freed addresses -- the cache then returns another frame's camera)."""
+    key = (id(camera), sh_degree)
+    hit = cache.get(key)
+    if hit is None or hit[0] is not camera:
+        hit = cache[key] = (camera, make_camera_struct(camera, sh_degree=sh_degree, bg=bg))
+    return hit[1]
+
+
 class Trainer:
     def __init__(self, rig: FlameRig, flame_params: dict, gaussians: dict, views: list, width: int, height: int,
                  bg=(0.0, 0.0, 0.0), device="cuda", iterations: int = 30000, lambda_dssim: float = 0.2,
@@ -164,12 +175,7 @@ class Trainer:
                 self._frames_all[t0:t0 + nb].copy_(self.dflame.face_frames(t0, nb)[1])
 
     def _cam(self, view: View, sh_degree: int):
-        key = (id(view), sh_degree)
-        c = self._cams.get(key)
-        if c is None:
-            c = make_camera_struct(view.camera, sh_degree=sh_degree, bg=self.bg)
-            self._cams[key] = c
-        return c
+        return _cached_camera(self._cams, view.camera, sh_degree, self.bg)
 
     def _frame_key(self, step: int):
         from .distributed import view_index
@@ -581,7 +587,10 @@ class Renderer:
         self.rast = self.rasts[0]
         self._streams = [torch.cuda.Stream(device=self.device) for _ in range(self.n_streams)] if self.n_streams > 1 else []
         self._slot_done = [None] * self.n_streams      # event behind the last frame of each stream
+        self._render_done = None                       # event behind the last frame of render() (caller's stream)
         self._next_slot = 0
+        # the raster buffers were zero-filled on the constructor's stream and are used on the side streams: drain it once
+        torch.cuda.current_stream(self.device).synchronize()
         self.bg, self.sh_degree = tuple(bg), sh_degree
         self.timer = StageTimer(False)
         self._cams = {}
@@ -633,10 +642,15 @@ class Renderer:
             self._png_host = [torch.empty(16 + cap, dtype=torch.uint8, pin_memory=True) for _ in range(n_slots)]
             self._png_host_mv = [memoryview(h.numpy()) for h in self._png_host]
             self._png_events = [torch.cuda.Event() for _ in range(n_slots)]
+            self._png_done = [torch.cuda.Event() for _ in range(n_slots)]      # rebuilt WITH the ring (a larger n_slots later)
+            self._png_got = [0] * n_slots
             self._png_next = 0
             self._png_guess = cap // 4
             import threading
             self._png_tls = threading.local()
+            # the ring is zero-filled on THIS stream and its slots are written by deflate launches on the renderer's other
+            # streams: a fill that lands late would wipe a frame's length word -- drain the filling stream once
+            torch.cuda.current_stream(self.device).synchronize()
         k = self._png_next
         self._png_next = (k + 1) % n_slots
         buf = self._png_ring[k]
@@ -646,8 +660,6 @@ class Renderer:
         # (synchronising a stream from many threads contends with this thread's launches inside the HIP runtime)
         if getattr(self, "_png_copy_stream", None) is None:
             self._png_copy_stream = torch.cuda.Stream(device=self.device)
-            self._png_done = [torch.cuda.Event() for _ in range(n_slots)]
-            self._png_got = [0] * n_slots
         self._png_events[k].record()
         got = min(16 + self._png_guess, buf.numel())
         with torch.cuda.stream(self._png_copy_stream):
@@ -684,7 +696,11 @@ class Renderer:
                 if e is not None:
                     torch.cuda.current_stream().wait_event(e)
         self._enqueue_frame(view, self.rast)
-        return self.rast.to_rgb8() if rgb8 else self.rast.image
+        out = self.rast.to_rgb8() if rgb8 else self.rast.image
+        if self.n_streams > 1:          # a later render_async that poses a new FLAME batch must not overwrite the frames this reads
+            self._render_done = torch.cuda.Event()
+            self._render_done.record()
+        return out
 
     def render_async(self, view: View, rgb8: bool = True):
         """Enqueue one frame on the next of the renderer's streams (n_streams > 1).  Returns (tensor, event): the tensor -- that
@@ -710,7 +726,7 @@ class Renderer:
         if fr is None or not (fr[0] <= t < fr[0] + fr[1]):
             # the next FLAME batch is posed on this frame's stream, once every stream has finished with the previous batch's
             # triangle frames (the buffers are reused); the other streams wait for the event recorded behind the pose
-            for e in self._slot_done:
+            for e in (*self._slot_done, self._render_done):
                 if e is not None:
                     stream.wait_event(e)
             with torch.cuda.stream(stream):
@@ -747,11 +763,7 @@ class Renderer:
 
     def _enqueue_frame(self, view: View, r):
         """Project, bin, sort and composite one frame into the raster buffers `r` on the current stream."""
-        key = id(view)
-        cam = self._cams.get(key)
-        if cam is None:
-            cam = make_camera_struct(view.camera, sh_degree=self.sh_degree, bg=self.bg)
-            self._cams[key] = cam
+        cam = _cached_camera(self._cams, view.camera, self.sh_degree, self.bg)
         tm = self.timer
         tm.begin()
         # a sequence is rendered in order: FLAME is posed for `flame_batch` consecutive timesteps at once (the pass reads

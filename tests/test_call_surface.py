@@ -199,3 +199,39 @@ def test_every_engine_module_imports_without_a_gpu():
     for name in ("densify", "distributed", "flame_finetune", "flame_rig", "gaussians", "io_formats", "rasterizer", "render", "rig_loader",
                  "synthetic", "train", "trainer"):
         importlib.import_module(f"omfs_4d_video_gen_amd.engine.{name}")
+
+
+def test_rollback_survives_a_densification_that_keeps_n_pad():
+    """engine/train.py::Rollback (ADVICE r3, high): `binding` is [n] while the planes are [59][n_pad]; a densification can change
+    n and keep n_pad (1000 -> 1010 Gaussians are both 1024 columns).  take() after such a densification, and restore() across
+    one, must work -- on a mock trainer with CPU tensors (the class only moves tensors about)."""
+    from types import SimpleNamespace as NS
+    import torch
+    from omfs_4d_video_gen_amd.engine.train import Rollback
+
+    def cloud(n, n_pad, fill):
+        return NS(params=torch.full((59, n_pad), float(fill)), binding=torch.arange(n, dtype=torch.int32), n=n, n_pad=n_pad, order=None)
+    t = NS(model=cloud(1000, 1024, 1.0), flame_ft=None, densify_stats=torch.zeros(2, 1024), step_idx=7, sh_degree=1,
+           opt=NS(m=torch.zeros(59, 1024), v=torch.zeros(59, 1024), step_count=7), grads=torch.zeros(59, 1024),
+           rast=NS(g2=torch.ones(2048, 4)), _prefetch=None, _frames_ready=None, _state_step=-1, invalidate_graphs=lambda: None)
+    rb = Rollback(t)
+    rb.take(7)
+
+    def densify(n_new, fill):            # what engine/densify.py does to the trainer: new buffers, n_pad kept
+        t.model.params = torch.full((59, 1024), float(fill))
+        t.model.binding = torch.arange(n_new, dtype=torch.int32) % 50
+        t.model.n = n_new
+        t.opt.m, t.opt.v = torch.ones(59, 1024), torch.ones(59, 1024)
+    densify(1010, 2.0)
+    t.step_idx = t.opt.step_count = 20
+    rb.take(20)                          # used to raise: size of tensor a (1000) must match the size of tensor b (1010)
+    assert rb.s["binding"].shape == (1010,) and rb.s["n"] == 1010
+    t.model.params.add_(5.0)
+    t.step_idx = t.opt.step_count = 33
+    assert rb.restore() == 20
+    assert t.model.n == 1010 and float(t.model.params[0, 0]) == 2.0 and t.step_idx == 20 and t.opt.step_count == 20
+    densify(1003, 3.0)                   # a densification INSIDE the interval that is rolled back (same n_pad, other n)
+    assert rb.restore() == 20
+    assert t.model.n == 1010 and t.model.binding.shape == (1010,) and float(t.model.params[0, 0]) == 2.0
+    assert torch.equal(t.model.binding, torch.arange(1010, dtype=torch.int32) % 50) and float(t.opt.m[0, 0]) == 1.0
+    assert t.grads.shape == (59, 1024) and float(t.rast.g2[1010:].abs().sum()) == 0.0

@@ -179,3 +179,60 @@ def test_overflowed_interval_is_rolled_back_and_redone(dataset, tmp_path):
     la = [float(m) for m in re.findall(r"loss=([0-9.]+)", r1.stdout)]
     lb = [float(m) for m in re.findall(r"loss=([0-9.]+)", r2.stdout)]
     assert abs(la[-1] - lb[-1]) < 0.02 * lb[-1]
+
+
+def test_training_with_densification_under_a_small_pair_capacity(dataset, tmp_path):
+    """engine/train.py with adaptive density control ON and a tile-list capacity far too small (no test ran train.py
+    with densification): snapshots are taken after every densification (binding is [n], the planes [59][n_pad]), overflowed
+    intervals are rolled back and redone, a save at an iteration inside a log interval (35) comes after that interval's overflow
+    check, and the run ends with a consistent checkpoint of the grown cloud."""
+    env = {**os.environ, "OMFS_SYNTHETIC_RIG": "1", "PYTHONPATH": str(ROOT)}
+    train = str(ROOT / "omfs_4d_video_gen_amd" / "engine" / "train.py")
+    m = tmp_path / "m"
+    r = subprocess.run([sys.executable, train, "--source_path", str(dataset), "--model_path", str(m), "--bind_to_mesh", "--white_background",
+                        "--n_gaussians", "12000", "--log_every", "10", "--iterations", "60", "--checkpoint_iterations", "60",
+                        "--save_iterations", "35", "--dup_capacity", "3000", "--densify_from_iter", "15", "--densification_interval", "10",
+                        "--densify_until_iter", "1000", "--densify_grad_threshold", "1e-6", "--max_gaussians", "40000"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    assert "are redone" in r.stdout and "densify:" in r.stdout and "iteration 60/60" in r.stdout, r.stdout[-3000:]
+    ck = torch.load(m / "chkpnt60.pth", weights_only=True)
+    n = int(ck["binding"].shape[0])
+    assert n > 12000 and ck["params"].shape == (59, (n + 255) // 256 * 256) and ck["adam_m"].shape == ck["params"].shape
+    assert torch.isfinite(ck["params"][:, :n]).all() and int(ck["binding"].max()) < 10312
+    assert (m / "point_cloud" / "iteration_35" / "point_cloud.ply").exists() and (m / "point_cloud" / "iteration_60" / "point_cloud.ply").exists()
+    # the kept iterations rendered real lists: the loss of the last interval is below the first's
+    losses = [float(x) for x in re.findall(r"loss=([0-9.]+)", r.stdout)]
+    assert np.mean(losses[-2:]) < np.mean(losses[:2]), losses
+
+
+def test_renderer_uses_each_frames_own_camera():
+    """the Renderer cached camera structs under id(view); engine/render.py builds a short-lived View per
+    frame and CPython hands the freed address to the next one, so frames 2.. were rendered with the camera of frame 0 or 1.
+    Six frames from six clearly different cameras through short-lived Views (one stream and three) against a renderer whose
+    Views all stay alive."""
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, View
+    W, H, T = 128, 96, 6
+    rig = synthetic.make_rig(0)
+    frig = FlameRig.from_synthetic(rig)
+    seq = synthetic.make_flame_sequence(T, 3)
+    g = synthetic.make_gaussians(8000, rig.faces.shape[0], 1)
+    cams = [synthetic.make_camera(W, H, yaw=-0.6 + 0.24 * i) for i in range(T)]
+    keep = [View(cams[i], i) for i in range(T)]
+    ref = Renderer(frig, seq, g, W, H)
+    want = [ref.render(keep[i], rgb8=True).cpu().clone() for i in range(T)]
+    assert all(not torch.equal(want[i], want[i + 1]) for i in range(T - 1))
+    for n_streams in (1, 3):
+        r = Renderer(frig, seq, g, W, H, n_streams=n_streams)
+        for i in range(T):
+            img, ev = r.render_async(View(cams[i], i), rgb8=True)       # the View dies at the end of the statement
+            ev.synchronize()
+            assert torch.equal(img.cpu(), want[i]), (n_streams, i)
+        # render() on the caller's stream between asynchronous frames of another FLAME batch
+        r.flame_batch = 2
+        for i in (0, 3, 1, 5):
+            a = r.render(View(cams[i], i), rgb8=True).cpu()
+            b, ev = r.render_async(View(cams[(i + 2) % T], (i + 2) % T), rgb8=True)
+            ev.synchronize()
+            assert torch.equal(a, want[i]) and torch.equal(b.cpu(), want[(i + 2) % T]), (n_streams, i)
