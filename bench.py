@@ -57,7 +57,9 @@ def stage_bytes(N, n_pad, D, P, n_tiles, F, D_visit):
         "tile_sort": D * 8 + D * 4,
         "composite_fwd": D * 4 + D * 36 + P * 12 + P * 8,
         "loss": 3 * P * (8 + 12) + 3 * P * (12 + 8 + 4),
-        "composite_bwd": D_visit * (4 + 36) + D * 40 + P * (12 + 8),
+        # visited entries only: id + 36-byte record gathered, one 40-byte gradient record added per visited entry (float atomics);
+        # entries behind a tile's last contributor are never read.  (Round 1-3 charged the atomics for all D entries.)
+        "composite_bwd": D_visit * (4 + 36) + D_visit * 40 + P * (12 + 8),
         "project_bwd": N * (64 + 240 + 236) + F * 64,
         "adam": 7 * 59 * n_pad * 4,
     }
@@ -129,7 +131,17 @@ def cpu_baseline_train(snap):
         for p in flame_leaves:
             O.adam_step(p, p.grad, torch.zeros_like(p), torch.zeros_like(p), 1, 1e-5)
     dt = time.perf_counter() - t0
-    return dt, int(ts[-1])
+    # the checker's own forward image of that state (C oracle composite with the near-threshold map), NOT part of the timed sample:
+    # bench.py reports the stated per-pixel tolerance as measured on the very step the line describes
+    parity = None
+    if snap.get("gpu_image") is not None:
+        import helpers
+        cimg, cT, cnc, near = CO.composite(proj, ts, ids, w_s, h_s, [0.0, 0.0, 0.0], near=True)
+        ref = {"image": cimg, "final_T": cT, "n_contrib": cnc, "near": near, "proj": proj}
+        st = helpers.image_parity_stats(snap["gpu_image"], snap["gpu_final_T"], snap["gpu_n_contrib"].view(np.uint32), ref)
+        parity = {"stated": helpers.STATED_TOLERANCE, "measured_on_this_step": {k: (round(v, 10) if isinstance(v, float) else v) for k, v in st.items()},
+                  "oracle": "oracle/splat_oracle.c (parity UNPINNED: the reference holds no rasteriser; DESIGN.md section 0)"}
+    return dt, int(ts[-1]), parity
 
 
 _T0 = time.perf_counter()
@@ -239,11 +251,16 @@ def main():
             log("first step done")
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     log("warmup done")
+    # one HIP event per step on the launch stream (K + 1 records, ~1 us of queue each): the spread of the K timed steps
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         trainer.step()
+        marks[i + 1].record()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = np.array([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]) if args.steps > 0 else np.zeros(1)
     if world > 1:
         import torch.distributed as dist
         tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -280,6 +297,9 @@ def main():
                 "rotmats": trainer.dflame.rotmats.cpu().numpy()}
     trainer.step()
     torch.cuda.synchronize()
+    if snap is not None:        # the forward outputs of that step, for the parity figures of the line
+        snap.update(gpu_image=trainer.rast.image.cpu().numpy(), gpu_final_T=trainer.rast.final_T.cpu().numpy(),
+                    gpu_n_contrib=trainer.rast.n_contrib.cpu().numpy())
     D = int(trainer.rast.tile_start[-1].item())
     n_contrib = trainer.rast.n_contrib
     P = W * H
@@ -318,7 +338,9 @@ def main():
             traffic_src, traffic_D = tj.get("_source"), tj.get("_D")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # `bound` names the roofline `frac` is priced against (the contract's hbm | mfma): none of the path's large kernels runs on
+    # the matrix cores (north_star: MFMA only for the FLAME basis product), so it is the HBM roofline unless a FLAME stage dominates
+    roofline = {"bound": "mfma" if dom in ("flame",) else "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": (traffic_src or "profiles/traffic.json (committed PMC pass of an earlier run of this command, not this run)") if traffic else None,
                 "traffic_D": traffic_D, "traffic_if_fetch_doubled": traffic_x2,
@@ -330,9 +352,20 @@ def main():
         for kname, vals in json.load(open(mix)).items():
             if f"{dom}_kernel" in kname and "valu_issue_util" in vals:
                 roofline["valu_issue_util"] = vals["valu_issue_util"]
-                # `bound` names the roofline the fraction is priced against (the contract's hbm | mfma); `limiter` is what the
-                # counters say actually holds the kernel
+                # `limiter` is what the counters say actually holds the kernel; the VALU-side figures say how far that is from
+                # useful work: issue slots used x the fraction of lanes an issued instruction does something for
                 roofline["limiter"] = "valu_issue" if vals["valu_issue_util"] >= 0.6 else "latency / memory"
+                valu = {"issue_util": vals["valu_issue_util"], "valu_winst_per_launch": round(vals.get("SQ_INSTS_VALU", 0)),
+                        "salu_inst_per_launch": round(vals.get("SQ_INSTS_SALU", 0)), "lds_inst_per_launch": round(vals.get("SQ_INSTS_LDS", 0))}
+                vc = os.path.join(ROOT, "profiles", "visit_counters.json")
+                if os.path.exists(vc):
+                    vj = json.load(open(vc)).get(dom, {})
+                    if vj.get("hit_lanes_per_visit"):
+                        valu["lanes_hit_per_visit"] = vj["hit_lanes_per_visit"]
+                        valu["useful_lane_issue_frac"] = round(vals["valu_issue_util"] * vj["hit_lanes_per_visit"] / 64.0, 3)
+                        valu["visits_per_launch"] = vj.get("visits_per_launch")
+                        valu["source"] = vj.get("source")
+                roofline["valu"] = valu
 
                 roofline["valu_note"] = "SQ_ACTIVE_INST_VALU*4/(1024 SIMDs x kernel cycles), " + os.path.basename(mix)
     except Exception:
@@ -341,7 +374,11 @@ def main():
 
     out = {
         "metric": "train_ghost_iters_per_sec", "value": round(value, 3), "unit": "iters/s", "n_gpus": n_ranks,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        # spread of the K timed steps on the GPU's clock (event to event on the launch stream; rank 0): early steps of a run
+        # carry more tile pairs than late ones (the untrained cloud is the heavy one), which is most of the spread
+        "ms_per_step_min": round(float(per_step.min()), 4), "ms_per_step_median": round(float(np.median(per_step)), 4),
+        "ms_per_step_max": round(float(per_step.max()), 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"train_ghost {N} mesh-bound Gaussians, {W}x{H}, {args.views} synthetic views, "
                                f"SH degree 3, L1+D-SSIM, Adam, fixed N (no densification), "
@@ -509,7 +546,9 @@ def main():
 
     # ---- CPU baseline (rank 0, single GPU run only): the PyTorch-CPU oracle on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sec, D_s = cpu_baseline_train(snap)
+        sec, D_s, parity = cpu_baseline_train(snap)
+        if parity is not None:
+            out["parity"] = parity
         log(f"cpu baseline done: {sec:.2f}s, D_cpu={D_s} D_gpu={D}")
         out["cpu_baseline"] = {
             "value": round(1.0 / sec, 6), "unit": "iters/s", "cores": torch.get_num_threads(), "kind": "port",

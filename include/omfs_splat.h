@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OMFS_ABI_VERSION 6
+#define OMFS_ABI_VERSION 7
 #define OMFS_TILE 16
 #define OMFS_SEG 128     /* list entries per backward segment                                          */
 #define OMFS_NPLANES 59
@@ -401,6 +401,12 @@ typedef struct omfs_view_step {
   float* loss_scratch;         /* 3*3*H*W + OMFS_LOSS_TAIL floats (omfs_loss_l1_ssim)                                      */
 } omfs_view_step;
 int omfs_view_forward_backward(const omfs_view_step* v, void* stream);
+/* ABI 7: the same call in two halves, for a data-parallel host that issues a collective between them (SURVEY.md section 8e:
+ * the all-gather of each rank's dL/dcolour runs under omfs_project_bwd).  The first half ends with omfs_composite_bwd and,
+ * when drgb_out != NULL ([3][n_pad]), omfs_extract_drgb into it; the second half is omfs_project_bwd with the same struct.
+ * omfs_view_forward_backward(v) == omfs_view_forward_composite_bwd(v, NULL) followed by omfs_view_project_bwd(v).     */
+int omfs_view_forward_composite_bwd(const omfs_view_step* v, float* drgb_out, void* stream);
+int omfs_view_project_bwd(const omfs_view_step* v, void* stream);
 
 /* ---- device-resident per-iteration scalars.  With them nothing about a training iteration is a kernel ARGUMENT any more
  * (the learning-rate schedule and Adam's bias corrections were the last ones), so a whole iteration can be captured in a

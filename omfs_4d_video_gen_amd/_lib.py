@@ -14,7 +14,7 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see module d
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 LOSS_TAIL = 16384              # OMFS_LOSS_TAIL: loss partials behind the three maps of omfs_loss_l1_ssim's scratch
 RB_FORWARD_ONLY = 1
 NPLANES = 59
@@ -126,6 +126,8 @@ SIGNATURES = {
     "omfs_adam_step_range": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_longlong, C.c_longlong,
                                        C.POINTER(AdamParamsC), c_void_p]),
     "omfs_view_forward_backward": (C.c_int, [C.POINTER(ViewStepC), c_void_p]),
+    "omfs_view_forward_composite_bwd": (C.c_int, [C.POINTER(ViewStepC), c_void_p, c_void_p]),
+    "omfs_view_project_bwd": (C.c_int, [C.POINTER(ViewStepC), c_void_p]),
     "omfs_step_advance": (C.c_int, [c_void_p, C.POINTER(LrScheduleC), c_void_p, C.c_int, c_void_p, c_void_p]),
     "omfs_adam_step_dev": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), c_void_p,
                                      C.c_int, C.c_int, c_void_p]),

@@ -13,6 +13,7 @@
 // power = -0.5(A dx^2 + C dy^2) - B dx dy, skip power > 0; alpha = min(0.99, o exp(power)), skip
 // alpha < 1/255; stop a pixel before a splat that would take T below 1e-4; out = C + T bg.
 // Evaluated here as alpha = exp2(power*log2e + log2 o): same value to ~1e-6 relative.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace omfs {
@@ -165,6 +166,12 @@ __device__ __forceinline__ int pop_lowest_bit(unsigned long long& m) {
   return i + 1;
 }
 
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+  return v;
+}
+
 // Forward.  One 64-lane workgroup (= one wave) per (tile, 8x8 quadrant); lane l owns pixel (l&7, l>>3) of
 // the quadrant.  No workgroup barrier exists: a wave whose pixels have all saturated simply exits and
 // frees its slot, silhouette quadrants take as long as they need without holding three idle partners.
@@ -184,7 +191,9 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
                                                            const float4* __restrict__ g0, const float4* __restrict__ g1,
                                                            const float4* __restrict__ g2, float* __restrict__ image,
                                                            float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                                                           float4* __restrict__ seg_ckpt, int keep_ckpt) {
+                                                           float4* __restrict__ seg_ckpt, int keep_ckpt,
+                                                           const uint32_t* __restrict__ order_seg0, uint32_t* __restrict__ seg_table,
+                                                           uint32_t* __restrict__ quad_max) {
   // staged records live at index 1 .. 64; index 0 is a record that no pixel can hit (log2 opacity -1e30): the visit
   // loop takes FOUR list entries per iteration and pads an incomplete batch with it (ffs of an empty bit mask is 0)
   __shared__ float4 s0[WB + 1];
@@ -199,10 +208,21 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
   const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const bool inside = px < cam.width && py < cam.height;
-  if (__ballot(inside) == 0ull) return;
+  if (__ballot(inside) == 0ull) {
+    if (quad_max && lane == 0) quad_max[tile * 4 + quad] = 0u;
+    return;
+  }
   const float fx = (float)px, fy = (float)py;
   float open = inside ? 1.f : 0.f;               // 1.0 while the pixel takes splats (see the walk)
   const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
+  // Segment table for the backward pass (one wave per (segment, quadrant), which otherwise finds its tile by a 13-step bisection
+  // of order_seg0 -- 13 dependent L2 round trips at the head of waves that visit a dozen splats): entry of global segment
+  // order_seg0[upos] + k = tile | k << 16; lists of 65535 segments or more (> 8.3 M entries in one tile) get the sentinel that
+  // sends the backward wave to the bisection.  Written by the tile's quadrant-0 wave, off everybody's critical path.
+  if (seg_table && quad == 0) {
+    const uint32_t nseg = (end - beg + OMFS_SEG - 1) / OMFS_SEG, s0g = order_seg0[upos];
+    for (uint32_t k = lane; k < nseg; k += 64) seg_table[s0g + k] = nseg < 0xFFFFu ? (tile | k << 16) : 0xFFFFFFFFu;
+  }
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);  // 4x4 sub-block of this lane's pixel
   unsigned long long sbl[4];
 #pragma unroll
@@ -348,6 +368,14 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
     final_T[o] = T;
     n_contrib[o] = last;
   }
+  // Depth of the quadrant = its deepest last contributor (tile-wide, 1-based): the backward wave of (segment k, this quadrant)
+  // has work exactly when 128 k < depth, and then visits min(depth - 128 k, segment length) entries -- known from ONE scalar
+  // load, before any of the pixel state has arrived (composite_bwd*).  A handed-over quadrant is finished by the deep kernel,
+  // which raises the word.
+  if (quad_max) {
+    const uint32_t mx = wave_max_u32(inside ? last : 0u);
+    if (lane == 0) quad_max[tile * 4 + quad] = mx;
+  }
 }
 
 // Forward, deep part.  Lists longer than FWD_SEQ_SEGS segments: one workgroup of DEEP_WAVES waves per (tile,
@@ -376,7 +404,7 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
     CompCam cam, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ tile_start,
     const uint32_t* __restrict__ sorted_ids, const float4* __restrict__ g0, const float4* __restrict__ g1,
     const float4* __restrict__ g2, float* __restrict__ image, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float4* __restrict__ seg_ckpt, int keep_ckpt) {
+    uint32_t* __restrict__ n_contrib, float4* __restrict__ seg_ckpt, int keep_ckpt, uint32_t* __restrict__ quad_max) {
   __shared__ float4 pg0[DEEP_WAVES][WB + 1];  // index 0 of every wave's page: the record no pixel can hit (see composite_fwd_kernel)
   __shared__ float4 pg1[DEEP_WAVES][WB + 1];
   __shared__ float4 pg2[DEEP_WAVES][WB + 1];  // .x = blue
@@ -596,6 +624,29 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
     final_T[o] = T;
     n_contrib[o] = last;
   }
+  if (quad_max && wave == 0) {     // the pixels finished here may lie deeper than the ones the one-wave forward finished
+    const uint32_t mx = wave_max_u32(mine ? last : 0u);
+    if (lane == 0) quad_max[tile * 4 + quad] = max(quad_max[tile * 4 + quad], mx);
+  }
+}
+
+// (tile, segment within the tile's list) of global list segment `seg`: one load from the table the forward pass left
+// (composite_fwd_kernel), or -- no table, or the sentinel of an over-long list -- the launch-order position p with
+// order_seg0[p] <= seg < order_seg0[p+1] by bisection (~13 dependent L2-resident loads).
+__device__ __forceinline__ void segment_tile(uint32_t seg, int n_tiles, const uint32_t* __restrict__ tile_order,
+                                             const uint32_t* __restrict__ order_seg0, const uint32_t* __restrict__ seg_table,
+                                             uint32_t& tile, uint32_t& kseg) {
+  if (seg_table) {
+    const uint32_t e = seg_table[seg];
+    if (e != 0xFFFFFFFFu) { tile = e & 0xFFFFu; kseg = e >> 16; return; }
+  }
+  int lo = 0, hi = n_tiles;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (order_seg0[mid] <= seg) lo = mid; else hi = mid;
+  }
+  tile = tile_order[lo];
+  kseg = seg - order_seg0[lo];
 }
 
 // Sums of 9 values over each group of 8 consecutive lanes, left in the group's last lane.  v_add_f32 with a DPP
@@ -657,7 +708,8 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
                                                            const float4* __restrict__ g2, const float* __restrict__ image,
                                                            const float* __restrict__ final_T,
                                                            const uint32_t* __restrict__ n_contrib,
-                                                           const float* __restrict__ dimage, float* __restrict__ dsplat) {
+                                                           const float* __restrict__ dimage, float* __restrict__ dsplat,
+                                                           const uint32_t* __restrict__ seg_table, const uint32_t* __restrict__ quad_max) {
   constexpr int PEND = OMFS_BWD_PEND;     // reduced splats parked before a flush
   __shared__ float4 s0[WB];
   __shared__ float4 s1[WB];
@@ -670,15 +722,17 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
   uint32_t seg; int quad;
   unit_quadrant_of_block(seg, quad);
   if (seg >= order_seg0[n_tiles]) return;
-  // launch-order position p with order_seg0[p] <= seg < order_seg0[p+1] (bisection, ~13 L2-resident loads)
-  int lo = 0, hi = n_tiles;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (order_seg0[mid] <= seg) lo = mid; else hi = mid;
-  }
-  const uint32_t tile = tile_order[lo], kseg = seg - order_seg0[lo];
+  uint32_t tile, kseg;
+  segment_tile(seg, n_tiles, tile_order, order_seg0, seg_table, tile, kseg);
   const int lane = threadIdx.x;
+  // Depth of this quadrant (deepest last contributor of its pixels; one scalar load of the word the forward pass left): the
+  // exact "does anything of this quadrant reach this segment" test and the number of entries to visit, known before any of
+  // the pixel state has arrived -- so the whole head of the wave is ONE batch of loads (pixel state, checkpoint, the first
+  // list entries and their records) instead of three dependent rounds through a memory system busy with gathers and atomics.
+  const uint32_t qdepth = quad_max ? quad_max[tile * 4 + quad] : 0xFFFFFFFFu;
+  if (qdepth <= kseg * OMFS_SEG) return;
   const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
+  const uint32_t beg = tbeg + kseg * OMFS_SEG, seg_len = min(tend, beg + OMFS_SEG) - beg;
   const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
   const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
   const bool inside = px < cam.width && py < cam.height;
@@ -686,14 +740,34 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
   const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
   const float T_final = inside ? final_T[o] : 0.f;
   const uint32_t last_g = inside ? n_contrib[o] : 0u;     // tile-wide, 1-based
-  if (__ballot(last_g > kseg * OMFS_SEG) == 0ull) return;   // nothing of this quadrant reaches this segment
-  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f, Cf0 = 0.f, Cf1 = 0.f, Cf2 = 0.f;
-  if (inside) {
+  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f, Ci0 = 0.f, Ci1 = 0.f, Ci2 = 0.f;
+  if (quad_max && inside) {                               // with the depth word the wave is known to have work: load ahead
     dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
-    Cf0 = image[o] - T_final * cam.bg[0]; Cf1 = image[plane + o] - T_final * cam.bg[1]; Cf2 = image[2 * plane + o] - T_final * cam.bg[2];
+    Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
   }
-  const float bgdot = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];
-  const uint32_t beg = tbeg + kseg * OMFS_SEG, seg_len = min(tend, beg + OMFS_SEG) - beg;
+  const bool deeper = quad_max && qdepth > (kseg + 1) * OMFS_SEG;     // wave-uniform: some pixel goes on behind this segment
+  float4 ck = make_float4(1.f, 0.f, 0.f, 0.f);
+  if (deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
+  // the first step to be staged is the LAST 64-entry step of the visited range
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  float r2 = 0.f;
+  uint32_t rid = 0;
+  int pre_step = -1;
+  if (quad_max) {
+    const uint32_t n_up = min(qdepth - kseg * OMFS_SEG, seg_len);
+    pre_step = (int)((n_up - 1u) / WB);
+    if ((uint32_t)lane < n_up - (uint32_t)pre_step * WB) {
+      rid = sorted_ids[beg + (uint32_t)pre_step * WB + lane];
+      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+    }
+  }
+  if (__ballot(last_g > kseg * OMFS_SEG) == 0ull) return;   // nothing of this quadrant reaches this segment (no depth word: decided here)
+  if (!quad_max && inside) {
+    dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
+    Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
+  }
+  const float Cf0 = Ci0 - T_final * cam.bg[0], Cf1 = Ci1 - T_final * cam.bg[1], Cf2 = Ci2 - T_final * cam.bg[2];
+  const float bgterm = T_final * (dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2]);
   const uint32_t last = last_g > kseg * OMFS_SEG ? min(last_g - kseg * OMFS_SEG, seg_len) : 0u;  // segment-local
   // last contributor: maxima per 4x4 sub-block and for the quadrant bound what has to be visited
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
@@ -708,15 +782,15 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
   const uint32_t n_visit = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
   if (n_visit == 0) return;
   float T = T_final;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;         // colour accumulated behind the current splat
-  float la = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f;  // last alpha / colour
+  // The colour accumulated behind the current splat only ever enters through its dot product with dL/dimage, so the three
+  // per-channel recurrences are carried as ONE scalar per pixel, S = <colour behind, dL/dimage> (7 instructions instead of 13)
+  float S = 0.f;
+  float la = 0.f, lcd = 0.f;                        // last visited splat: alpha, <colour, dL/dimage>
   if (last_g > (kseg + 1) * OMFS_SEG) {             // the pixel goes on behind this segment
-    const float4 ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
+    if (!deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
     const float inv = __builtin_amdgcn_rcpf(ck.x);
     T = ck.x;
-    acc0 = (Cf0 - ck.y) * inv;
-    acc1 = (Cf1 - ck.z) * inv;
-    acc2 = (Cf2 - ck.w) * inv;
+    S = ((Cf0 - ck.y) * dL0 + (Cf1 - ck.z) * dL1 + (Cf2 - ck.w) * dL2) * inv;
   }
   int n_pending = 0;
   auto flush_pending = [&]() {
@@ -736,10 +810,7 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
     __builtin_amdgcn_wave_barrier();
   };
   const int n_steps = (int)((n_visit + WB - 1) / WB);
-  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-  float r2 = 0.f;
-  uint32_t rid = 0;
-  {
+  if (n_steps - 1 != pre_step) {          // no depth word (or a stale one): gather the first step now
     const int cnt0 = (int)min((uint32_t)WB, n_visit - (uint32_t)(n_steps - 1) * WB);
     if (lane < cnt0) {
       rid = sorted_ids[beg + (uint32_t)(n_steps - 1) * WB + lane];
@@ -838,12 +909,10 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
         T = T * r1a;
         const float w = alpha * T;
         v[6] = w * dL0; v[7] = w * dL1; v[8] = w * dL2;  // dL/dcolour
-        acc0 = fma_(la, lc0, (1.f - la) * acc0);
-        acc1 = fma_(la, lc1, (1.f - la) * acc1);
-        acc2 = fma_(la, lc2, (1.f - la) * acc2);
-        lc0 = c.z; lc1 = c.w; lc2 = cb.x; la = alpha;
-        float dLa = (c.z - acc0) * dL0 + (c.w - acc1) * dL1 + (cb.x - acc2) * dL2;
-        dLa = fma_(dLa, T, -(T_final * r1a) * bgdot);
+        S = fma_(la, lcd, (1.f - la) * S);
+        const float cd = fma_(cb.x, dL2, fma_(c.w, dL1, c.z * dL0));
+        lcd = cd; la = alpha;
+        const float dLa = fma_(cd - S, T, -r1a * bgterm);
         // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream rasteriser does
         // (DESIGN.md "Frozen conventions").  Only the moments of gL = dL/dG * G over the pixels are reduced here:
         //   S_x = sum gL dx, S_y, S_xx, S_xy, S_yy  (dx = mean - pixel);
@@ -877,6 +946,292 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
   OMFS_DBG_ADD(11, max(max(rowtot_dbg[0], rowtot_dbg[1]), max(rowtot_dbg[2], rowtot_dbg[3])));
   OMFS_DBG_ADD(14, 1);
 #endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward, matrix-core reduction (round 4; the round-3 experiment lost on residency: 16-visit batches, two coefficient sets,
+// 13 KB of LDS and 146 VGPRs per wave).  Same decomposition as composite_bwd_kernel -- one wave per (segment, quadrant), lanes =
+// pixels, back-to-front walk from the forward's checkpoints -- but the nine per-splat sums are no longer reduced across lanes
+// with DPP adds.  They are LINEAR in two per-pixel values with coefficients that depend on the pixel only:
+//     gL = opacity * G * dL/dalpha-term,   w = alpha * T                       (per visit and pixel)
+//     M0 = sum gL, Mu = sum gL u, Mv = sum gL v, Muu, Muv, Mvv                  (u, v = pixel position about the quadrant centre)
+//     dC_k = sum w * dL/dimage_k(pixel)
+// i.e. [rows x pixels] . [pixels x 9].  Per visit a lane only parks (gL, w) in LDS (two rows of a 16-row ring: rows 0..7 the gL
+// of eight visits, rows 8..15 their w); every eight visits the wave reads the ring back TRANSPOSED (lane = (row, 16-pixel
+// group): the A operand of v_mfma_f32_16x16x4_f32) and multiplies by ONE constant coefficient matrix held in 16 registers (B
+// operand: lane = (16-pixel group, column); columns 0..5 the monomials, 6..8 dL/dimage): 16 matrix instructions per eight
+// visits, exact fp32 products and accumulation, executed by the matrix cores beside the vector ALU this kernel is bound by.
+// D[row][column]: a gL row carries its six moments in columns 0..5, a w row its three colour sums in columns 6..8 (the other
+// entries of the tile are computed and ignored).  The moments about the quadrant centre become the moments about the splat's
+// own mean (S_x = X M0 - Mu, S_xx = X^2 M0 - 2 X Mu + Muu, ...; X, Y = mean - centre, |u|, |v| <= 3.5) in sixteen lanes per
+// visit -- the 64-byte dsplat record shape the float atomics want.  Replaces per visit: 9 products, 18 v_add_f32_dpp, 9 LDS
+// stores by a quarter of the lanes and the 16-partial flush sums.  The colour recurrence is carried as ONE scalar per pixel,
+// S = <colour behind the splat, dL/dimage> (it only ever enters through that dot product): 7 instructions instead of 13.
+// b where the lane's bit of the wave-uniform mask is set, a elsewhere: ONE v_cndmask_b32 with the mask in a scalar register pair
+// (a nest of `cond ? x : y` over lane-only conditions is otherwise turned into divergent control flow)
+__device__ __forceinline__ float lane_select(float a, float b, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+  return r;
+}
+#define COLS(bits16) (0x0001000100010001ull * (unsigned long long)(bits16))   // lanes whose column (lane & 15) is in the 16-bit set
+#ifndef OMFS_BWD_BV
+#define OMFS_BWD_BV 8
+#endif
+constexpr int BV = OMFS_BWD_BV;        // visits per matrix batch (<= 8): rows 0..BV-1 gL, BV..2BV-1 w of the 16-row A tile
+constexpr int AROW = 68;               // floats per ring row: 64 pixels + 4 (rows 0..7 start in distinct 16-byte bank groups)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#ifndef OMFS_BWD_MFMA_WAVES
+#define OMFS_BWD_MFMA_WAVES 5
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFMA_WAVES, 8))) void composite_bwd_mfma_kernel(
+    CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_seg0,
+    const float4* __restrict__ seg_ckpt, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ sorted_ids,
+    const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ g2, const float* __restrict__ image,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dimage,
+    float* __restrict__ dsplat, const uint32_t* __restrict__ seg_table, const uint32_t* __restrict__ quad_max) {
+  __shared__ float4 s0[WB];               // mean.x, mean.y, -0.5 log2e A, -log2e B
+  __shared__ float4 s1[WB];               // -0.5 log2e C, log2 opacity, red, green
+  __shared__ float4 s2[WB];               // blue, opacity, Gaussian id (bits), -
+  __shared__ __attribute__((aligned(16))) float abuf[2 * BV][AROW];   // the ring; reused as D [16][16] inside a flush
+  __shared__ float4 svis[BV];             // per parked visit: mean.x, mean.y, opacity, Gaussian id (bits)
+  OMFS_DBG_SPAN(2);
+  uint32_t seg; int quad;
+  unit_quadrant_of_block(seg, quad);
+  if (seg >= order_seg0[n_tiles]) return;
+  uint32_t tile, kseg;
+  segment_tile(seg, n_tiles, tile_order, order_seg0, seg_table, tile, kseg);
+  const int lane = threadIdx.x;
+  // Depth of this quadrant (deepest last contributor of its pixels; one scalar load of the word the forward pass left): the
+  // exact "does anything of this quadrant reach this segment" test and the number of entries to visit, known before any of
+  // the pixel state has arrived -- so the whole head of the wave is ONE batch of loads (pixel state, checkpoint, the first
+  // list entries and their records) instead of three dependent rounds through a memory system busy with gathers and atomics.
+  const uint32_t qdepth = quad_max ? quad_max[tile * 4 + quad] : 0xFFFFFFFFu;
+  if (qdepth <= kseg * OMFS_SEG) return;
+  const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
+  const uint32_t beg = tbeg + kseg * OMFS_SEG, seg_len = min(tend, beg + OMFS_SEG) - beg;
+  const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const bool inside = px < cam.width && py < cam.height;
+  const float fx = (float)px, fy = (float)py;
+  const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
+  const float T_final = inside ? final_T[o] : 0.f;
+  const uint32_t last_g = inside ? n_contrib[o] : 0u;     // tile-wide, 1-based
+  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f, Ci0 = 0.f, Ci1 = 0.f, Ci2 = 0.f;
+  if (quad_max && inside) {                               // with the depth word the wave is known to have work: load ahead
+    dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
+    Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
+  }
+  const bool deeper = quad_max && qdepth > (kseg + 1) * OMFS_SEG;     // wave-uniform: some pixel goes on behind this segment
+  float4 ck = make_float4(1.f, 0.f, 0.f, 0.f);
+  if (deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
+  // the first step to be staged is the LAST 64-entry step of the visited range
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  float r2 = 0.f;
+  uint32_t rid = 0;
+  int pre_step = -1;
+  if (quad_max) {
+    const uint32_t n_up = min(qdepth - kseg * OMFS_SEG, seg_len);
+    pre_step = (int)((n_up - 1u) / WB);
+    if ((uint32_t)lane < n_up - (uint32_t)pre_step * WB) {
+      rid = sorted_ids[beg + (uint32_t)pre_step * WB + lane];
+      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+    }
+  }
+  if (__ballot(last_g > kseg * OMFS_SEG) == 0ull) return;   // nothing of this quadrant reaches this segment (no depth word: decided here)
+  if (!quad_max && inside) {
+    dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
+    Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
+  }
+  const float Cf0 = Ci0 - T_final * cam.bg[0], Cf1 = Ci1 - T_final * cam.bg[1], Cf2 = Ci2 - T_final * cam.bg[2];
+  const float bgterm = T_final * (dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2]);
+  const uint32_t last = last_g > kseg * OMFS_SEG ? min(last_g - kseg * OMFS_SEG, seg_len) : 0u;  // segment-local
+  const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
+  uint32_t smax[4];
+#pragma unroll
+  for (int sb = 0; sb < 4; ++sb) {
+    uint32_t v = sidx == sb ? last : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    smax[sb] = __builtin_amdgcn_readfirstlane(v);
+  }
+  const uint32_t n_visit = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+  if (n_visit == 0) return;
+  // ---- the constant B operand: lane (grp = lane >> 4 = k, col = lane & 15), step s -> pixel 16 grp + s, column col
+  const int col = lane & 15, grp = lane >> 4;
+  float cb_[16];
+  {
+    float* sdl = &abuf[0][0];             // [3][64] dL/dimage of the quadrant's pixels (the ring is not in use yet)
+    sdl[lane] = dL0; sdl[64 + lane] = dL1; sdl[128 + lane] = dL2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // branch-free: column col = a0 + a1 u + a2 u^2 times b0 + b1 v + b2 v^2 with one-hot (a, b) per lane -- (eu, ev) = (0,0) (1,0)
+    // (0,1) (2,0) (1,1) (0,2) for columns 0..5, all zero beyond -- plus, in columns 6..8, the pixel's dL/dimage
+    const float a0 = (col == 0 || col == 2 || col == 5) ? 1.f : 0.f, a1 = (col == 1 || col == 4) ? 1.f : 0.f, a2 = col == 3 ? 1.f : 0.f;
+    const float b0 = (col == 0 || col == 1 || col == 3) ? 1.f : 0.f, b1 = (col == 2 || col == 4) ? 1.f : 0.f, b2 = col == 5 ? 1.f : 0.f;
+    const bool wcol = col >= 6 && col < 9;
+    const float isw = wcol ? 1.f : 0.f;
+    const float4* dsrc = reinterpret_cast<const float4*>(sdl + (wcol ? (col - 6) * 64 : 0) + 16 * grp);
+    const float4 d0 = dsrc[0], d1 = dsrc[1], d2 = dsrc[2], d3 = dsrc[3];
+    const float dv[16] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x, d3.y, d3.z, d3.w};
+    const float v0 = (float)(2 * grp) - 3.5f, v1 = v0 + 1.f;      // pixel 16 grp + s lies in quadrant row 2 grp + (s >> 3)
+    const float fv0 = fma_(b2, v0 * v0, fma_(b1, v0, b0)), fv1 = fma_(b2, v1 * v1, fma_(b1, v1, b0));
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float u = (float)(s & 7) - 3.5f;                       // compile-time
+      const float fu = fma_(a2, u * u, fma_(a1, u, a0));
+      cb_[s] = fma_(dv[s], isw, fu * ((s >> 3) ? fv1 : fv0));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const float cx = (float)qx0 + 3.5f, cy = (float)qy0 + 3.5f;
+  // word of a visit's D rows that output column col is built around: Mu, Mv, Muu, Muv, Mvv, M0; the w row's columns 6..8
+  const int own_off = col < 5 ? col + 1 : (col == 5 ? 0 : BV * 16 + min(col, 8));
+  float T = T_final;
+  float S = 0.f;                          // <colour accumulated behind the current splat, dL/dimage>
+  float la = 0.f, lcd = 0.f;              // last visited splat: alpha, <colour, dL/dimage>
+  if (last_g > (kseg + 1) * OMFS_SEG) {   // the pixel goes on behind this segment
+    if (!deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
+    const float inv = __builtin_amdgcn_rcpf(ck.x);
+    T = ck.x;
+    S = ((Cf0 - ck.y) * dL0 + (Cf1 - ck.z) * dL1 + (Cf2 - ck.w) * dL2) * inv;
+  }
+  int n_parked = 0;
+  auto flush_batch = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // A operand: lane (row = col, grp) reads 16 consecutive pixels of its ring row
+    const float4* row = reinterpret_cast<const float4*>(&abuf[col < 2 * BV ? col : 2 * BV - 1][16 * grp]);   // rows beyond 2 BV: unused
+    const float4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.x, cb_[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.y, cb_[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.z, cb_[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.w, cb_[3], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.x, cb_[4], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.y, cb_[5], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.z, cb_[6], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.w, cb_[7], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.x, cb_[8], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.y, cb_[9], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.z, cb_[10], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.w, cb_[11], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.x, cb_[12], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.y, cb_[13], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.z, cb_[14], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.w, cb_[15], acc, 0, 0, 0);
+    // D: register r of lane (grp, col) = row 4 grp + r, column col.  The tile goes through LDS (the ring is consumed) so that the
+    // sixteen lanes of a visit's output record see its six moments.
+    __builtin_amdgcn_wave_barrier();
+    float* dbuf = &abuf[0][0];            // [16 rows][16 columns]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dbuf[(4 * grp + r) * 16 + col] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < (BV + 3) / 4; ++h) {
+      const int i = min(4 * h + grp, BV - 1);     // visit of this lane's 16-lane record (clamped: a pass beyond BV emits nothing)
+      // Branch-free (a select chain over the column compiles to seven divergent paths): column col of the record is
+      //   out = c_own * own + cA * M0 + cB * Mu + cC * Mv
+      // with own = the D entry the column is built around (Mu, Mv, Muu, Muv, Mvv, M0, colour sums: one LDS word at a per-lane
+      // offset) and coefficients that are products of X, Y selected by lane-only predicates (scalar masks, one v_cndmask each):
+      //   S_x = X M0 - Mu | S_y = Y M0 - Mv | S_xx = X^2 M0 - 2X Mu + Muu | S_xy = XY M0 - Y Mu - X Mv + Muv | S_yy = Y^2 M0 - 2Y Mv + Mvv
+      //   d opacity = M0 / opacity | colour sums as they are
+      const float4 m = *reinterpret_cast<const float4*>(&dbuf[i * 16]);          // M0, Mu, Mv, (Muu)
+      const float own = dbuf[i * 16 + own_off];
+      const float4 vis = svis[i];
+      const float X = vis.x - cx, Y = vis.y - cy;
+      // lane-only predicates as literal lane masks (column = lane & 15): one v_cndmask_b32 per select, no control flow
+      const float P = lane_select(lane_select(0.f, Y, COLS(0x0012)), X, COLS(0x000D));       // columns {1,4}: Y, {0,2,3}: X
+      const float Q = lane_select(lane_select(1.f, Y, COLS(0x0018)), X, COLS(0x0004));       // columns {3,4}: Y, {2}: X
+      const float cB = lane_select(lane_select(0.f, -Y, COLS(0x0008)), -2.f * X, COLS(0x0004));
+      const float cC = lane_select(lane_select(0.f, -2.f * Y, COLS(0x0010)), -X, COLS(0x0008));
+      const float c_own = lane_select(lane_select(1.f, __builtin_amdgcn_rcpf(vis.z), COLS(0x0020)), -1.f, COLS(0x0003));
+      const float out = fma_(P * Q, m.x, fma_(cB, m.y, fma_(cC, m.z, c_own * own)));
+      if (4 * h + grp < n_parked && col < 9 && out != 0.f) atomicAdd(&dsplat[(size_t)__float_as_uint(vis.w) * 16 + col], out);
+    }
+    __builtin_amdgcn_wave_barrier();
+    n_parked = 0;
+  };
+  const int n_steps = (int)((n_visit + WB - 1) / WB);
+  if (n_steps - 1 != pre_step) {          // no depth word (or a stale one): gather the first step now
+    const int cnt0 = (int)min((uint32_t)WB, n_visit - (uint32_t)(n_steps - 1) * WB);
+    if (lane < cnt0) {
+      rid = sorted_ids[beg + (uint32_t)(n_steps - 1) * WB + lane];
+      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+    }
+  }
+  for (int st = n_steps - 1; st >= 0; --st) {
+    const uint32_t cbase = (uint32_t)st * WB;                       // list position of bit 0, 0-based
+    const int cnt = (int)min((uint32_t)WB, n_visit - cbase);
+    uint32_t mask = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cnt) {
+      const float A = r0.z, B = r0.w, C = r1.x;
+      const float lo2 = __log2f(fmaxf(r1.y, 1e-30f));
+      s0[lane] = make_float4(r0.x, r0.y, -0.5f * LOG2E * A, -LOG2E * B);
+      s1[lane] = make_float4(-0.5f * LOG2E * C, lo2, r1.z, r1.w);
+      s2[lane] = make_float4(r2, r1.y, __uint_as_float(rid), 0.f);
+      mask = quadrant_mask(r0.x, r0.y, A, B, C, lo2, qx0, qy0);
+    }
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+      const unsigned long long bal = __ballot((mask >> sb) & 1u);
+      if (smax[sb] > cbase) {
+        const uint32_t lim = smax[sb] - cbase;
+        m |= bal & (lim >= 64u ? ~0ull : ((1ull << lim) - 1ull));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (st > 0) {   // every earlier step is full
+      rid = sorted_ids[beg + cbase - WB + lane];
+      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+    }
+    int jbn = m ? 63 - __builtin_clzll(m) : 0;
+    float4 recA0 = s0[jbn], recA1 = s1[jbn], recA2 = s2[jbn], recB0 = recA0, recB1 = recA1, recB2 = recA2;
+    auto visit = [&](const float4& an, const float4& cn, const float4& cbn, float4& nx0, float4& nx1, float4& nx2) {
+      const int jb = jbn;
+      OMFS_DBG_WORK();
+      m &= ~(1ull << jb);
+      const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
+      const float4 a = an;
+      const float4 c = cn;
+      const float4 cb = cbn;
+      jbn = 63 - __builtin_clzll(m | 1ull);   // prefetch the next splat's record
+      nx0 = s0[jbn]; nx1 = s1[jbn]; nx2 = s2[jbn];
+      const float dx = a.x - fx, dy = a.y - fy;
+      const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
+      const float e = p2 + c.y;
+      const bool hit = contributor <= last && p2 <= 0.f && e >= LOG2_INV255;
+      if (__ballot(hit) == 0ull) return;    // nobody in this quadrant was touched: nothing to park
+      // Branch-free: G is masked to 0 for lanes that are not hit, which makes alpha = 0, 1/(1-alpha) = 1 and both parked values
+      // exactly 0 for them; their recurrence takes a no-op step (a splat of alpha 0).
+      const float G = hit ? __builtin_amdgcn_exp2f(p2) : 0.f;
+      const float oG = cb.y * G;                              // opacity * G
+      const float alpha = fminf(0.99f, oG);
+      const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
+      T = T * r1a;
+      const float w = alpha * T;
+      S = fma_(la, lcd, (1.f - la) * S);
+      const float cd = fma_(cb.x, dL2, fma_(c.w, dL1, c.z * dL0));
+      lcd = cd; la = alpha;
+      // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream rasteriser does
+      const float dLa = fma_(cd - S, T, -r1a * bgterm);
+      const float gL = oG * dLa;                     // opacity folded in; d opacity = sum gL / opacity
+      abuf[n_parked][lane] = gL;
+      abuf[BV + n_parked][lane] = w;
+      if (lane == 0) svis[n_parked] = make_float4(a.x, a.y, cb.y, cb.z);
+      if (++n_parked == BV) flush_batch();
+    };
+    while (m) {
+      visit(recA0, recA1, recA2, recB0, recB1, recB2);
+      if (!m) break;
+      visit(recB0, recB1, recB2, recA0, recA1, recA2);
+    }
+  }
+  if (n_parked) flush_batch();
 }
 
 __global__ void image_to_rgb8_kernel(const float* __restrict__ image, int width, int height, uint8_t* __restrict__ rgb8) {
@@ -917,6 +1272,18 @@ __global__ void image_to_png_rows_kernel(const float* __restrict__ image, int wi
   }
 }
 
+// The segment table of the backward pass lives in `keys`: the (depth, id) pairs are dead once omfs_tile_sort has produced
+// sorted_ids, and the next frame's binning rewrites them.  2 * dup_capacity words hold seg_capacity entries unless the pair
+// capacity is tiny against the tile count (then: no table, the backward bisects).
+static uint32_t* segment_table(const omfs_raster_buffers* rb) {
+  return (rb->keys && rb->order_seg0 && 2ull * rb->dup_capacity >= (unsigned long long)rb->seg_capacity) ? rb->keys : nullptr;
+}
+// ... followed by one word per (tile, quadrant): the quadrant's depth (see composite_fwd_kernel)
+static uint32_t* quadrant_depths(const omfs_raster_buffers* rb, int n_tiles) {
+  return (segment_table(rb) && 2ull * rb->dup_capacity >= (unsigned long long)rb->seg_capacity + 4ull * (unsigned long long)n_tiles)
+             ? rb->keys + rb->seg_capacity : nullptr;
+}
+
 static CompCam make_compcam(const omfs_camera* c) {
   CompCam k;
   k.width = c->width; k.height = c->height; k.gx = cdiv(c->width, OMFS_TILE);
@@ -938,12 +1305,14 @@ extern "C" int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buff
   const int keep_ckpt = (rb->flags & OMFS_RB_FORWARD_ONLY) ? 0 : 1;
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_tiles * 4), dim3(64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
-                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt);
+                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt,
+                     rb->order_seg0, keep_ckpt ? segment_table(rb) : nullptr, keep_ckpt ? quadrant_depths(rb, n_tiles) : nullptr);
   OMFS_CHECK_HIP(hipGetLastError());
   // quadrants whose list is longer than FWD_SEQ_SEGS segments and still unsaturated (the rest exit at once)
   hipLaunchKernelGGL(composite_fwd_deep_kernel, dim3(n_tiles * 4), dim3(DEEP_WAVES * 64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
-                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt);
+                     (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt,
+                     keep_ckpt ? quadrant_depths(rb, n_tiles) : nullptr);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
@@ -957,10 +1326,19 @@ extern "C" int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buff
   const int n_tiles = cc.gx * cdiv(cam->height, OMFS_TILE);
   OMFS_REQUIRE(rb->order_seg0 && rb->seg_capacity >= (uint32_t)n_tiles + rb->dup_capacity / OMFS_SEG, "segment buffers");
   // one wave per (list segment, quadrant); the grid covers the segment capacity, waves beyond the device-side
-  // total (order_seg0[n_tiles]) exit at once
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
-                     rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
-                     (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat);
+  // total (order_seg0[n_tiles]) exit at once.  Two implementations of the same decomposition: the cross-lane reduction with DPP
+  // adds (default) or on the matrix cores (OMFS_BWD_IMPL=mfma: 37 % fewer vector instructions, but 95 VGPRs and 7.4 KB of LDS
+  // per wave leave 5 waves per SIMD where the DPP form keeps 8, and the kernel is bound by the lifetime of its 23 k working
+  // waves, not by instruction issue: 0.221 against 0.200 ms, profiles/r04_bwd_*; kept as a second opinion for the tests)
+  const char* impl = getenv("OMFS_BWD_IMPL");      // read per call: tools switch between the two inside one process
+  if (!(impl && impl[0] == 'm'))
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
+                       rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
+                       (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat, segment_table(rb), quadrant_depths(rb, n_tiles));
+  else
+    hipLaunchKernelGGL(composite_bwd_mfma_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
+                       rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
+                       (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat, segment_table(rb), quadrant_depths(rb, n_tiles));
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -211,15 +211,16 @@ class Trainer:
     def _view_step(self, view: View, cam, fxf: torch.Tensor, g, ft):
         """omfs_view_step of this view (cached with everything it points at: the structs must outlive the call)."""
         target = view.target
+        drgb = L.ptr(self.drgb_scratch) if self.compact_dp else 0      # compact exchange: project_bwd leaves the 45 SH planes out
         key = (id(view), id(cam), fxf.data_ptr(), g.n, g.n_pad, g.params, g.binding, L.ptr(self.densify_stats), L.ptr(ft.dface) if ft is not None else 0,
-               target.data_ptr(), self.lambda_dssim, tuple(self.reg), self.rast.rb.keys, self.rast.rb.dup_capacity)
+               target.data_ptr(), self.lambda_dssim, tuple(self.reg), self.rast.rb.keys, self.rast.rb.dup_capacity, drgb)
         hit = self._view_steps.get(key)
         if hit is None:
             if len(self._view_steps) > 8 * max(len(self.views), 1):
                 self._view_steps.clear()
             r = self.rast
             gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
-                                L.ptr(ft.dface) if ft is not None else 0, 0)
+                                L.ptr(ft.dface) if ft is not None else 0, drgb)
             rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
             u8 = target.dtype == torch.uint8
             if u8 and self._target_f32 is None:
@@ -451,10 +452,24 @@ class Trainer:
         tm.mark("flame")
         fxf = face_xf[col]
         gather = None
+        if self.compact_dp and (self.drgb_local is None or self.drgb_local.shape[1] != self.model.n_pad):
+            self.drgb_local = torch.zeros(3, self.model.n_pad, device=self.device)
+            self.drgb_scratch = torch.zeros(3, self.model.n_pad, device=self.device)
+            self.drgb_all = torch.zeros(self.world, 3, self.model.n_pad, device=self.device)
         if not tm.enabled and not self.dp:
             # one C-ABI call for the whole view (projection ... parameter gradients): a Python host pays ~10 us per ctypes call
             lib, s, g = L.load(), L.stream_ptr(), r._gauss(self.model)
             L.check(lib.omfs_view_forward_backward(self._view_step(view, cam, fxf, g, ft), s), "omfs_view_forward_backward")
+        elif not tm.enabled:
+            # data parallel: the same call in its two halves (ABI 7) -- projection ... composite_bwd (+ the rank's dL/dcolour
+            # planes), then project_bwd, with the all-gather of dL/dcolour issued between them so that it runs under project_bwd
+            lib, s, g = L.load(), L.stream_ptr(), r._gauss(self.model)
+            vs = self._view_step(view, cam, fxf, g, ft)
+            L.check(lib.omfs_view_forward_composite_bwd(vs, L.ptr(self.drgb_local) if self.compact_dp else 0, s), "omfs_view_forward_composite_bwd")
+            if self.compact_dp:
+                from .distributed import allgather_into_
+                gather = allgather_into_(self.drgb_all, self.drgb_local, self.pg, async_op=True)
+            L.check(lib.omfs_view_project_bwd(vs, s), "omfs_view_project_bwd")
         else:
             r.project(self.model, fxf, cam); tm.mark("project")
             lib = L.load()
@@ -472,10 +487,6 @@ class Trainer:
                 L.check(lib.omfs_rgb8_to_image(L.ptr(target), r.width, r.height, L.ptr(self._target_f32), s), "omfs_rgb8_to_image")
                 target = self._target_f32
             r.loss_l1_ssim(target, self.lambda_dssim); tm.mark("loss")
-            if self.compact_dp and (self.drgb_local is None or self.drgb_local.shape[1] != self.model.n_pad):
-                self.drgb_local = torch.zeros(3, self.model.n_pad, device=self.device)
-                self.drgb_scratch = torch.zeros(3, self.model.n_pad, device=self.device)
-                self.drgb_all = torch.zeros(self.world, 3, self.model.n_pad, device=self.device)
             gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
                                 L.ptr(ft.dface) if ft is not None else 0, L.ptr(self.drgb_scratch) if self.compact_dp else 0)
             L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")

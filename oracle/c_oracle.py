@@ -104,14 +104,25 @@ def bin_sort(proj: dict, width: int, height: int, cull: bool = True):
     return tile_start, ids[:int(D)]
 
 
-def composite(proj: dict, tile_start, ids, width: int, height: int, bg):
+NEAR_TOL_ALPHA = 2e-5   # |255 alpha - 1| below which a (Gaussian, pixel) pair counts as "on the 1/255 threshold" (= torch_splat.NEAR_TOL)
+NEAR_TOL_T = 2e-5       # relative distance of T(1 - alpha) from the 1e-4 stop threshold below which a pixel's stop is "on the threshold"
+
+
+def composite(proj: dict, tile_start, ids, width: int, height: int, bg, near: bool = False):
+    """near=True: also returns the [H][W] uint8 map of pixels that own a decision on a threshold (bit 0: alpha vs 1/255 within
+    NEAR_TOL_ALPHA, bit 1: T vs 1e-4 within NEAR_TOL_T) -- see orc_composite_diag."""
     img = np.zeros((3, height, width), np.float32)
     fT = np.zeros((height, width), np.float32)
     nc = np.zeros((height, width), np.uint32)
     ids_ = np.ascontiguousarray(ids if len(ids) else np.zeros(1, np.uint32), np.uint32)
-    lib().orc_composite(C.c_int(width), C.c_int(height), _p(f32(bg)), _p(tile_start), _p(ids_), _p(proj["mean2d"]),
-                        _p(proj["conic"]), _p(proj["opac"]), _p(proj["rgb"]), _p(img), _p(fT), _p(nc))
-    return img, fT, nc
+    args = (C.c_int(width), C.c_int(height), _p(f32(bg)), _p(tile_start), _p(ids_), _p(proj["mean2d"]),
+            _p(proj["conic"]), _p(proj["opac"]), _p(proj["rgb"]), _p(img), _p(fT), _p(nc))
+    if not near:
+        lib().orc_composite(*args)
+        return img, fT, nc
+    flags = np.zeros((height, width), np.uint8)
+    lib().orc_composite_diag(*args, _p(flags), C.c_float(NEAR_TOL_ALPHA), C.c_float(NEAR_TOL_T))
+    return img, fT, nc, flags
 
 
 def render(dflame, t, params, binding, n, cam: OrcCamera, cull: bool = True):
@@ -120,6 +131,6 @@ def render(dflame, t, params, binding, n, cam: OrcCamera, cull: bool = True):
     fxf = face_frames(verts, dflame.rig.faces)
     proj = project(params, binding, fxf, cam, n)
     ts, ids = bin_sort(proj, cam.width, cam.height, cull)
-    img, fT, nc = composite(proj, ts, ids, cam.width, cam.height, list(cam.bg))
+    img, fT, nc, near = composite(proj, ts, ids, cam.width, cam.height, list(cam.bg), near=True)
     return {"verts": verts, "joint_xf": jx, "face_xf": fxf, "proj": proj, "tile_start": ts, "ids": ids,
-            "image": img, "final_T": fT, "n_contrib": nc}
+            "image": img, "final_T": fT, "n_contrib": nc, "near": near}

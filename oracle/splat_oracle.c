@@ -312,10 +312,15 @@ int64_t orc_bin_sort(int n, int width, int height, const float* depth, const int
 #undef TOUCH
 }
 
-/* Front-to-back composite (Appendix A item 6). image [3][H][W], final_T [H][W], n_contrib [H][W] */
-void orc_composite(int width, int height, const float* bg, const uint32_t* tile_start, const uint32_t* sorted_ids,
-                   const float* mean2d, const float* conic, const float* opac, const float* rgb, float* image,
-                   float* final_T, uint32_t* n_contrib) {
+/* Front-to-back composite (Appendix A item 6). image [3][H][W], final_T [H][W], n_contrib [H][W].
+ * near (optional, [H][W] bytes): which pixels own a DISCRETE decision that two correct fp32 evaluations may take differently --
+ *   bit 0: a pair the pixel evaluated before it stopped has |255 alpha - 1| < tol_alpha (the 1/255 inclusion threshold),
+ *   bit 1: a pair's T(1 - alpha) lies within tol_T (relative) of the 1e-4 stop threshold.
+ * Every other pixel ("calm") must show the same n_contrib in any implementation of the spec and the same colour up to
+ * rounding; tests state the bound.  The values the function returns do not depend on `near`. */
+static void composite_impl(int width, int height, const float* bg, const uint32_t* tile_start, const uint32_t* sorted_ids,
+                           const float* mean2d, const float* conic, const float* opac, const float* rgb, float* image,
+                           float* final_T, uint32_t* n_contrib, uint8_t* near, float tol_alpha, float tol_T) {
   const int gx = (width + TILE - 1) / TILE;
   const size_t plane = (size_t)width * height;
 #pragma omp parallel for schedule(dynamic, 4)
@@ -325,6 +330,7 @@ void orc_composite(int width, int height, const float* bg, const uint32_t* tile_
       const float fx = (float)px, fy = (float)py;
       float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f;
       uint32_t contributor = 0, last = 0;
+      uint8_t flags = 0;
       for (uint32_t k = tile_start[t]; k < tile_start[t + 1]; ++k) {
         const uint32_t id = sorted_ids[k];
         ++contributor;
@@ -333,8 +339,10 @@ void orc_composite(int width, int height, const float* bg, const uint32_t* tile_
         const float power = fmaf(-0.5f, fmaf(A * dx, dx, Cc * dy * dy), -(B * dx) * dy);
         if (power > 0.f) continue;
         const float alpha = fminf(0.99f, opac[id] * expf(power));
+        if (fabsf(alpha * 255.f - 1.f) < tol_alpha) flags |= 1;
         if (alpha < (1.f / 255.f)) continue;
         const float Tn = T * (1.f - alpha);
+        if (fabsf(Tn - 1e-4f) < tol_T * 1e-4f) flags |= 2;
         if (Tn < 1e-4f) break;
         const float w = alpha * T;
         C0 = fmaf(rgb[id * 3], w, C0); C1 = fmaf(rgb[id * 3 + 1], w, C1); C2 = fmaf(rgb[id * 3 + 2], w, C2);
@@ -344,5 +352,18 @@ void orc_composite(int width, int height, const float* bg, const uint32_t* tile_
       const size_t o = (size_t)py * width + px;
       image[o] = fmaf(T, bg[0], C0); image[plane + o] = fmaf(T, bg[1], C1); image[2 * plane + o] = fmaf(T, bg[2], C2);
       final_T[o] = T; n_contrib[o] = last;
+      if (near) near[o] = flags;
     }
+}
+
+void orc_composite(int width, int height, const float* bg, const uint32_t* tile_start, const uint32_t* sorted_ids,
+                   const float* mean2d, const float* conic, const float* opac, const float* rgb, float* image,
+                   float* final_T, uint32_t* n_contrib) {
+  composite_impl(width, height, bg, tile_start, sorted_ids, mean2d, conic, opac, rgb, image, final_T, n_contrib, NULL, 0.f, 0.f);
+}
+
+void orc_composite_diag(int width, int height, const float* bg, const uint32_t* tile_start, const uint32_t* sorted_ids,
+                        const float* mean2d, const float* conic, const float* opac, const float* rgb, float* image,
+                        float* final_T, uint32_t* n_contrib, uint8_t* near, float tol_alpha, float tol_T) {
+  composite_impl(width, height, bg, tile_start, sorted_ids, mean2d, conic, opac, rgb, image, final_T, n_contrib, near, tol_alpha, tol_T);
 }

@@ -114,3 +114,49 @@ def assert_grads_close(got: dict, want: dict, near_gaussians, n: int):
         if near.any():
             assert d[near].max() <= 2e-2 * scale + 1e-7, f"{name}: near-threshold max diff {d[near].max()} vs max ref {scale}"
         assert np.abs(gt - r).sum() <= 2e-4 * np.abs(r).sum() + 1e-6, name
+
+
+# ------------------------------------------------------------------ stated image tolerance (north_star: "within a stated per-pixel L1 tolerance")
+# A pixel is CALM when none of its discrete decisions sits on a threshold in the bit-level spec (oracle/splat_oracle.c
+# orc_composite_diag: no pair with |255 alpha - 1| < 2e-5, no T(1 - alpha) within 2e-5 relative of the 1e-4 stop rule).
+# On calm pixels every implementation of the spec takes the same decisions, so n_contrib is EQUAL and the colour differs
+# by rounding only (exp2-domain alpha, summation order of the segment-parallel forward).
+TOL_CALM = 5e-6            # max over calm pixels of max_c |image - oracle|, [0,1] fp32 RGB (measured: 1.1e-6 at 500 k / 1080p)
+TOL_CALM_T = 5e-6          # same for final_T (measured: 4.2e-7)
+MAX_NEAR_FRACTION = 1e-3   # at most 0.1 % of the pixels may own a threshold decision (BASELINE scenes; a close-up in which EVERY
+                           # pixel ends on the stop rule has proportionally more: its test passes 5e-3)
+TOL_NEAR_ALPHA = 1.0 / 255.0   # a pair that flips at alpha = 1/255 moves a pixel by at most alpha * T * colour <= colour / 255 ...
+TOL_NEAR_STOP = 1e-2           # ... a stop that flips adds or drops one splat of weight alpha * T <= 0.99e-2 (T(1 - alpha) ~ 1e-4, alpha <= 0.99)
+
+
+STATED_TOLERANCE = {"calm_pixel_max_abs": TOL_CALM, "calm_final_T_max_abs": TOL_CALM_T, "n_contrib_on_calm_pixels": "equal",
+                    "max_near_threshold_pixel_fraction": MAX_NEAR_FRACTION, "near_alpha_pixel_max_abs": TOL_NEAR_ALPHA,
+                    "near_stop_pixel_max_abs": TOL_NEAR_STOP + TOL_NEAR_ALPHA, "mean_abs": 1e-4,
+                    "units": "[0,1] fp32 RGB, x max(1, largest SH colour); calm = no decision within 2e-5 of alpha = 1/255 nor 2e-5 (relative) of T = 1e-4"}
+
+
+def image_parity_stats(image, final_T, n_contrib, ref: dict, max_near_fraction: float = MAX_NEAR_FRACTION) -> dict:
+    """HIP forward outputs (numpy: [3][H][W] f32, [H][W] f32, [H][W] u32) against oracle.c_oracle.render()'s dict: the numbers
+    the stated tolerance is about, and `holds` = whether they meet it."""
+    d = np.abs(image - ref["image"]).max(0)
+    dT = np.abs(final_T - ref["final_T"])
+    near = ref["near"]
+    calm = near == 0
+    cmax = max(1.0, float(ref["proj"]["rgb"].max()))         # SH colours are clamped at 0 from below only
+    a_only, stop = ((near & 2) == 0) & ~calm, (near & 2) != 0
+    st = {"pixels": int(d.size), "near_fraction": float((~calm).mean()), "mean_abs": float(np.abs(image - ref["image"]).mean()),
+          "calm_max": float(d[calm].max()), "calm_p999": float(np.quantile(d[calm], 0.999)), "calm_T_max": float(dT[calm].max()),
+          "near_alpha_max": float(d[a_only].max()) if a_only.any() else 0.0, "near_stop_max": float(d[stop].max()) if stop.any() else 0.0,
+          "n_contrib_mismatch_calm": int((n_contrib[calm] != ref["n_contrib"][calm]).sum()),
+          "n_contrib_mismatch_near": int((n_contrib[~calm] != ref["n_contrib"][~calm]).sum()), "colour_max": cmax}
+    st["holds"] = bool(st["n_contrib_mismatch_calm"] == 0 and st["calm_max"] <= TOL_CALM * cmax and st["calm_T_max"] <= TOL_CALM_T
+                       and st["near_fraction"] <= max_near_fraction and st["near_alpha_max"] <= TOL_NEAR_ALPHA * cmax * 1.01 + TOL_CALM
+                       and st["near_stop_max"] <= (TOL_NEAR_STOP + TOL_NEAR_ALPHA) * cmax + TOL_CALM and st["mean_abs"] < 1e-4)
+    return st
+
+
+def image_parity(image, final_T, n_contrib, ref: dict, max_near_fraction: float = MAX_NEAR_FRACTION) -> dict:
+    """Assert the stated tolerance; returns the statistics (printed by the callers so they land in the GPU test log)."""
+    st = image_parity_stats(image, final_T, n_contrib, ref, max_near_fraction)
+    assert st["holds"], st
+    return st

@@ -1,6 +1,7 @@
 """GPU: integer / index work is BIT-EXACT against the C oracle on the same inputs (BASELINE.json
 north_star: "tile/bin indices bit-exact"): posed vertices, triangle frames, radii, tile rectangles,
-per-tile offsets and the per-tile front-to-back order.  Colour/opacity/image are tolerance-level."""
+per-tile offsets and the per-tile front-to-back order, n_contrib on every pixel whose decisions sit on no
+threshold.  Colour / image are tolerance-level, with the tolerance stated per pixel (tests/helpers.py::image_parity)."""
 import numpy as np
 import pytest
 import torch
@@ -85,6 +86,70 @@ def test_bitexact_vs_c_oracle(n, width, height, yaw, seed, identity):
     ids = rast.sorted_ids.cpu().numpy().view(np.uint32)[:D]
     assert np.array_equal(ids, ref["ids"]), "per-tile order differs"
 
-    out = img.cpu().numpy()
-    assert np.abs(out - ref["image"]).mean() < 1e-4
-    assert (rast.n_contrib.cpu().numpy().view(np.uint32) != ref["n_contrib"]).mean() < 1e-3
+    # image, final_T, n_contrib: the STATED tolerance (tests/helpers.py): on pixels whose decisions sit on no threshold n_contrib
+    # is equal and the colour within TOL_CALM; the others are < 0.1 % and each within one splat's weight
+    from helpers import image_parity
+    stats = image_parity(img.cpu().numpy(), rast.final_T.cpu().numpy(), rast.n_contrib.cpu().numpy().view(np.uint32), ref,
+                         max_near_fraction=5e-3 if closeup else 1e-3)    # close-up: every pixel ends on the stop rule
+    print(f"image parity N={n} {width}x{height}: " + ", ".join(f"{k}={v:.3g}" if isinstance(v, float) else f"{k}={v}" for k, v in stats.items()))
+    if n >= 30000:   # the segment-parallel forward (lists longer than 4 x 128 entries) must be exercised
+        assert int(np.diff(ts.astype(np.int64)).max()) > 2048
+
+
+def test_tile_test_is_unobservable_at_full_size():
+    """DESIGN section 3 "Binning": the engine emits a (Gaussian, tile) pair only for tiles that pass the frozen tile test; upstream
+     emits every tile of the 3-sigma rectangle.  At BASELINE's size (300 k, 1080p) on the GPU box: the C
+    oracle composites both list sets -- image and final_T bit-identical; the HIP lists equal the every-tile lists with exactly
+    the pairs `orc_tile_touched` rejects removed, order preserved; and the HIP image holds the stated tolerance against the
+    EVERY-TILE render (so the deviation from upstream's binning rule is not observable in any output but n_contrib, an
+    internal list position)."""
+    import ctypes as C
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig, DeviceFlame
+    from omfs_4d_video_gen_amd.engine.gaussians import GaussianModel, pack_params
+    from omfs_4d_video_gen_amd.engine.rasterizer import Rasterizer, make_camera_struct
+    from oracle import c_oracle as CO
+    n, width, height, seed, t = 300000, 1920, 1080, 0, 2
+    rig = synthetic.make_rig(seed)
+    g = synthetic.make_gaussians(n, rig.faces.shape[0], seed)
+    seq = synthetic.make_flame_sequence(4, seed)
+    cam = synthetic.make_camera(width, height, yaw=0.35)
+    dflame = DeviceFlame(FlameRig.from_synthetic(rig), seq)
+    ccam = make_camera_struct(cam, sh_degree=3, bg=(0.1, 0.2, 0.3))
+    model, rast = GaussianModel(g), Rasterizer(n, width, height)
+    img = rast.forward(model, dflame.face_frames(t, 1)[1][0], ccam)
+    torch.cuda.synchronize()
+    rast.check_status()
+    culled = CO.render(dflame, t, pack_params(g), g["binding"], n, CO.camera(ccam), cull=True)
+    full = CO.render(dflame, t, pack_params(g), g["binding"], n, CO.camera(ccam), cull=False)
+    D_c, D_f = len(culled["ids"]), len(full["ids"])
+    assert D_c < 0.8 * D_f                                        # the test removes a quarter to a third of the pairs ...
+    assert np.array_equal(culled["image"].view(np.uint32), full["image"].view(np.uint32))       # ... and no bit of the image
+    assert np.array_equal(culled["final_T"].view(np.uint32), full["final_T"].view(np.uint32))
+    # the every-tile lists minus the rejected pairs ARE the engine's lists, tile by tile, in order
+    lib, p = CO.lib(), full["proj"]
+    lib.orc_tile_touched.restype = C.c_int
+    lib.orc_tile_touched.argtypes = [C.c_float] * 6 + [C.c_int] * 2
+    gx = (width + 15) // 16
+    tile_of = np.repeat(np.arange(len(full["tile_start"]) - 1), np.diff(full["tile_start"].astype(np.int64)))
+    ids_f = full["ids"].astype(np.int64)
+    rng = np.random.default_rng(3)
+    some = np.sort(rng.choice(D_f, 200000, replace=False))         # the per-pair predicate in Python: a seeded sample of pairs ...
+    m2, con, op = p["mean2d"], p["conic"], p["opac"]
+    keep_s = np.array([lib.orc_tile_touched(m2[i, 0], m2[i, 1], con[i, 0], con[i, 1], con[i, 2], op[i], int(tl % gx), int(tl // gx))
+                       for i, tl in zip(ids_f[some], tile_of[some])], bool)
+    # ... against membership in the culled lists (ids are unique inside a tile: (tile, id) identifies a pair)
+    key_c = np.repeat(np.arange(len(culled["tile_start"]) - 1), np.diff(culled["tile_start"].astype(np.int64))) * n + culled["ids"].astype(np.int64)
+    key_f = tile_of * n + ids_f
+    in_c = np.isin(key_f, key_c)
+    assert np.array_equal(keep_s, in_c[some]) and 0.55 < keep_s.mean() < 0.8
+    # order preserved: dropping the non-members from the every-tile lists gives the culled lists exactly (all pairs)
+    assert int(in_c.sum()) == D_c and np.array_equal(full["ids"][in_c], culled["ids"])
+    # the HIP path: its lists are the culled lists bit for bit, its image holds the stated tolerance against the EVERY-TILE render
+    ts = rast.tile_start.cpu().numpy().view(np.uint32)
+    assert np.array_equal(ts, culled["tile_start"]) and np.array_equal(rast.sorted_ids.cpu().numpy().view(np.uint32)[:D_c], culled["ids"])
+    from helpers import image_parity
+    ref = dict(full)
+    ref["n_contrib"] = culled["n_contrib"]                        # list positions are only comparable within one list set
+    stats = image_parity(img.cpu().numpy(), rast.final_T.cpu().numpy(), rast.n_contrib.cpu().numpy().view(np.uint32), ref)
+    print(f"every-tile vs tile-test lists at {n} / {width}x{height}: D {D_f} -> {D_c} ({100 * (1 - D_c / D_f):.1f} % fewer), image bit-identical; "
+          f"HIP vs every-tile render: calm max {stats['calm_max']:.3g}, near fraction {stats['near_fraction']:.3g}")

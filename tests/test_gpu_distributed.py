@@ -210,3 +210,27 @@ def test_three_exchange_modes_give_the_same_replicas():
         ends[mode] = p0
     for mode in ("full", "sharded"):
         assert np.allclose(ends[mode], ends["compact"], rtol=2e-4, atol=2e-6), (mode, np.abs(ends[mode] - ends["compact"]).max())
+
+
+def test_bench_two_ranks_end_to_end_on_one_card():
+    """`python bench.py --gpus 2 ...` end to end: the parent starts two ranks, both share the box's one card
+    (OMFS_DIST_BACKEND=gloo: functional rehearsal, no RCCL link involved), rank 0 prints ONE JSON line that says what ran."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMFS_DIST_BACKEND="gloo", OMFS_DP_EXCHANGE="compact")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no_cpu_baseline",
+                        "--n_gaussians", "60000", "--width", "640", "--height", "360", "--render_frames", "8", "--profile_steps", "4"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["warmup"] == 2 and out["scaling"] == "weak"
+    assert out["replicas_in_sync"] is True
+    assert out["config"]["parallelism"].startswith("dp2") and "all-gather" in out["config"]["parallelism"]     # names the exchange
+    assert out["value"] > 0 and abs(out["value"] - 2 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-2 * out["value"]
+    assert "allreduce" in out["stages_ms"] and out["roofline"]["kernel"] != "allreduce"
+    assert out["aux"]["render_surgery_fps"] > 0

@@ -198,8 +198,8 @@ def test_training_with_densification_under_a_small_pair_capacity(dataset, tmp_pa
     assert "are redone" in r.stdout and "densify:" in r.stdout and "iteration 60/60" in r.stdout, r.stdout[-3000:]
     ck = torch.load(m / "chkpnt60.pth", weights_only=True)
     n = int(ck["binding"].shape[0])
-    assert n > 12000 and ck["params"].shape == (59, (n + 255) // 256 * 256) and ck["adam_m"].shape == ck["params"].shape
-    assert torch.isfinite(ck["params"][:, :n]).all() and int(ck["binding"].max()) < 10312
+    assert n > 12000 and ck["params"].shape == (59, n) and ck["adam_m"].shape == ck["params"].shape      # checkpoints hold the n columns
+    assert torch.isfinite(ck["params"][:, :n]).all()
     assert (m / "point_cloud" / "iteration_35" / "point_cloud.ply").exists() and (m / "point_cloud" / "iteration_60" / "point_cloud.ply").exists()
     # the kept iterations rendered real lists: the loss of the last interval is below the first's
     losses = [float(x) for x in re.findall(r"loss=([0-9.]+)", r.stdout)]

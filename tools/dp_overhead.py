@@ -1,7 +1,9 @@
-"""Fixed cost of the data-parallel exchange path on ONE GPU: the bench workload stepped with the exchange forced over a
-one-rank RCCL group (OMFS_DP_FORCE=1), compact and full, against the plain step.  What is measured is everything but the
-link time: the collectives' launches, their stream hand-overs, the rebuilt SH gradients and the split Adam.
-usage (GPU box): python tools/dp_overhead.py [--steps 200]"""
+"""Fixed cost of the data-parallel exchange path on ONE GPU: the bench workload (FLAME fine-tuning on, as the headline) stepped
+with the exchange forced over a one-rank RCCL group (OMFS_DP_FORCE=1) -- compact, full, sharded -- against the plain step.
+What is measured is everything but the link time: the collectives' launches, their stream hand-overs, the rebuilt SH
+gradients and the split Adam; and, beside the GPU time per step, the HOST's enqueue time per step (the Python loop's own
+wall clock before the final sync): the exchange path must not become host bound at 8 ranks.
+usage (GPU box): python tools/dp_overhead.py [--steps 200] [--out profiles/r04_dp_overhead.json]"""
 import argparse
 import json
 import os
@@ -37,20 +39,24 @@ def run(mode, steps):
     else:
         os.environ.pop("OMFS_DP_FORCE", None)
     t = Trainer(rig, seq, synthetic.make_gaussians(N, rig.n_faces, 0), views, W, H, iterations=30000, start_sh_degree=3,
-                rank=0, world_size=1, process_group=pg)
+                rank=0, world_size=1, process_group=pg, finetune_flame=True)
     for _ in range(20):
         t.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         t.step()
+    t1 = time.perf_counter()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    t2 = time.perf_counter()
+    del t
+    return {"ms_per_step": round((t2 - t0) / steps * 1e3, 4), "host_enqueue_ms_per_step": round((t1 - t0) / steps * 1e3, 4)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--out", default="")
     a = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -58,8 +64,15 @@ def main():
     os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    out = {m: round(run(m, a.steps), 4) for m in ("plain", "compact", "full")}
-    print(json.dumps({"ms_per_step": out, "note": "one-rank RCCL group: exchange path without link time"}))
+    out = {m: run(m, a.steps) for m in ("plain", "compact", "full", "sharded")}
+    base = out["plain"]["ms_per_step"]
+    rec = {"workload": "bench default (300k Gaussians, 1920x1080, 16 views, FLAME fine-tuning on)", "steps": a.steps, "modes": out,
+           "overhead_us_over_plain": {m: round((v["ms_per_step"] - base) * 1e3, 1) for m, v in out.items() if m != "plain"},
+           "note": "one-rank RCCL group (OMFS_DP_FORCE=1): the exchange path without link time; UNMEASURED on more than one GPU"}
+    print(json.dumps(rec))
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump(rec, f, indent=1)
     dist.destroy_process_group()
 
 
