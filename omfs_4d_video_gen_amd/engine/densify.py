@@ -116,7 +116,7 @@ class DensityController:
         m.params, m.binding, m.n, m.n_pad = params, binding, n, n_pad
         m.order = None                 # the compaction re-indexed the cloud: the storage order is the order from here on
         t.opt.m, t.opt.v = adam_m, adam_v
-        t.grads = torch.zeros(NPLANES, n_pad, device=params.device)
+        t.alloc_grads(n_pad)
         t.densify_stats = torch.zeros(2, n_pad, device=params.device)
         t.invalidate_graphs()          # captured iterations refer to the buffers just replaced
         # stale projections beyond the new count must not look visible

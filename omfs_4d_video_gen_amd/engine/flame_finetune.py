@@ -47,12 +47,8 @@ class FlameFineTuner:
         self.params = {"expr": self.expr, "pose": self.pose, "translation": self.translation}
         # the three gradient tensors are views of ONE buffer: data-parallel ranks sum them with a single small all-reduce
         # (three latency-bound collectives per iteration otherwise)
-        sizes = {k: v.numel() for k, v in self.params.items()}
-        self.grad_flat = torch.zeros(sum(sizes.values()), device=dev)
-        self.grad, off = {}, 0
-        for k, v in self.params.items():
-            self.grad[k] = self.grad_flat[off:off + sizes[k]].view(v.shape)
-            off += sizes[k]
+        self.n_grad = sum(v.numel() for v in self.params.values())
+        self._bind_grads(torch.zeros(self.n_grad, device=dev))
         self.m = {k: torch.zeros_like(v) for k, v in self.params.items()}
         self.v = {k: torch.zeros_like(v) for k, v in self.params.items()}
         self.lr = {**FLAME_LR, **(lr or {})}
@@ -86,6 +82,25 @@ class FlameFineTuner:
         self._adam_args = (arr([self.params[k] for k in keys]), arr([self.grad[k] for k in keys]), arr([self.m[k] for k in keys]),
                            arr([self.v[k] for k in keys]), (C.c_int * 3)(*[self.params[k].numel() for k in keys]),
                            (C.c_float * 3)(*[float(self.lr[k]) for k in keys]))
+
+    def _bind_grads(self, flat: torch.Tensor):
+        self.grad_flat = flat
+        self.grad, off = {}, 0
+        for k, v in self.params.items():
+            self.grad[k] = flat[off:off + v.numel()].view(v.shape)
+            off += v.numel()
+
+    def rebind_grads(self, flat: torch.Tensor):
+        """Move the three gradient tensors into `flat` (zeroed, >= n_grad floats): the data-parallel trainer puts them in front
+        of the Gaussians' gradient planes, in ONE allocation, so that one all-reduce sums both (a small collective of its own
+        costs a launch, two stream hand-overs and its latency on the links every iteration)."""
+        if flat.numel() < self.n_grad or flat.dtype != torch.float32:
+            raise ValueError("gradient buffer too small")
+        flat[:self.n_grad].copy_(self.grad_flat)
+        self._bind_grads(flat[:self.n_grad])
+        keys = ("expr", "pose", "translation")
+        a = self._adam_args
+        self._adam_args = (a[0], (C.c_void_p * 3)(*[L.ptr(self.grad[k]) for k in keys]), a[2], a[3], a[4], a[5])
 
     def refresh_rotmats(self):
         """All timesteps: axis-angle poses -> the rotation matrices the forward kernels read."""

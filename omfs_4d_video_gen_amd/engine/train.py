@@ -125,7 +125,7 @@ class Rollback:
             # a densification lies inside the interval (it may have kept n_pad and changed only n): put the old buffers back
             m.params, m.binding, m.n, m.n_pad = s["params"].clone(), s["binding"].clone(), s["n"], int(s["params"].shape[1])
             t.opt.m, t.opt.v = s["m"].clone(), s["v"].clone()
-            t.grads = torch.zeros_like(m.params)
+            t.alloc_grads(m.n_pad)
             t.rast.g2[m.n:].zero_()
         else:
             m.params.copy_(s["params"]); t.opt.m.copy_(s["m"]); t.opt.v.copy_(s["v"]); m.binding.copy_(s["binding"]); m.n = s["n"]

@@ -115,7 +115,9 @@ class Trainer:
         self.lr_planes = default_lr_planes(position_lr=position_lr_init)
         self.pos_lr = (position_lr_init, position_lr_final)
         self.opt = Adam(self.model, self.lr_planes)
-        self.grads = torch.zeros(NPLANES, self.model.n_pad, device=self.device)
+        self.flame_ft = None           # FLAME-parameter fine-tuning (engine/flame_finetune.py)
+        self._grad_head = 0            # floats in front of the planes inside grad_store (the FLAME gradients, data parallel)
+        self.alloc_grads(self.model.n_pad)
         self.sh_degree_max, self.sh_every, self.sh_degree = sh_degree_max, sh_increase_every, start_sh_degree
         self.step_idx = 0
         self.timer = StageTimer(False)
@@ -149,6 +151,9 @@ class Trainer:
         # whole iterations as hipGraphs (one per view and buffer parity; single GPU): the step-dependent scalars -- position
         # learning rate, Adam bias corrections -- live in an omfs_step_state on the device, advanced by the graph's first node
         self.use_graph = world_size == 1 and os.environ.get("OMFS_STEP_GRAPH", "0") == "1"
+        # OMFS_GRAPH_ITERS=G (even, single-view training only): ONE graph holds G consecutive iterations, which divides the idle
+        # time ROCm leaves in front of every graph launch (~0.1 ms) by G; a `step()` that replays advances G iterations
+        self.graph_iters = max(1, int(os.environ.get("OMFS_GRAPH_ITERS", "1"))) if len(views) == 1 else 1
         self._graphs, self._graph_seen = {}, set()
         self._state = torch.zeros(L.STEP_STATE_WORDS, dtype=torch.int32, device=self.device)
         self._state_step, self._frames_ready = -1, None
@@ -158,10 +163,14 @@ class Trainer:
         self._events = [(torch.cuda.Event(), torch.cuda.Event()), (torch.cuda.Event(), torch.cuda.Event())]
         self._prefetch = None
         self._target_f32 = None
-        self.flame_ft = None           # FLAME-parameter fine-tuning (engine/flame_finetune.py)
         if finetune_flame:
             from .flame_finetune import FlameFineTuner
             self.flame_ft = FlameFineTuner(self.dflame, flame_params, flame_lr)
+            if self.dp and not self.sharded_dp:
+                # data parallel: the FLAME gradients live in front of the Gaussians' gradient planes, in one allocation -- the
+                # all-reduce of the planes (14 of them in the compact exchange, all 59 in the full one) carries them along
+                self._grad_head = (self.flame_ft.n_grad + 63) // 64 * 64
+                self.alloc_grads(self.model.n_pad)
         # A fixed FLAME sequence is posed ONCE: the triangle frames of every timestep stay resident ([T][F][16] fp32, 0.65 MB
         # per timestep at FLAME's size -- a few hundred MB of the 288 GB), and a step starts with its projection instead of
         # a cross-stream wait for the frames (15 us of idle queue per iteration in the kernel trace).  Sequences too long for
@@ -176,6 +185,14 @@ class Trainer:
 
     def _cam(self, view: View, sh_degree: int):
         return _cached_camera(self._cams, view.camera, sh_degree, self.bg)
+
+    def alloc_grads(self, n_pad: int) -> None:
+        """(Re)allocate the gradient planes [59][n_pad] (construction, densification, rollback).  One allocation `grad_store` =
+        [FLAME gradients, padded to 64 floats | 59 planes]: with data-parallel FLAME fine-tuning one all-reduce sums both."""
+        self.grad_store = torch.zeros(self._grad_head + NPLANES * n_pad, device=self.device)
+        self.grads = self.grad_store[self._grad_head:].view(NPLANES, n_pad)
+        if self._grad_head and self.flame_ft is not None:
+            self.flame_ft.rebind_grads(self.grad_store[:self._grad_head])
 
     def _frame_key(self, step: int):
         from .distributed import view_index
@@ -268,12 +285,12 @@ class Trainer:
         """Capture iteration `it` (its view, camera, buffers; the step-dependent scalars live in self._state on the device).
         With FLAME fine-tuning the graph expects the frames of this view in buffer set it&1 and leaves the next view's in the
         other one: FLAME backward + FLAME Adam + next FLAME forward fork onto the side stream under the Gaussians' Adam."""
+        it0 = it
         view = self.view_for_step(it)
         cam = self._cam(view, self.sh_degree)
         r, ft, lib = self.rast, self.flame_ft, L.load()
         sched = L.LrScheduleC(float(self.pos_lr[0]), float(self.pos_lr[1]), int(self.iterations), float(self.opt.ap.beta1), float(self.opt.ap.beta2))
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        def one_iteration(it):
             s = L.stream_ptr()
             L.check(lib.omfs_step_advance(L.ptr(self._state), sched, L.ptr(self._next_table), int(self._next_table.shape[0]),
                                           L.ptr(self._next_t), s), "omfs_step_advance")
@@ -335,16 +352,21 @@ class Trainer:
                 else:
                     adam()
                     flame_tail()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for j in range(self.graph_iters):
+                one_iteration(it0 + j)
         return graph
 
-    def _step_graph(self, it: int) -> bool:
-        """Replay (capturing it on the second visit of its key) the graph of iteration `it`; False: the caller steps eagerly."""
+    def _step_graph(self, it: int) -> int:
+        """Replay (capturing it on the second visit of its key) the graph of iteration `it`; returns the number of iterations
+        the replay ran (graph_iters), 0: the caller steps eagerly."""
         key = self._graph_key(it)
         graph = self._graphs.get(key)
         if graph is None:
             if key not in self._graph_seen:      # first visit: eager (one-off work such as function attributes happens there)
                 self._graph_seen.add(key)
-                return False
+                return 0
             if len(self._graphs) > 4 * max(len(self.views), 1):
                 self._graphs.clear()
         view = self.view_for_step(it)
@@ -360,7 +382,7 @@ class Trainer:
                 torch.cuda.current_stream().wait_stream(self._side_stream)
                 self.dflame.slot = it & 1
                 self._pose_frames(it)
-        if not (self._table_base <= it and it + 1 < self._table_base + int(self._next_table.shape[0])) or self._state_step != it:
+        if not (self._table_base <= it and it + self.graph_iters < self._table_base + int(self._next_table.shape[0])) or self._state_step != it:
             # (re)build the device-resident schedule: the FLAME timestep of the view of every iteration from `it` on; the graph's
             # first node reads the entry of iteration it + 1 (the view it poses last) -- nothing is copied between replays
             torch.cuda.synchronize(self.device)
@@ -379,12 +401,13 @@ class Trainer:
             torch.cuda.synchronize(self.device)
         elif dbg == "fence":
             self._next_t.add_(0)          # an eager kernel between two replays
-        self.opt.step_count += 1
+        G = self.graph_iters
+        self.opt.step_count += G
         if ft is not None:
-            ft.step_count += 1
-            self._frames_ready = (it + 1, self.view_for_step(it + 1).timestep)
-        self._state_step = it + 1
-        return True
+            ft.step_count += G
+            self._frames_ready = (it + G, self.view_for_step(it + G).timestep)
+        self._state_step = it + G
+        return G
 
     def step(self) -> None:
         """One training iteration of this rank (enqueue only)."""
@@ -394,8 +417,9 @@ class Trainer:
             self.sh_degree += 1
         if self._graph_eligible():
             try:
-                if self._step_graph(it):
-                    self.step_idx += 1
+                done = self._step_graph(it)
+                if done:
+                    self.step_idx += done
                     return
             except Exception as e:      # a failed capture must not cost the run: say so, go on eagerly
                 print(f"[engine] hipGraph capture of the training iteration failed ({type(e).__name__}: {e}); continuing without graphs")
@@ -527,7 +551,8 @@ class Trainer:
             from .distributed import allgather_into_, allreduce_sum_
             if self.compact_dp:
                 # 14 contiguous planes, asynchronously: the 45 rebuilt SH planes are updated while they are on the links
-                reduce14 = allreduce_sum_(self.grads[:P_SH + 3], self.pg, async_op=True)
+                # (with FLAME fine-tuning: the FLAME gradients in front of plane 0 travel in the same collective)
+                reduce14 = allreduce_sum_(self.grad_store[:self._grad_head + (P_SH + 3) * self.model.n_pad], self.pg, async_op=True)
                 gather.wait()
                 L.check(lib.omfs_sh_rest_grads(g, L.ptr(face_xf), self.dflame.rig.n_faces, L.ptr(self.cam_pos_table), pat[1],
                                                L.ptr(self.drgb_all), self.sh_degree, L.ptr(self.grads), s), "omfs_sh_rest_grads")
@@ -541,8 +566,8 @@ class Trainer:
                     self._gshard = torch.empty(S, device=self.device)
                 reduce_scatter_sum_(self._gshard, flat, self.pg)
             else:
-                allreduce_sum_(self.grads, self.pg)
-            if ft is not None and not self.compact_dp:   # every rank touched a different timestep: dense (tiny) tensors, summed
+                allreduce_sum_(self.grad_store, self.pg)      # all 59 planes (+ the FLAME gradients in front of them)
+            if ft is not None and self.sharded_dp:       # every rank touched a different timestep: dense (tiny) tensors, summed
                 allreduce_sum_(ft.grad_flat, self.pg)          # expr, pose, translation gradients: one buffer
             tm.mark("allreduce")
         lr = expon_lr(it, self.pos_lr[0], self.pos_lr[1], self.iterations)
@@ -551,9 +576,6 @@ class Trainer:
         if self.compact_dp:
             self.opt.begin_step(1.0 / self.world)
             self.opt.apply_planes(self.grads, P_SH + 3, NPLANES - (P_SH + 3))     # the rebuilt SH planes
-            if ft is not None:
-                from .distributed import allreduce_sum_
-                allreduce_sum_(ft.grad_flat, self.pg)          # expr, pose, translation gradients: one buffer
             reduce14.wait()
             self.opt.apply_planes(self.grads, 0, P_SH + 3)
         elif self.sharded_dp:

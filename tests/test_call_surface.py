@@ -214,6 +214,7 @@ def test_rollback_survives_a_densification_that_keeps_n_pad():
     t = NS(model=cloud(1000, 1024, 1.0), flame_ft=None, densify_stats=torch.zeros(2, 1024), step_idx=7, sh_degree=1,
            opt=NS(m=torch.zeros(59, 1024), v=torch.zeros(59, 1024), step_count=7), grads=torch.zeros(59, 1024),
            rast=NS(g2=torch.ones(2048, 4)), _prefetch=None, _frames_ready=None, _state_step=-1, invalidate_graphs=lambda: None)
+    t.alloc_grads = lambda n_pad: setattr(t, "grads", torch.zeros(59, n_pad))
     rb = Rollback(t)
     rb.take(7)
 
