@@ -194,6 +194,12 @@ typedef struct omfs_raster_buffers {
   uint32_t* n_visible;    /* optional [1]: number of Gaussians with radius > 0 in this view; omfs_project_fwd clears it,
                              omfs_bin_count accumulates it (what omfs_count_visible computes, without its two
                              dispatches); may be NULL                                                              */
+  uint32_t* quad_depth;   /* optional [n_tiles][4] (ABI 7): deepest last contributor of every (tile, 8x8 quadrant), written by
+                             omfs_composite_fwd in training mode and read by omfs_composite_bwd (NULL: the library keeps the
+                             table inside `keys`).  A caller that hands in a buffer of its own PER VIEW and leaves it alone
+                             between two visits of the view also gives the forward a HINT: the few quadrants that went deep
+                             last time are walked at raised wave priority (speed only: results do not depend on the content,
+                             which may be anything -- zero it once).                                                    */
 } omfs_raster_buffers;
 #define OMFS_RB_FORWARD_ONLY 1u
 

@@ -59,7 +59,7 @@ class RasterBuffersC(C.Structure):
                 ("dup_capacity", C.c_uint32), ("sort_lds_pairs", C.c_uint32), ("status", c_void_p),
                 ("seg_ckpt", c_void_p), ("order_seg0", c_void_p), ("seg_capacity", C.c_uint32),
                 ("image", c_void_p), ("final_T", c_void_p), ("n_contrib", c_void_p), ("flags", C.c_uint32),
-                ("n_visible", c_void_p)]
+                ("n_visible", c_void_p), ("quad_depth", c_void_p)]
 
 
 class GradBuffersC(C.Structure):

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
                                                            float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                                                            float4* __restrict__ seg_ckpt, int keep_ckpt,
                                                            const uint32_t* __restrict__ order_seg0, uint32_t* __restrict__ seg_table,
-                                                           uint32_t* __restrict__ quad_max) {
+                                                           uint32_t* __restrict__ quad_max, int depth_hint) {
   // staged records live at index 1 .. 64; index 0 is a record that no pixel can hit (log2 opacity -1e30): the visit
   // loop takes FOUR list entries per iteration and pads an incomplete batch with it (ffs of an empty bit mask is 0)
   __shared__ float4 s0[WB + 1];
@@ -215,6 +215,16 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
   const float fx = (float)px, fy = (float)py;
   float open = inside ? 1.f : 0.f;               // 1.0 while the pixel takes splats (see the walk)
   const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
+#ifndef OMFS_FWD_HINT_DEPTH
+#define OMFS_FWD_HINT_DEPTH 384
+#endif
+#ifndef OMFS_FWD_HINT_PRIO
+#define OMFS_FWD_HINT_PRIO 3
+#endif
+  // The launch is as long as its longest walks (quadrants that never saturate: 400-512 entries), and those crawl while six
+  // equally old waves share their SIMD.  Which quadrants they are is known from the last visit of this view (the caller's
+  // per-view depth table: a hint, the results do not depend on it): they issue ahead of their neighbours.
+  if (depth_hint && quad_max[tile * 4 + quad] >= (uint32_t)OMFS_FWD_HINT_DEPTH) __builtin_amdgcn_s_setprio(OMFS_FWD_HINT_PRIO);
   // Segment table for the backward pass (one wave per (segment, quadrant), which otherwise finds its tile by a 13-step bisection
   // of order_seg0 -- 13 dependent L2 round trips at the head of waves that visit a dozen splats): entry of global segment
   // order_seg0[upos] + k = tile | k << 16; lists of 65535 segments or more (> 8.3 M entries in one tile) get the sentinel that
@@ -1280,6 +1290,7 @@ static uint32_t* segment_table(const omfs_raster_buffers* rb) {
 }
 // ... followed by one word per (tile, quadrant): the quadrant's depth (see composite_fwd_kernel)
 static uint32_t* quadrant_depths(const omfs_raster_buffers* rb, int n_tiles) {
+  if (rb->quad_depth) return rb->quad_depth;       // the caller's own table (per view: also the forward's priority hint)
   return (segment_table(rb) && 2ull * rb->dup_capacity >= (unsigned long long)rb->seg_capacity + 4ull * (unsigned long long)n_tiles)
              ? rb->keys + rb->seg_capacity : nullptr;
 }
@@ -1306,7 +1317,8 @@ extern "C" int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buff
   hipLaunchKernelGGL(composite_fwd_kernel, dim3(n_tiles * 4), dim3(64), 0, (hipStream_t)stream, cc, rb->tile_order,
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
                      (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt,
-                     rb->order_seg0, keep_ckpt ? segment_table(rb) : nullptr, keep_ckpt ? quadrant_depths(rb, n_tiles) : nullptr);
+                     rb->order_seg0, keep_ckpt ? segment_table(rb) : nullptr, keep_ckpt ? quadrant_depths(rb, n_tiles) : nullptr,
+                     (keep_ckpt && rb->quad_depth && !getenv("OMFS_NO_FWD_HINT")) ? 1 : 0);
   OMFS_CHECK_HIP(hipGetLastError());
   // quadrants whose list is longer than FWD_SEQ_SEGS segments and still unsaturated (the rest exit at once)
   hipLaunchKernelGGL(composite_fwd_deep_kernel, dim3(n_tiles * 4), dim3(DEEP_WAVES * 64), 0, (hipStream_t)stream, cc, rb->tile_order,

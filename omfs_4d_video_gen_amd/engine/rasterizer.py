@@ -75,7 +75,7 @@ class Rasterizer:
                                    L.ptr(self.keys), L.ptr(self.keys_tmp), L.ptr(self.sorted_ids),
                                    self.dup_capacity, int(sort_lds_pairs or os.environ.get("OMFS_SORT_LDS_PAIRS", 0)), L.ptr(self.status),
                                    L.ptr(self.seg_ckpt), L.ptr(self.order_seg0), self.seg_capacity, L.ptr(self.image),
-                                   L.ptr(self.final_T), L.ptr(self.n_contrib), 0, 0)
+                                   L.ptr(self.final_T), L.ptr(self.n_contrib), 0, 0, 0)
         # backward-side buffers are created on first use
         self.dsplat = None
         self.dimage = None

@@ -166,3 +166,54 @@ def test_both_backward_implementations_agree():
     for q in range(9):
         scale = np.abs(a[:, q]).max()
         assert np.abs(a[:, q] - b[:, q]).max() <= 1e-5 * scale + 1e-12, (q, np.abs(a[:, q] - b[:, q]).max(), scale)
+
+
+def test_quadrant_depth_table_is_exact_and_its_hint_changes_nothing():
+    """omfs_raster_buffers.quad_depth (ABI 7): the forward leaves the deepest last contributor of every (tile, quadrant) -- equal to
+    the maximum of n_contrib over the quadrant's pixels -- and, when the caller keeps the table from one visit of a view to the
+    next, reads it first as a priority hint.  Whatever the table held before (zeros, the true depths, garbage), image, final_T,
+    n_contrib and the backward's gradient records are the same bits (the records up to the order of their float atomics)."""
+    from omfs_4d_video_gen_amd import _lib as L
+    from omfs_4d_video_gen_amd.engine import synthetic
+    from omfs_4d_video_gen_amd.engine.flame_rig import DeviceFlame, FlameRig
+    from omfs_4d_video_gen_amd.engine.gaussians import GaussianModel
+    from omfs_4d_video_gen_amd.engine.rasterizer import Rasterizer, make_camera_struct
+    N, W, H = 60000, 330, 250          # not a multiple of the tile size: quadrants outside the image exist
+    rig = synthetic.make_rig(6)
+    g = synthetic.make_gaussians(N, rig.faces.shape[0], 6)
+    dflame = DeviceFlame(FlameRig.from_synthetic(rig), synthetic.make_flame_sequence(3, 6))
+    ccam = make_camera_struct(synthetic.make_camera(W, H, yaw=-0.3), sh_degree=3, bg=(0.0, 0.1, 0.0))
+    model, rast = GaussianModel(g), Rasterizer(N, W, H)
+    fxf = dflame.face_frames(2, 1)[1][0]
+    rast._ensure_bwd()
+    rast.dimage.copy_(torch.randn(3, H, W, generator=torch.Generator().manual_seed(9)).cuda())
+    gb = L.GradBuffersC(L.ptr(rast.dsplat), 0, L.ptr(rast.dimage), 0, 0, 0)
+    qd = torch.zeros(rast.n_tiles, 4, dtype=torch.int32, device="cuda")
+    ref = None
+    for fill in ("library-owned", "zeros", "kept", "garbage"):
+        if fill == "library-owned":
+            rast.rb.quad_depth = 0
+        else:
+            rast.rb.quad_depth = L.ptr(qd)
+            if fill == "garbage":
+                qd.copy_(torch.randint(0, 1 << 30, qd.shape, dtype=torch.int32, generator=torch.Generator().manual_seed(1)).cuda())
+        rast.forward(model, fxf, ccam)
+        rast.dsplat.zero_()
+        L.check(L.load().omfs_composite_bwd(ccam, rast.rb, gb, L.stream_ptr()), "omfs_composite_bwd")
+        torch.cuda.synchronize()
+        rast.check_status()
+        got = (rast.image.cpu().numpy().copy(), rast.final_T.cpu().numpy().copy(), rast.n_contrib.cpu().numpy().copy(), rast.dsplat.cpu().numpy().copy())
+        if fill != "library-owned":
+            # the table now holds the exact depths: per (tile, quadrant) the maximum of n_contrib over its pixels
+            nc = np.zeros((rast.gy * 16, rast.gx * 16), np.int64)
+            nc[:H, :W] = got[2].view(np.uint32)
+            want = nc.reshape(rast.gy, 2, 8, rast.gx, 2, 8).max(axis=(2, 5)).transpose(0, 2, 1, 3).reshape(rast.n_tiles, 4)   # [tile][qy*2+qx]
+            assert np.array_equal(qd.cpu().numpy().view(np.uint32).astype(np.int64), want), fill
+        if ref is None:
+            ref = got
+            continue
+        for a, b in zip(ref[:3], got[:3]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), fill
+        scale = np.abs(ref[3]).max(0) + 1e-30
+        assert (np.abs(ref[3] - got[3]).max(0) <= 1e-5 * scale).all(), fill
+    rast.rb.quad_depth = 0
