@@ -213,7 +213,7 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
     return;
   }
   const float fx = (float)px, fy = (float)py;
-  float open = inside ? 1.f : 0.f;               // 1.0 while the pixel takes splats (see the walk)
+  float Tl = inside ? 1.f : 0.f;                 // the transmittance while the pixel takes splats, 0 once it is done (or outside the image)
   const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
 #ifndef OMFS_FWD_HINT_DEPTH
 #define OMFS_FWD_HINT_DEPTH 384
@@ -314,7 +314,8 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
       // ONE instruction per ~4.3 cycles and SIMD however many waves are resident (tools/micro/valu_rate.hip): the walk
       // used to carry 23 scalar instructions per entry next to its 26 vector ones.
       //   the four raw alphas do not depend on the pixel state (0 unless the splat is hit) and are evaluated side by side;
-      //   `open` is 1.0 while the pixel takes splats and 0.0 once it is done (or outside the image): alpha * open is exact;
+      //   `Tl` is the pixel's transmittance while it takes splats and 0 once it is done (or outside the image): a done pixel
+      //   "stops" again on every entry (Tn = 0), which composites nothing and leaves T, the value it ended on, alone;
       //   with alpha == 0, Tn == T and w == 0 (T >= 1e-4 always: no false stop); w > 0 exactly when the splat was composited.
       float ar[4];
 #pragma unroll
@@ -329,9 +330,9 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float alpha = ar[u] * open;
+        const float alpha = ar[u];
 #ifdef OMFS_DEBUG_COUNTERS
-        { const unsigned long long hb = __ballot(alpha > 0.f); OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb));
+        { const unsigned long long hb = __ballot(alpha > 0.f && Tl != 0.f); OMFS_DBG_ADD(3, 1); OMFS_DBG_ADD(4, hb != 0ull); OMFS_DBG_ADD(5, __popcll(hb));
           if (jx[u]) {
             int nsb = 0, nfl = 0;
             for (int sb = 0; sb < 4; ++sb) { nsb += (hb & sbl[sb]) != 0ull; nfl += ((ms[sb] >> (jx[u] - 1)) & 1ull) && (live & sbl[sb]); }
@@ -341,25 +342,25 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
             if (nl) OMFS_DBG_ADD(27 + nl, 1);
           } }
 #endif
-        const float Tn = T * (1.f - alpha);
+        const float Tn = Tl * (1.f - alpha);
         // the splat that would take T below the threshold is not composited: weight 0, T and last stay, the pixel is done
         const bool stop = Tn < 1e-4f;
-        const float w = stop ? 0.f : alpha * T;
+        const float w = stop ? 0.f : alpha * Tl;
         C0 = fma_(rc[u].z, w, C0);
         C1 = fma_(rc[u].w, w, C1);
         C2 = fma_(rb[u], w, C2);
         T = stop ? T : Tn;
-        open = stop ? 0.f : open;
+        Tl = stop ? 0.f : Tn;
         last = w > 0.f ? base + (uint32_t)jx[u] : last;
       }
       // saturation is looked at once per batch
-      const unsigned long long nl = __ballot(open != 0.f);
+      const unsigned long long nl = __ballot(Tl != 0.f);
       if (nl != live) {
         live = nl;
         m &= combine(live);
       }
     }
-    live = __ballot(open != 0.f);
+    live = __ballot(Tl != 0.f);
     OMFS_DBG_PHASE(2);
     OMFS_DBG_STEP((b - beg) / WB);
   }
