@@ -251,6 +251,9 @@ typedef struct omfs_grad_buffers {
                              rebuild the summed gradient with omfs_sh_rest_grads; may be NULL                     */
 } omfs_grad_buffers;
 
+/* Must follow omfs_composite_fwd of the SAME lists run in training mode (flags without OMFS_RB_FORWARD_ONLY), with `keys`
+ * untouched in between: besides the checkpoints the forward leaves the backward's work tables there (ABI 7: segment -> (tile,
+ * k) and, unless the caller passes rb->quad_depth, the quadrant depths), which the next frame's binning overwrites.        */
 int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, const omfs_grad_buffers* gb, void* stream);
 
 /* FLAME fine-tuning (upstream GaussianAvatars optimises the per-timestep FLAME parameters together with the
