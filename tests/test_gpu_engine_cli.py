@@ -236,3 +236,46 @@ def test_renderer_uses_each_frames_own_camera():
             b, ev = r.render_async(View(cams[(i + 2) % T], (i + 2) % T), rgb8=True)
             ev.synchronize()
             assert torch.equal(a, want[i]) and torch.equal(b.cpu(), want[(i + 2) % T]), (n_streams, i)
+
+
+def test_engine_clis_under_a_two_rank_launch(dataset, tmp_path):
+    """SURVEY section 8e at the level of the engine's own command lines (configs 3 and 4 in small): `engine/train.py` and `engine/render.py`
+    started by `torch.distributed.run --nproc-per-node 2` (both ranks on the box's one card, OMFS_DIST_BACKEND=gloo).  Training:
+    views shard across the ranks, the run completes, rank 0 writes the point cloud and the checkpoint, the loss falls.  Rendering:
+    frame f belongs to rank f mod 2, the union is the whole split, and every frame is the SAME BYTES a single process renders."""
+    import socket
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMFS_SYNTHETIC_RIG="1", PYTHONPATH=str(ROOT), OMFS_DIST_BACKEND="gloo")
+    eng = ROOT / "omfs_4d_video_gen_amd" / "engine"
+
+    def launch(script, *args):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(eng / script), *args]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+        return r.stdout + r.stderr
+    m = tmp_path / "m"
+    out = launch("train.py", "--source_path", str(dataset), "--model_path", str(m), "--bind_to_mesh", "--white_background",
+                 "--n_gaussians", "12000", "--log_every", "10", "--iterations", "60", "--checkpoint_iterations", "60", "--no_densify")
+    losses = [float(x) for x in re.findall(r"loss=([0-9.]+)", out)]
+    assert "iteration 60/60" in out and np.mean(losses[-2:]) < np.mean(losses[:2]), losses
+    assert (m / "point_cloud" / "iteration_60" / "point_cloud.ply").exists() and (m / "chkpnt60.pth").exists()
+    assert json.loads((m / "cfg_args.json").read_text())["world_size"] == 2
+    # render the train split with two ranks, then with one process into a copy of the model directory
+    out = launch("render.py", "--source_path", str(dataset), "--model_path", str(m), "--bind_to_mesh", "--skip_val", "--skip_test")
+    counts = sorted(int(x) for x in re.findall(r"rendered (\d+) train frames", out))
+    assert counts == [27, 27], out[-1500:]                              # 54 train frames: f mod 2
+    two = m / "train" / "ours_60" / "renders"
+    names = sorted(os.listdir(two))
+    assert names == [f"{i:05d}.png" for i in range(54)]
+    m1 = tmp_path / "m1"
+    shutil.copytree(m, m1, ignore=shutil.ignore_patterns("train"))
+    r = subprocess.run([sys.executable, str(eng / "render.py"), "--source_path", str(dataset), "--model_path", str(m1), "--bind_to_mesh",
+                        "--skip_val", "--skip_test"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    one = m1 / "train" / "ours_60" / "renders"
+    for n in names:
+        assert (two / n).read_bytes() == (one / n).read_bytes(), n
