@@ -375,6 +375,17 @@ def golden_surface(out):
             return sfe.build_single_frame_dataset()
         (tmp / "sf").mkdir()
         surf["single_frame_dataset"] = SC.single_frame_dataset(build, make_fixture_dataset, tmp / "sf")
+        monkey.restore()
+        tg = importlib.import_module("train_ghost")
+        assert str(REF) in os.path.abspath(tg.__file__)
+        (tmp / "rs_cli").mkdir()
+        surf["render_surgery_cli"] = SC.render_surgery_cli(rs, make_fixture_dataset, tmp / "rs_cli", monkey)
+        monkey.restore()
+        (tmp / "tg_cli").mkdir()
+        surf["train_ghost_cli"] = SC.train_ghost_cli(tg, make_fixture_dataset, tmp / "tg_cli", monkey)
+        monkey.restore()
+        (tmp / "vr_cli").mkdir()
+        surf["validation_reporting_cli"] = SC.validation_reporting_cli(vr, tmp / "vr_cli")
     finally:
         monkey.restore()
         shutil.rmtree(tmp, ignore_errors=True)

@@ -388,3 +388,158 @@ def single_frame_dataset(build, make_fixture_dataset, tmp: Path) -> dict:
     out["copies_are_bytewise"] = {rel: (dst / rel).read_bytes() == (src / rel).read_bytes()
                                   for rel in ("images/00000_00.png", "flame_param/00000.npz", "fg_masks/00000_00.png", "canonical_flame_param.npz")}
     return out
+
+
+# ------------------------------------------------------------------ the command lines: main() of render_surgery / train_ghost / validation_reporting
+def _argv(argv):
+    class _Ctx:
+        def __enter__(self):
+            self.old = sys.argv
+            sys.argv = list(argv)
+
+        def __exit__(self, *a):
+            sys.argv = self.old
+    return _Ctx()
+
+
+def _tmpnames(text: str) -> str:
+    """mkdtemp names differ from run to run: surgical_render_XXXXXXXX -> surgical_render_*"""
+    import re
+    text = re.sub(r"[^\s'\"]*surgical_render_[A-Za-z0-9_]+", "<MODIFIED>", text)
+    return re.sub(r"[^\s'\"]*stitch_[A-Za-z0-9_]+", "<STAGING>", text)
+
+
+def render_surgery_cli(rs, make_fixture_dataset, tmp: Path, monkey) -> dict:
+    """main() end to end with both child processes stubbed: argument parsing and defaults, mm -> offsets, rig-mode fallback and the
+    deformation map it switches on, the temporary dataset the engine is pointed at (its FLAME edits are read INSIDE the stub),
+    pinned iteration, deterministic export, stitch, and the clean-up of the temporary dataset -- also when the engine fails."""
+    tmp = Path(tmp)
+    engine = tmp / "engine"
+    engine.mkdir()
+    (engine / "render.py").write_text("# placeholder\n")
+    monkey(rs, "REPO_DIR", engine)
+    monkey(rs, "RENDER_SCRIPT", engine / "render.py")
+    monkey(rs, "_get_ffmpeg_path", lambda: "/opt/fake/ffmpeg")
+    data = tmp / "data"
+    make_fixture_dataset(data, n_frames=12)
+    base = np.load(data / "flame_param" / "00003.npz")
+    asset = tmp / "asset.npz"
+    np.savez(asset, version=np.array([1]))
+    dmap = tmp / "dmap.json"
+    dmap.write_text(json.dumps({"translation_axis": 2, "jaw_axis": 1, "lefort_scale": 2.0, "bsso_scale": 0.5}))
+    out = {}
+    cases = {
+        "defaults": (["--lefort_mm", "3", "--bsso_mm", "5"], 0),
+        "hybrid_with_map_pinned_export": (["--lefort_mm", "-2.5", "--bsso_mm", "4", "--sensitivity", "1.5", "--rig_mode", "hybrid_full_head",
+                                           "--canonical_head_asset", str(asset), "--deformation_map", str(dmap), "--iteration", "7", "--fps", "24",
+                                           "--export_frames_dir", str(tmp / "export"), "--deterministic_max_frames", "3"], 0),
+        "hybrid_without_asset_ignores_map": (["--lefort_mm", "1", "--bsso_mm", "1", "--rig_mode", "hybrid_full_head", "--deformation_map", str(dmap)], 0),
+        "engine_fails": (["--lefort_mm", "1", "--bsso_mm", "1"], 3),
+    }
+    for name, (extra, rc) in cases.items():
+        model = tmp / name / "model"
+        (model / "point_cloud" / "iteration_30").mkdir(parents=True)
+        video = tmp / name / "out" / "prediction.mp4"
+        subs = {str(model.resolve()): "<MODEL>", str(model): "<MODEL>", str(data.resolve()): "<DATA>", str(data): "<DATA>", str(engine): "<ENGINE>",
+                str(tmp): "<TMP>", sys.executable: "<PYTHON>"}
+        seen = {"calls": []}
+
+        def fake_run(cmd, _model=model, _rc=rc, _seen=seen, **kw):
+            if cmd[0] == "/opt/fake/ffmpeg":
+                _seen["calls"].append({"ffmpeg": [_tmpnames(c) for c in cmd]})
+                return _Result(0)
+            src = Path(cmd[cmd.index("--source_path") + 1])
+            _seen["modified_dir"] = str(src)
+            a = np.load(src / "flame_param" / "00003.npz")
+            _seen["calls"].append({"engine": [_tmpnames(c) for c in cmd],
+                                   "translation_delta": (a["translation"] - base["translation"]).round(7).tolist(),
+                                   "jaw_delta": (a["jaw_pose"] - base["jaw_pose"]).round(7).tolist(),
+                                   "dataset_files": sorted(p.name for p in src.iterdir())})
+            if _rc == 0:
+                it = cmd[cmd.index("--iteration") + 1]
+                d = _model / "train" / f"ours_{it}" / "renders"
+                d.mkdir(parents=True)
+                for i in range(5):
+                    put_png(d / f"{i:05d}.png", np.full((2, 2, 3), i, np.uint8))
+            return _Result(_rc, stdout="", stderr="engine said no")
+        monkey(subprocess, "run", fake_run)
+        with _argv(["render_surgery.py", "--model_path", str(model), "--data_dir", str(data), "--output", str(video), *extra]):
+            rec = _call(rs.main, subs=subs)
+        rec.pop("returned", None)
+        rec["stdout"] = _sorted_listing([_tmpnames(l) for l in rec["stdout"]])
+        if "raised" in rec:
+            rec["raised"][1] = _tmpnames(rec["raised"][1])
+        for c in seen["calls"]:
+            for k in ("engine", "ffmpeg"):
+                if k in c:
+                    c[k] = [_norm(x, subs) for x in c[k]]
+        out[name] = {**rec, "calls": seen["calls"], "temporary_dataset_removed": not os.path.exists(seen.get("modified_dir", "/nonexistent")),
+                     "exported": _tree(tmp / "export") if "export" in " ".join(extra) else None}
+    with _argv(["render_surgery.py", "--bsso_mm", "1"]):
+        rec = _call(lambda: _exit_code(rs.main))
+    out["missing_required_argument_exit_code"] = rec.get("returned")
+    return out
+
+
+def _sorted_listing(lines: list) -> list:
+    """The directory listing printed behind "Contents of temp_dir:" comes in os.listdir order (file-system dependent): sorted."""
+    out, i = [], 0
+    while i < len(lines):
+        out.append(lines[i])
+        if lines[i].endswith("Contents of temp_dir:"):
+            j = i + 1
+            while j < len(lines) and lines[j].startswith("  "):
+                j += 1
+            out.extend(sorted(lines[i + 1:j]))
+            i = j
+        else:
+            i += 1
+    return out
+
+
+def _exit_code(fn):
+    import contextlib
+    try:
+        with contextlib.redirect_stderr(io.StringIO()):
+            fn()
+    except SystemExit as e:
+        return e.code
+    return None
+
+
+def train_ghost_cli(tg, make_fixture_dataset, tmp: Path, monkey) -> dict:
+    tmp = Path(tmp)
+    monkey(tg, "validate_setup", lambda: None)
+    out = {}
+    for name, extra, masks in (("defaults_5000", [], False), ("explicit", ["--iterations", "30000", "--resolution", "2"], True)):
+        data, model = tmp / name / "data", tmp / name / "model"
+        make_fixture_dataset(data, n_frames=60, with_masks=masks)
+        seen = {}
+
+        def fake_run(cmd, _seen=seen, **kw):
+            _seen["argv"] = list(cmd)
+            return _Result(0)
+        monkey(subprocess, "run", fake_run)
+        subs = {str(data.resolve()): "<DATA>", str(data): "<DATA>", str(model.resolve()): "<MODEL>", str(model): "<MODEL>",
+                str(tg.REPO_DIR): "<ENGINE>", sys.executable: "<PYTHON>", str(tmp): "<TMP>"}
+        with _argv(["train_ghost.py", "--data_dir", str(data), "--output_dir", str(model), *extra]):
+            rec = _call(tg.main, subs=subs)
+        rec.pop("returned", None)
+        rec["stdout"] = [l for l in rec["stdout"] if "manifest" not in l.lower()]          # the manifest's name carries a time stamp
+        out[name] = {**rec, "argv": [_norm(c, subs) for c in seen["argv"]]}
+    return out
+
+
+def validation_reporting_cli(vr, tmp: Path) -> dict:
+    tmp = Path(tmp)
+    t = make_report_tree(tmp / "tree")
+    with _argv(["validation_reporting.py", "--model_path", str(t["model"]), "--deterministic_frames_dir", str(t["det"]), "--output_dir", str(tmp / "rep")]):
+        rec = _call(vr.main, subs={str(tmp): "<TMP>"})
+    rec.pop("returned", None)
+    return {**rec, "files": _tree(tmp / "rep"), "count": json.loads((tmp / "rep" / "strict_scores.json").read_text())["summary"]["count"],
+            "missing_required_argument_exit_code": _with_argv_exit(["validation_reporting.py"], vr.main)}
+
+
+def _with_argv_exit(argv, fn):
+    with _argv(argv):
+        return _exit_code(fn)

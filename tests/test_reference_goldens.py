@@ -346,3 +346,32 @@ def test_single_frame_dataset_matches_reference(tmp_path):
     tj = json.loads((many / "transforms_train.json").read_text())
     assert len(tj["frames"]) == 50 and [f["timestep_index"] for f in tj["frames"]] == list(range(50))
     assert np.load(many / "flame_param.npz")["expr"].shape == (50, 100) and np.load(many / "flame_param.npz")["static_offset"].shape[0] == 1
+
+
+def _make_goldens_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_goldens4", GOLD / "make_goldens.py")
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg
+
+
+def test_render_surgery_command_line_matches_reference(tmp_path, monkeypatch):
+    """main() of render_surgery (reference :452-541) with both child processes stubbed: defaults, mm -> offsets, the rig-mode
+    fallback and the deformation map it switches on (the FLAME edits of the temporary dataset are read inside the engine stub),
+    pinned iteration, deterministic export, stitch argv, every printed line, removal of the temporary dataset (also when the
+    engine fails), exit code 2 without a required argument."""
+    got = _scenarios().render_surgery_cli(rs, _make_goldens_module().make_fixture_dataset, tmp_path, monkeypatch.setattr)
+    _same(got, S["render_surgery_cli"])
+
+
+def test_train_ghost_command_line_matches_reference(tmp_path, monkeypatch):
+    """main() of train_ghost (reference :280-300): defaults (5000 iterations, native resolution) and explicit flags -> engine argv
+    incl. save / checkpoint iterations and --white_background, printed lines."""
+    got = _scenarios().train_ghost_cli(tg, _make_goldens_module().make_fixture_dataset, tmp_path, monkeypatch.setattr)
+    _same(got, S["train_ghost_cli"])
+
+
+def test_validation_reporting_command_line_matches_reference(tmp_path):
+    from omfs_4d_video_gen_amd import validation_reporting as vr
+    _same(_scenarios().validation_reporting_cli(vr, tmp_path), S["validation_reporting_cli"])
