@@ -261,14 +261,15 @@ def golden_flame_fitter(out):
     lmk2d = [np.stack([px[t], py[t]], -1).astype(np.float32) for t in range(T)]
     lmk2d[3] = None   # a frame without a detected face
     poses = [list(ff.estimate_head_pose_from_landmarks(l, (W, H))) for l in lmk2d]
-    fits = {}
+    fits, fit_stdout = {}, {}
     for iters in (1, 3, 200):
-        with redirect_stdout(io.StringIO()):
+        with redirect_stdout(io.StringIO()) as sink:
             # 200 is the reference's default fit length (flame_fitter.py:302): that run is made WITHOUT the argument
             kw = {} if iters == 200 else {"n_iters": iters}
             res = ff.fit_flame_to_landmarks([None if l is None else l.copy() for l in lmk2d], (W, H), str(pkl), n_shape=100, n_expr=50,
                                             lr=0.01, device="cpu", **kw)
         fits[iters] = res
+        fit_stdout[str(iters)] = sink.getvalue().splitlines()
     np.savez_compressed(
         HERE / "flame_fitter_golden.npz", rig_seed=np.array([0]), axis_angle=aa, rotmats=R,
         fwd_shape=shape, fwd_expr=expr, fwd_rot=rot, fwd_jaw=jaw, fwd_trans=trans, fwd_landmarks=lm,
@@ -276,7 +277,7 @@ def golden_flame_fitter(out):
         lmk2d_valid=np.array([l is not None for l in lmk2d]), image_size=np.array([W, H]), head_pose_init=np.array(poses, np.float32),
         **{f"fit{it}_{k}": v for it, r in fits.items() for k, v in r.items() if k not in ("static_offset", "dynamic_offset")},
         fit_static_offset_shape=np.array(fits[3]["static_offset"].shape), fit_dynamic_offset_shape=np.array(fits[3]["dynamic_offset"].shape))
-    out["flame_fitter"] = {"result_keys": sorted(fits[3].keys()), "n_landmarks": int(lm.shape[1]),
+    out["flame_fitter"] = {"fit_stdout": fit_stdout, "result_keys": sorted(fits[3].keys()), "n_landmarks": int(lm.shape[1]),
                            "shapes": {k: list(v.shape) for k, v in fits[3].items()}}
     shutil.rmtree(tmp, ignore_errors=True)
 
