@@ -83,6 +83,22 @@ def make_fixture_dataset(root: Path, n_frames=60, with_masks=False, gaps=0):
     np.savez(root / "canonical_flame_param.npz", **canon)
 
 
+class _Monkey:
+    """setattr with restore (what pytest's monkeypatch does for the tests that replay the scenarios)."""
+
+    def __init__(self):
+        self.undo = []
+
+    def __call__(self, obj, name, value):
+        self.undo.append((obj, name, getattr(obj, name)))
+        setattr(obj, name, value)
+
+    def restore(self):
+        for obj, name, old in reversed(self.undo):
+            setattr(obj, name, old)
+        self.undo.clear()
+
+
 def golden_render_surgery(out):
     rs = importlib.import_module("render_surgery")
     grid = [(mm, s) for mm in (-7.5, -1.0, 0.0, 0.25, 3.0, 12.0) for s in (0.0, 0.5, 1.0, 2.5)]
@@ -277,7 +293,19 @@ def golden_flame_fitter(out):
         lmk2d_valid=np.array([l is not None for l in lmk2d]), image_size=np.array([W, H]), head_pose_init=np.array(poses, np.float32),
         **{f"fit{it}_{k}": v for it, r in fits.items() for k, v in r.items() if k not in ("static_offset", "dynamic_offset")},
         fit_static_offset_shape=np.array(fits[3]["static_offset"].shape), fit_dynamic_offset_shape=np.array(fits[3]["dynamic_offset"].shape))
-    out["flame_fitter"] = {"fit_stdout": fit_stdout, "result_keys": sorted(fits[3].keys()), "n_landmarks": int(lm.shape[1]),
+    sys.path.insert(0, str(HERE))
+    import scenarios as SC
+    (tmp / "detect").mkdir()
+    detect = SC.detect_landmarks(ff, tmp / "detect")
+    (tmp / "fv").mkdir()
+    monkey = _Monkey()
+    try:
+        fv = SC.fit_video(ff, tmp / "fv", monkey, str(pkl), str(lmk), "cpu", lmk2d, (W, H))
+    finally:
+        monkey.restore()
+    fv_arrays = fv.pop("_arrays")
+    np.savez_compressed(HERE / "flame_fitter_fit_video_golden.npz", **fv_arrays)
+    out["flame_fitter"] = {"detect_landmarks": detect, "fit_video": fv, "fit_stdout": fit_stdout, "result_keys": sorted(fits[3].keys()), "n_landmarks": int(lm.shape[1]),
                            "shapes": {k: list(v.shape) for k, v in fits[3].items()}}
     shutil.rmtree(tmp, ignore_errors=True)
 
@@ -327,22 +355,6 @@ def golden_preprocess(out):
                         **{f"canonical_{k}_shape": np.array(c[k].shape) for k in c.files},
                         canonical_nonzero=np.array([float(np.abs(c[k]).max()) for k in sorted(c.files) if k not in ("shape", "static_offset")]))
     shutil.rmtree(tmp, ignore_errors=True)
-
-
-class _Monkey:
-    """setattr with restore (what pytest's monkeypatch does for the tests that replay the scenarios)."""
-
-    def __init__(self):
-        self.undo = []
-
-    def __call__(self, obj, name, value):
-        self.undo.append((obj, name, getattr(obj, name)))
-        setattr(obj, name, value)
-
-    def restore(self):
-        for obj, name, old in reversed(self.undo):
-            setattr(obj, name, old)
-        self.undo.clear()
 
 
 def golden_surface(out):

@@ -543,3 +543,88 @@ def validation_reporting_cli(vr, tmp: Path) -> dict:
 def _with_argv_exit(argv, fn):
     with _argv(argv):
         return _exit_code(fn)
+
+
+# ------------------------------------------------------------------ flame_fitter.detect_landmarks_mediapipe (reference flame_fitter.py:45-66, 200-244)
+def detect_landmarks(ff, tmp: Path) -> dict:
+    """The glue around the third-party detector, with deterministic stand-ins for `cv2` and `mediapipe` registered in sys.modules
+    (the detector itself is out of scope): which 68 of the mesh's landmarks are taken and in which order (MEDIAPIPE_TO_68),
+    the pixel scaling, None for an unreadable image and for a frame without a face, the FaceMesh options, the printed lines."""
+    import types
+    tmp = Path(tmp)
+    d = tmp / "frames"
+    d.mkdir()
+    for name in ("00000.png", "00001.png", "00002.png", "00003.png", "notes.txt", "00004.PNG"):
+        (d / name).write_bytes(b"x")
+    log = {"facemesh_kwargs": None, "closed": 0, "cvt_codes": []}
+    cv2 = sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    mp = sys.modules.setdefault("mediapipe", types.ModuleType("mediapipe"))
+    sizes = {"00000.png": (48, 64), "00001.png": (48, 64), "00003.png": (30, 40)}       # (h, w)
+
+    def imread(path):
+        name = os.path.basename(path)
+        if name not in sizes:
+            return None                              # 00002.png: unreadable
+        h, w = sizes[name]
+        img = np.zeros((h, w, 3), np.uint8)
+        img[0, 0, 0] = int(name[:5])                 # the frame number travels in a pixel
+        return img
+
+    def cvt(img, code):
+        log["cvt_codes"].append(code)
+        return img
+    cv2.imread, cv2.cvtColor, cv2.COLOR_BGR2RGB = imread, cvt, 4
+
+    class Landmark:
+        def __init__(self, i, f):
+            self.x, self.y, self.z = ((i * 37 + f * 11) % 1000) / 1000.0, ((i * 91 + f * 7) % 997) / 997.0, 0.0
+
+    class FaceMesh:
+        def __init__(self, **kw):
+            log["facemesh_kwargs"] = {k: kw[k] for k in sorted(kw)}
+
+        def process(self, rgb):
+            f = int(rgb[0, 0, 0])
+            faces = [] if f == 1 else [types.SimpleNamespace(landmark=[Landmark(i, f) for i in range(478)])]
+            return types.SimpleNamespace(multi_face_landmarks=faces)
+
+        def close(self):
+            log["closed"] += 1
+    mp.solutions = types.SimpleNamespace(face_mesh=types.SimpleNamespace(FaceMesh=FaceMesh))
+    rec = _call(ff.detect_landmarks_mediapipe, str(d))
+    found = rec.pop("returned")
+    return {**rec, "table": [int(i) for i in ff.MEDIAPIPE_TO_68], "log": log,
+            "landmarks": [None if l is None else {"dtype": str(l.dtype), "shape": list(l.shape), "values": np.asarray(l, np.float64).round(6).tolist()} for l in found]}
+
+
+# ------------------------------------------------------------------ flame_fitter.fit_video + its command line (reference flame_fitter.py:447-490)
+def fit_video(ff, tmp: Path, monkey, pkl: str, lmk_npy: str, device: str, lmk2d, size_wh) -> dict:
+    """detect -> fit -> np.savez with the detector replaced by `lmk2d` (list of (68,2) arrays / None) and 3 fit iterations,
+    through the command line (`main()`), on `device`; the size of the first frame is read from a real PNG of `size_wh`
+    (the reference reads it with cv2.imread: the stand-in returns an array of that size).  Returns the printed lines, the saved
+    arrays (the caller compares them with the tolerance of the fit) and the refusal without the FLAME pickle."""
+    import types
+    tmp = Path(tmp)
+    d = tmp / "frames"
+    d.mkdir()
+    w, h = size_wh
+    for i in range(len(lmk2d)):
+        put_png(d / f"{i:05d}.png", np.zeros((h, w, 3), np.uint8))
+    cv2 = sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    cv2.imread = lambda path: np.zeros((h, w, 3), np.uint8)
+    monkey(ff, "detect_landmarks_mediapipe", lambda images_dir: [None if l is None else np.array(l, np.float32) for l in lmk2d])
+    monkey(ff, "FLAME_LMK_PATH", Path(lmk_npy))
+    subs = {str(tmp): "<TMP>"}
+    monkey(ff, "FLAME_MODEL_PATH", tmp / "absent.pkl")
+    out = {"no_model": _call(ff.fit_video, str(d), str(tmp / "x.npz"), device, 3, subs=subs)}
+    monkey(ff, "FLAME_MODEL_PATH", Path(pkl))
+    with _argv(["flame_fitter.py", "--images_dir", str(d), "--output", str(tmp / "fit.npz"), "--device", device, "--n_iters", "3"]):
+        rec = _call(ff.main, subs=subs)
+    rec.pop("returned", None)
+    rec["stdout"] = [l for l in rec["stdout"] if l.strip()]
+    res = np.load(tmp / "fit.npz")
+    out["cli"] = {**rec, "keys": sorted(res.files), "shapes": {k: list(res[k].shape) for k in sorted(res.files)},
+                  "dtypes": {k: str(res[k].dtype) for k in sorted(res.files)}}
+    out["_arrays"] = {k: res[k] for k in res.files if k not in ("static_offset", "dynamic_offset")}      # not JSON: stripped by the caller
+    out["missing_required_argument_exit_code"] = _with_argv_exit(["flame_fitter.py", "--output", "x"], ff.main)
+    return out

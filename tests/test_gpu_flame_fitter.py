@@ -114,3 +114,34 @@ def test_default_length_fit_matches_the_reference_run(setup, capsys):
     out = capsys.readouterr().out
     assert "/200 — loss:" in out and "[flame_fitter] Fitting complete." in out
     _same_printout(out, 200)
+
+
+def test_fit_video_and_its_command_line_match_the_reference(setup, tmp_path, monkeypatch):
+    """fit_video + main() (reference flame_fitter.py:447-490) through the shared scenario (tests/golden/scenarios.py::fit_video: the
+    detector replaced by the golden landmarks, 3 iterations, device cuda here / cpu when the reference ran it): the refusal
+    without the FLAME pickle, argv parsing, every printed line (numbers within 1.5 of their last printed digit), the keys, shapes
+    and dtypes of the saved npz, its arrays within the 3-iteration tolerance (5e-6)."""
+    import importlib.util
+    import json
+    import re
+    ff, rig, pkl, gold = setup
+    spec = importlib.util.spec_from_file_location("golden_scenarios_fv", GOLD / "scenarios.py")
+    SC = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(SC)
+    W, H = [int(v) for v in gold["image_size"]]
+    lmk = [gold["lmk2d"][i].copy() if gold["lmk2d_valid"][i] else None for i in range(len(gold["lmk2d"]))]
+    got = SC.fit_video(ff, tmp_path, monkeypatch.setattr, pkl, str(ff.FLAME_LMK_PATH), "cuda", lmk, (W, H))
+    want = json.loads((GOLD / "reference_goldens.json").read_text())["flame_fitter"]["fit_video"]
+    arrays = got.pop("_arrays")
+    assert got["no_model"] == want["no_model"] and got["missing_required_argument_exit_code"] == want["missing_required_argument_exit_code"]
+    for k in ("keys", "shapes", "dtypes"):
+        assert got["cli"][k] == want["cli"][k], k
+    num = re.compile(r"-?\\d+\\.\\d+")
+    assert len(got["cli"]["stdout"]) == len(want["cli"]["stdout"])
+    for g, w in zip(got["cli"]["stdout"], want["cli"]["stdout"]):
+        assert num.sub("#", g) == num.sub("#", w), (g, w)
+        for a, b in zip(num.findall(g), num.findall(w)):
+            assert abs(float(a) - float(b)) <= 1.5 * 10 ** -len(b.split(".")[1]), (g, w)
+    ref = np.load(GOLD / "flame_fitter_fit_video_golden.npz")
+    for k in ref.files:
+        assert np.abs(arrays[k] - ref[k]).max() < 5e-6, (k, np.abs(arrays[k] - ref[k]).max())

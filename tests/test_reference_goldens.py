@@ -375,3 +375,21 @@ def test_train_ghost_command_line_matches_reference(tmp_path, monkeypatch):
 def test_validation_reporting_command_line_matches_reference(tmp_path):
     from omfs_4d_video_gen_amd import validation_reporting as vr
     _same(_scenarios().validation_reporting_cli(vr, tmp_path), S["validation_reporting_cli"])
+
+
+def test_landmark_detection_glue_matches_reference(tmp_path):
+    """detect_landmarks_mediapipe (reference flame_fitter.py:45-66, 200-244) around stand-ins for the third-party detector: the
+    MEDIAPIPE_TO_68 table and its order, pixel scaling to float32, None for an unreadable image and for a frame without a face,
+    the FaceMesh options, close(), the two printed lines."""
+    from omfs_4d_video_gen_amd import flame_fitter as ff
+    import sys
+    saved = {k: sys.modules.get(k) for k in ("cv2", "mediapipe")}
+    try:
+        got = _scenarios().detect_landmarks(ff, tmp_path)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    _same(got, G["flame_fitter"]["detect_landmarks"])
