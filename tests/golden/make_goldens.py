@@ -399,6 +399,9 @@ def golden_surface(out):
         monkey.restore()
         (tmp / "vr_cli").mkdir()
         surf["validation_reporting_cli"] = SC.validation_reporting_cli(vr, tmp / "vr_cli")
+        (tmp / "helpers").mkdir()
+        surf["helper_functions"] = SC.helper_functions(rs, tg, make_fixture_dataset, tmp / "helpers", monkey)
+        monkey.restore()
     finally:
         monkey.restore()
         shutil.rmtree(tmp, ignore_errors=True)

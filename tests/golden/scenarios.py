@@ -628,3 +628,101 @@ def fit_video(ff, tmp: Path, monkey, pkl: str, lmk_npy: str, device: str, lmk2d,
     out["_arrays"] = {k: res[k] for k in res.files if k not in ("static_offset", "dynamic_offset")}      # not JSON: stripped by the caller
     out["missing_required_argument_exit_code"] = _with_argv_exit(["flame_fitter.py", "--output", "x"], ff.main)
     return out
+
+
+# ------------------------------------------------------------------ the smaller helpers of train_ghost and render_surgery
+def helper_functions(rs, tg, make_fixture_dataset, tmp: Path, monkey) -> dict:
+    """train_ghost.validate_setup / validate_data (exact messages), _collect_checkpoint_lineage, write_experiment_manifest (whole
+    payload minus its time stamps); render_surgery._get_ffmpeg_path (bundled, system, absent) and export_deterministic_frames with
+    an index file (list form, {"indices": ...} form, out-of-range indices dropped, a non-integer refused, no frames refused)."""
+    import re
+    import types
+    tmp = Path(tmp)
+    subs = {str(tmp.resolve()): "<TMP>", str(tmp): "<TMP>"}
+    out = {}
+    # ---- validate_setup
+    monkey(tg, "REPO_DIR", tmp / "no_repo")
+    monkey(tg, "TRAIN_SCRIPT", tmp / "no_repo" / "train.py")
+    out["setup_no_repo"] = _call(tg.validate_setup, subs=subs)
+    (tmp / "repo").mkdir()
+    monkey(tg, "REPO_DIR", tmp / "repo")
+    monkey(tg, "TRAIN_SCRIPT", tmp / "repo" / "train.py")
+    out["setup_no_script"] = _call(tg.validate_setup, subs=subs)
+    (tmp / "repo" / "train.py").write_text("#\n")
+    out["setup_ok"] = _call(tg.validate_setup, subs=subs)
+    # ---- validate_data: each refusal in the order the function checks
+    d = tmp / "vd"
+    d.mkdir()
+    steps = []
+    steps.append(_call(tg.validate_data, str(d), subs=subs))
+    (d / "transforms_train.json").write_text("{}")
+    steps.append(_call(tg.validate_data, str(d), subs=subs))
+    (d / "transforms_test.json").write_text("{}")
+    steps.append(_call(tg.validate_data, str(d), subs=subs))
+    (d / "flame_param.npz").write_bytes(b"x")
+    steps.append(_call(tg.validate_data, str(d), subs=subs))
+    (d / "images").mkdir()
+    (d / "images" / "a.jpg").write_bytes(b"x")
+    steps.append(_call(tg.validate_data, str(d), subs=subs))
+    for i in range(3):
+        put_png(d / "images" / f"{i:05d}_00.png", np.zeros((2, 2, 3), np.uint8))
+    steps.append(_call(tg.validate_data, str(d), subs=subs))
+    out["validate_data_steps"] = steps
+    # ---- checkpoint lineage + manifest
+    m = tmp / "model"
+    out["lineage_missing_dir"] = tg._collect_checkpoint_lineage(str(m))
+    m.mkdir()
+    for name, size in (("chkpnt500.pth", 7), ("chkpnt10000.pth", 11), ("chkpnt_note.txt", 3), ("other.pth", 5)):
+        (m / name).write_bytes(b"z" * size)
+        os.utime(m / name, (1700000000, 1700000000 + size))
+    out["lineage"] = tg._collect_checkpoint_lineage(str(m))
+    data = tmp / "data"
+    make_fixture_dataset(data, n_frames=6)
+    rec = _call(tg.write_experiment_manifest, str(data), str(m), 1234, 2, ["python", "train.py", "--x"], {"note": "n", "k": [1, 2]}, subs=subs)
+    path = Path(str(rec.pop("returned")))
+    payload = json.loads(path.read_text())
+    out["manifest"] = {"stdout": [re.sub(r"\d{8}T\d{6}Z", "<STAMP>", l) for l in rec["stdout"]],
+                       "name_is_utc_stamp": bool(re.fullmatch(r"\d{8}T\d{6}Z\.json", path.name)), "parent": _norm(str(path.parent), subs),
+                       "keys_in_order": list(payload.keys()), "created_utc_is_iso_utc": payload["created_utc"].endswith("+00:00"),
+                       "payload": {k: (_norm(v, subs) if isinstance(v, str) else v) for k, v in payload.items() if k not in ("created_utc", "dataset_fingerprint")},
+                       "fingerprint_keys": sorted(payload["dataset_fingerprint"].keys())}
+    # ---- _get_ffmpeg_path
+    fake = types.ModuleType("imageio_ffmpeg")
+    fake.get_ffmpeg_exe = lambda: "/bundled/ffmpeg"
+    saved = sys.modules.get("imageio_ffmpeg", "absent")
+    try:
+        sys.modules["imageio_ffmpeg"] = fake
+        ff = {"bundled": _call(rs._get_ffmpeg_path)}
+        sys.modules["imageio_ffmpeg"] = None                      # import raises ImportError
+        monkey(rs.shutil, "which", lambda name: "/usr/bin/" + name)
+        ff["system"] = _call(rs._get_ffmpeg_path)
+        monkey(rs.shutil, "which", lambda name: None)
+        ff["absent"] = _call(rs._get_ffmpeg_path)
+    finally:
+        if saved == "absent":
+            sys.modules.pop("imageio_ffmpeg", None)
+        else:
+            sys.modules["imageio_ffmpeg"] = saved
+    out["ffmpeg_path"] = ff
+    # ---- export_deterministic_frames with an index file
+    frames = tmp / "frames"
+    frames.mkdir()
+    for i in range(7):
+        put_png(frames / f"{i:05d}.png", np.full((2, 2, 3), i, np.uint8))
+    (frames / "skip.txt").write_text("x")
+    ex = {}
+    for name, content in (("list", [5, 0, 99, 3, -1, 3]), ("dict", {"indices": [6, 2], "comment": "x"}), ("bad_entry", [1, "2"]), ("bad_type", {"indices": "0,1"}),
+                          ("dict_without_key", {"other": 1})):
+        idx = tmp / f"idx_{name}.json"
+        idx.write_text(json.dumps(content))
+        rec = _call(rs.export_deterministic_frames, str(frames), str(tmp / f"exp_{name}"), str(idx), 24, subs=subs)
+        if "returned" in rec:
+            rec["returned"] = _norm(rec["returned"], subs)
+            man = json.loads((tmp / f"exp_{name}" / "deterministic_indices_manifest.json").read_text())
+            rec["manifest"] = {**man, "source_frames_dir": _norm(man["source_frames_dir"], subs)}
+            rec["files"] = _tree(tmp / f"exp_{name}")
+        ex[name] = rec
+    (tmp / "noframes").mkdir()
+    ex["no_frames"] = _call(rs.export_deterministic_frames, str(tmp / "noframes"), str(tmp / "exp_none"), None, 24, subs=subs)
+    out["export_with_index_file"] = ex
+    return out

@@ -393,3 +393,12 @@ def test_landmark_detection_glue_matches_reference(tmp_path):
             else:
                 sys.modules[k] = v
     _same(got, G["flame_fitter"]["detect_landmarks"])
+
+
+def test_helper_functions_match_reference(tmp_path, monkeypatch):
+    """train_ghost.validate_setup / validate_data (every refusal, in the order checked), _collect_checkpoint_lineage,
+    write_experiment_manifest (key order, values, file name pattern); render_surgery._get_ffmpeg_path (bundled / system / absent)
+    and export_deterministic_frames with an index file -- including what the reference really does with a plain JSON list
+    (`payload.get` on a list: AttributeError, although its own message promises lists)."""
+    got = _scenarios().helper_functions(rs, tg, _make_goldens_module().make_fixture_dataset, tmp_path, monkeypatch.setattr)
+    _same(got, S["helper_functions"])
