@@ -2,6 +2,8 @@
 composite backward + projection/deformation backward (+ regularisers), the L1+D-SSIM loss and
 the fused Adam.  fp32 tolerance: per parameter group, max|diff| <= 2e-3 * max|ref| + 1e-7
 (float atomics reorder sums; the oracle differentiates through torch's own exp/matmul), see helpers.assert_grads_close."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -217,3 +219,55 @@ def test_quadrant_depth_table_is_exact_and_its_hint_changes_nothing():
         scale = np.abs(ref[3]).max(0) + 1e-30
         assert (np.abs(ref[3] - got[3]).max(0) <= 1e-5 * scale).all(), fill
     rast.rb.quad_depth = 0
+
+
+def test_backward_without_its_work_tables():
+    """The backward's work tables live in `keys` when the caller passes no quad_depth buffer, and only when they fit: a pair
+    capacity that is tiny against the tile count (few Gaussians on a 1080p image) leaves room for the segment table but not for
+    the quadrant depths, or for neither -- then composite_bwd falls back to the exit test on the pixels' n_contrib and to the
+    bisection of order_seg0.  All three set-ups (both tables / segment table only / none) give the same gradient records."""
+    from omfs_4d_video_gen_amd import _lib as L
+    from omfs_4d_video_gen_amd.engine import synthetic
+    from omfs_4d_video_gen_amd.engine.flame_rig import DeviceFlame, FlameRig
+    from omfs_4d_video_gen_amd.engine.gaussians import GaussianModel
+    from omfs_4d_video_gen_amd.engine.rasterizer import Rasterizer, make_camera_struct
+    N, W, H = 120, 1920, 1080
+    rig = synthetic.make_rig(2)
+    g = synthetic.make_gaussians(N, rig.faces.shape[0], 2)
+    g["log_scale"] = g["log_scale"] + 1.0          # a few large splats: lists of several entries, few pairs in all
+    dflame = DeviceFlame(FlameRig.from_synthetic(rig), synthetic.make_flame_sequence(2, 2))
+    ccam = make_camera_struct(synthetic.make_camera(W, H, yaw=0.1), sh_degree=3, bg=(0.2, 0.2, 0.2))
+    model = GaussianModel(g)
+    fxf = dflame.face_frames(1, 1)[1][0]
+    dimage = torch.randn(3, H, W, generator=torch.Generator().manual_seed(4)).cuda()
+    big = Rasterizer(N, W, H)
+    big.forward(model, fxf, ccam)
+    torch.cuda.synchronize()
+    D, n_tiles = int(big.tile_start[-1]), big.n_tiles
+    assert 0 < D < 3800, D
+    outs = {}
+    for name, cap in (("both tables", None), ("segment table only", 12000), ("no table", 4000)):
+        r = Rasterizer(N, W, H, dup_capacity=cap)
+        seg_cap = r.seg_capacity
+        fits_seg, fits_depth = 2 * r.dup_capacity >= seg_cap, 2 * r.dup_capacity >= seg_cap + 4 * n_tiles
+        assert (fits_seg, fits_depth) == {"both tables": (True, True), "segment table only": (True, False), "no table": (False, False)}[name]
+        r.forward(model, fxf, ccam)
+        r._ensure_bwd()
+        r.dimage.copy_(dimage)
+        r.dsplat.zero_()
+        gb = L.GradBuffersC(L.ptr(r.dsplat), 0, L.ptr(r.dimage), 0, 0, 0)
+        for impl in ("dpp", "mfma"):
+            os.environ["OMFS_BWD_IMPL"] = impl
+            try:
+                r.dsplat.zero_()
+                L.check(L.load().omfs_composite_bwd(ccam, r.rb, gb, L.stream_ptr()), "omfs_composite_bwd")
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("OMFS_BWD_IMPL", None)
+            r.check_status()
+            outs[(name, impl)] = r.dsplat.cpu().numpy()[:, :9].copy()
+    ref = outs[("both tables", "dpp")]
+    assert np.abs(ref).max() > 0
+    scale = np.abs(ref).max(0) + 1e-30
+    for key, got in outs.items():
+        assert (np.abs(got - ref).max(0) <= 1e-5 * scale).all(), key
