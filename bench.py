@@ -47,7 +47,7 @@ def parse():
     return ap.parse_args()
 
 
-def stage_bytes(N, n_pad, D, P, n_tiles, F, D_visit):
+def stage_bytes(N, n_pad, D, P, n_tiles, F, D_visit, sh_adam=False):
     """Algorithmic HBM bytes per launch of each stage (DESIGN.md 'Algorithmic bytes')."""
     return {
         "flame": 0.0,   # set by caller (basis read)
@@ -61,8 +61,10 @@ def stage_bytes(N, n_pad, D, P, n_tiles, F, D_visit):
         # visited entries only: id + 36-byte record gathered, one 40-byte gradient record added per visited entry (float atomics);
         # entries behind a tile's last contributor are never read.  (Round 1-3 charged the atomics for all D entries.)
         "composite_bwd": D_visit * (4 + 36) + D_visit * 40 + P * (12 + 8),
-        "project_bwd": N * (64 + 240 + 236) + F * 64,
-        "adam": 7 * 59 * n_pad * 4,
+        # sh_adam (single GPU): project_bwd writes 14 gradient planes + d(rgb) + the view direction (6 planes) instead of 59, and
+        # the Adam launch forms the other 45 gradients from those 6 planes (read once per Gaussian, algorithmically)
+        "project_bwd": N * (64 + 240 + (14 * 4 + 24 if sh_adam else 236)) + F * 64,
+        "adam": (7 * 14 + 6 * 45 + 6 if sh_adam else 7 * 59) * n_pad * 4,
     }
 
 
@@ -310,7 +312,7 @@ def main():
     pad = torch.zeros(gy * 16, gx * 16, dtype=torch.int32, device="cuda")
     pad[:H, :W] = n_contrib
     D_visit = int(pad.view(gy, 16, gx, 16).permute(0, 2, 1, 3).reshape(gy * gx, 256).max(1).values.sum().item())
-    sb = stage_bytes(N, trainer.model.n_pad, D, P, n_tiles, F, D_visit)
+    sb = stage_bytes(N, trainer.model.n_pad, D, P, n_tiles, F, D_visit, sh_adam=getattr(trainer, "sh_adam", False))
     # a fixed FLAME sequence is posed once before training (resident triangle frames): no per-step FLAME traffic
     sb["flame"] = 0 if getattr(trainer, "_frames_all", None) is not None else \
         trainer.dflame.k_pad * trainer.dflame.v_pad * 3 * 4 + trainer.dflame.v_pad * 16 + F * (64 + 12)

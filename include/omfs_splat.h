@@ -249,6 +249,10 @@ typedef struct omfs_grad_buffers {
                              clamped channels and invisible Gaussians) here and leaves the 45 SH planes of degree >= 1
                              (planes 14..58) untouched: data-parallel ranks exchange these 3 planes instead of 45 and
                              rebuild the summed gradient with omfs_sh_rest_grads; may be NULL                     */
+  float* dir_out;         /* optional [3][n_pad] (ABI 7; only with drgb_out): the unit view direction camera -> Gaussian that the
+                             colour was evaluated with (0 for invisible Gaussians).  With drgb_out it is everything the gradient
+                             of the 45 SH planes of degree >= 1 is made of, Y_k(dir) * drgb[c]: omfs_adam_step_sh_rest forms
+                             it where it is consumed, so those planes are never written nor read; may be NULL          */
 } omfs_grad_buffers;
 
 /* Must follow omfs_composite_fwd of the SAME lists run in training mode (flags without OMFS_RB_FORWARD_ONLY), with `keys`
@@ -383,6 +387,15 @@ int omfs_adam_step(float* params, const float* grads, float* m, float* v, int n,
  * data-parallel trainer update the planes whose gradients are complete while the others are still being reduced */
 int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v, int n, int n_pad,
                           const omfs_adam_params* ap, int plane0, int n_planes, void* stream);
+/* ABI 7: the same step on the 45 SH planes of degree >= 1 (planes 14..58) with their gradient formed where it is consumed:
+ * plane 11 + 3k + c takes Y_k(dir) * drgb[c] for k < (sh_degree + 1)^2 and 0 beyond -- the very product omfs_project_bwd writes
+ * into the gradient planes when gb->drgb_out is NULL (same operations in the same order: parameters and moments come out
+ * bit-identical).  drgb, dir [3][n_pad] as omfs_project_bwd left them (gb->drgb_out, gb->dir_out).  Saves the 2 x 45 planes of
+ * gradient traffic (write in project_bwd, read here) of a single-GPU training iteration.  ap->step as for the other parts.
+ * grads_low (may be NULL): the gradient buffer; when given, planes 0..13 are updated from it in the SAME launch (what
+ * omfs_adam_step_planes(.., 0, 14) does), so the whole Adam step of an iteration stays one launch.                        */
+int omfs_adam_step_sh_rest(float* params, const float* grads_low, const float* drgb, const float* dir, float* m, float* v, int n,
+                           int n_pad, const omfs_adam_params* ap, int sh_degree, void* stream);
 
 /* The same step on the flat range [offset, offset + count) of the [59][n_pad] buffers (both multiples of 4): the shard a
  * data-parallel rank owns after a reduce-scatter of the gradient ("sharded" exchange: reduce-scatter, Adam on 1/W of the

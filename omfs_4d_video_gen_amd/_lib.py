@@ -64,7 +64,7 @@ class RasterBuffersC(C.Structure):
 
 class GradBuffersC(C.Structure):
     _fields_ = [("dsplat", c_void_p), ("grads", c_void_p), ("dimage", c_void_p), ("densify_stats", c_void_p),
-                ("dface", c_void_p), ("drgb_out", c_void_p)]
+                ("dface", c_void_p), ("drgb_out", c_void_p), ("dir_out", c_void_p)]
 
 
 class ViewSetC(C.Structure):
@@ -172,6 +172,8 @@ SIGNATURES = {
     "omfs_adam_step": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), c_void_p]),
     "omfs_adam_step_planes": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC), C.c_int, C.c_int,
                                         c_void_p]),
+    "omfs_adam_step_sh_rest": (C.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, C.c_int, C.POINTER(AdamParamsC),
+                                         C.c_int, c_void_p]),
     "omfs_count_visible": (C.c_int, [C.POINTER(RasterBuffersC), C.c_int, c_void_p, c_void_p]),
     "omfs_flame_fit_scratch_floats": (C.c_size_t, [C.POINTER(SimpleFlameC), C.c_int]),
     "omfs_flame_fit_step": (C.c_int, [C.POINTER(SimpleFlameC), C.POINTER(FlameFitC), c_void_p]),

@@ -375,6 +375,89 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const
   p[o] = pp; m[o] = mm; v[o] = vv;
 }
 
+// The 45 SH planes of degree >= 1 with the gradient formed in place: grid = (n_pad/1024, 5); block y takes the NINE planes of
+// SH coefficients k = 1 + 3 y .. 3 + 3 y (three channels each: planes 14 + 9 y .. 22 + 9 y), so a thread loads the view direction
+// and dL/dcolour of its four Gaussians ONCE for nine plane updates (one plane per block re-read them 45 times: 40 bytes per
+// element instead of 28 -- measured 84 us for the 45 planes against 56 us through the gradient buffer).
+// g = Y_k(dir) * drgb[c] -- the basis expressions are those of project_bwd_kernel, operation for operation (the TUs are built with
+// -ffp-contract=off: the same IEEE operations give the same bits), then exactly adam_kernel's update.
+__device__ __forceinline__ float sh_basis_k(int kk, float x, float y, float z) {
+  constexpr float C1 = 0.4886025119029199f;
+  constexpr float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+  constexpr float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                           -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+  const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yzp = y * z, xzp = x * z;
+  switch (kk) {                         // uniform over the block
+    case 1: return -C1 * y;
+    case 2: return C1 * z;
+    case 3: return -C1 * x;
+    case 4: return C2[0] * xy;
+    case 5: return C2[1] * yzp;
+    case 6: return C2[2] * (2.f * zz - xx - yy);
+    case 7: return C2[3] * xzp;
+    case 8: return C2[4] * (xx - yy);
+    case 9: return C3[0] * y * (3.f * xx - yy);
+    case 10: return C3[1] * xy * z;
+    case 11: return C3[2] * y * (4.f * zz - xx - yy);
+    case 12: return C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+    case 13: return C3[4] * x * (4.f * zz - xx - yy);
+    case 14: return C3[5] * z * (xx - yy);
+    default: return C3[6] * x * (xx - 3.f * yy);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_sh_rest_kernel(float4* __restrict__ p, const float4* __restrict__ drgb,
+                                                           const float4* __restrict__ dir, float4* __restrict__ m, float4* __restrict__ v,
+                                                           int n4_per_plane, AdamK k, int ncoef, const float4* __restrict__ g_low) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4_per_plane) return;
+  if (blockIdx.y >= 5) {               // (g_low given) blocks 5..18: planes 0..13 from the gradient buffer, exactly adam_kernel
+    const int plane = blockIdx.y - 5;
+    const size_t o = (size_t)plane * n4_per_plane + i;
+    const float lr = k.lr_step[plane];
+    float4 pp = p[o], gg = g_low[o], mm = m[o], vv = v[o];
+    auto upd0 = [&](float& pe, float ge, float& me, float& ve) {
+      ge *= k.grad_scale;
+      me = fma_(k.b1, me, (1.f - k.b1) * ge);
+      ve = fma_(k.b2, ve, (1.f - k.b2) * ge * ge);
+      const float denom = fma_(sqrtf(ve), k.inv_sqrt_bc2, k.eps);
+      pe = pe - lr * (me / denom);
+    };
+    upd0(pp.x, gg.x, mm.x, vv.x); upd0(pp.y, gg.y, mm.y, vv.y); upd0(pp.z, gg.z, mm.z, vv.z); upd0(pp.w, gg.w, mm.w, vv.w);
+    p[o] = pp; m[o] = mm; v[o] = vv;
+    return;
+  }
+  const int k0 = 1 + 3 * blockIdx.y;
+  const float4 X = dir[i], Y = dir[(size_t)n4_per_plane + i], Z = dir[(size_t)2 * n4_per_plane + i];
+  const float4 D[3] = {drgb[i], drgb[(size_t)n4_per_plane + i], drgb[(size_t)2 * n4_per_plane + i]};
+  auto upd = [&](float& pe, float ge, float& me, float& ve, float lr) {
+    ge *= k.grad_scale;
+    me = fma_(k.b1, me, (1.f - k.b1) * ge);
+    ve = fma_(k.b2, ve, (1.f - k.b2) * ge * ge);
+    const float denom = fma_(sqrtf(ve), k.inv_sqrt_bc2, k.eps);
+    pe = pe - lr * (me / denom);
+  };
+#pragma unroll
+  for (int dk = 0; dk < 3; ++dk) {
+    const int kk = k0 + dk;
+    const bool on = kk < ncoef;
+    const float4 B = make_float4(sh_basis_k(kk, X.x, Y.x, Z.x), sh_basis_k(kk, X.y, Y.y, Z.y), sh_basis_k(kk, X.z, Y.z, Z.z),
+                                 sh_basis_k(kk, X.w, Y.w, Z.w));
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const int plane = OMFS_P_SH + 3 * kk + ch;
+      const size_t o = (size_t)plane * n4_per_plane + i;
+      const float lr = k.lr_step[plane];
+      float4 pp = p[o], mm = m[o], vv = v[o];
+      upd(pp.x, on ? B.x * D[ch].x : 0.f, mm.x, vv.x, lr);
+      upd(pp.y, on ? B.y * D[ch].y : 0.f, mm.y, vv.y, lr);
+      upd(pp.z, on ? B.z * D[ch].z : 0.f, mm.z, vv.z, lr);
+      upd(pp.w, on ? B.w * D[ch].w : 0.f, mm.w, vv.w, lr);
+      p[o] = pp; m[o] = mm; v[o] = vv;
+    }
+  }
+}
+
 // The same update on a flat range [offset, offset + count) of the [59][n_pad] buffers (count, offset multiples of 4):
 // a data-parallel rank that owns one contiguous shard of the reduce-scattered gradient.  p / g / m / v point at the
 // START of the range; the plane of element offset + i selects the learning rate.
@@ -454,6 +537,25 @@ static int adam_launch(float* params, const float* grads, float* m, float* v, in
   const int n4 = n_pad / 4;
   hipLaunchKernelGGL(adam_kernel, dim3(cdiv(n4, 256), n_planes), dim3(256), 0, (hipStream_t)stream, (float4*)params,
                      (const float4*)grads, (float4*)m, (float4*)v, n4, k, plane0, state_dev);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_adam_step_sh_rest(float* params, const float* grads_low, const float* drgb, const float* dir, float* m, float* v,
+                                      int n, int n_pad, const omfs_adam_params* ap, int sh_degree, void* stream) {
+  OMFS_REQUIRE(params && drgb && dir && m && v && ap, "null pointer");
+  OMFS_REQUIRE(n > 0 && n_pad >= n && n_pad % 256 == 0 && ap->step >= 1 && sh_degree >= 0 && sh_degree <= 3, "shape");
+  AdamK k;
+  const double bc1 = 1.0 - pow((double)ap->beta1, ap->step), bc2 = 1.0 - pow((double)ap->beta2, ap->step);
+  for (int i = 0; i < OMFS_NPLANES; ++i) k.lr_step[i] = (float)(ap->lr[i] / bc1);
+  k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  k.b1 = ap->beta1; k.b2 = ap->beta2; k.eps = ap->eps;
+  k.grad_scale = ap->grad_scale;
+  const int n4 = n_pad / 4;
+  // the five nine-plane blocks first (they take nine times as long as a one-plane block), then planes 0..13 if asked for
+  hipLaunchKernelGGL(adam_sh_rest_kernel, dim3(cdiv(n4, 256), grads_low ? 5 + OMFS_P_SH + 3 : 5), dim3(256), 0, (hipStream_t)stream,
+                     (float4*)params, (const float4*)drgb, (const float4*)dir, (float4*)m, (float4*)v, n4, k, (sh_degree + 1) * (sh_degree + 1),
+                     (const float4*)grads_low);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) OMFS_PBWD_ATTR void project_bwd_kernel(int n, 
                                                           float4* __restrict__ dsplat, RegK reg,
                                                           const uint32_t* __restrict__ n_visible,
                                                           float* __restrict__ grads, float* __restrict__ densify_stats,
-                                                          float half_w, float half_h, float* __restrict__ dface, float* __restrict__ drgb_out) {
+                                                          float half_w, float half_h, float* __restrict__ dface, float* __restrict__ drgb_out,
+                                                          float* __restrict__ dir_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   auto P = [&](int plane) { return params[(size_t)plane * n_pad + i]; };
@@ -49,6 +50,8 @@ __global__ __launch_bounds__(256) OMFS_PBWD_ATTR void project_bwd_kernel(int n, 
     for (int p = 0; p < (drgb_out ? OMFS_P_SH + 3 : OMFS_NPLANES); ++p) G(p, 0.f);
     if (drgb_out)
       for (int ch = 0; ch < 3; ++ch) drgb_out[(size_t)ch * n_pad + i] = 0.f;
+    if (dir_out)
+      for (int ch = 0; ch < 3; ++ch) dir_out[(size_t)ch * n_pad + i] = 0.f;
     if (dface) {
       float4* o = reinterpret_cast<float4*>(dface) + (size_t)i * 4;
       for (int q = 0; q < 4; ++q) o[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -167,6 +170,7 @@ __global__ __launch_bounds__(256) OMFS_PBWD_ATTR void project_bwd_kernel(int n, 
     if ((clampbits >> ch) & 1u) drgb[ch] = 0.f;
   if (drgb_out)
     for (int ch = 0; ch < 3; ++ch) drgb_out[(size_t)ch * n_pad + i] = drgb[ch];
+  if (dir_out) { dir_out[i] = x; dir_out[(size_t)n_pad + i] = y; dir_out[(size_t)2 * n_pad + i] = z; }
   {
     constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
     constexpr float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
@@ -386,7 +390,7 @@ extern "C" int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, c
   RegK rk{reg->lambda_xyz, reg->thr_xyz, reg->lambda_scale, reg->thr_scale};
   hipLaunchKernelGGL(project_bwd_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, (hipStream_t)stream, g->n, g->n_pad,
                      g->params, g->binding, face_xf, pc, (const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2, (float4*)gb->dsplat, rk,
-                     reg->n_visible, gb->grads, gb->densify_stats, 0.5f * (float)cam->width, 0.5f * (float)cam->height, gb->dface, gb->drgb_out);
+                     reg->n_visible, gb->grads, gb->densify_stats, 0.5f * (float)cam->width, 0.5f * (float)cam->height, gb->dface, gb->drgb_out, gb->drgb_out ? gb->dir_out : nullptr);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

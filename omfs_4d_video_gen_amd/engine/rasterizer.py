@@ -246,6 +246,14 @@ class Adam:
         L.check(L.load().omfs_adam_step_planes(L.ptr(m.params), L.ptr(grads), L.ptr(self.m), L.ptr(self.v), m.n, m.n_pad,
                                                C.byref(self.ap), int(plane0), int(n_planes), L.stream_ptr()), "omfs_adam_step_planes")
 
+    def apply_sh_rest(self, drgb: torch.Tensor, view_dir: torch.Tensor, sh_degree: int, grads_low: torch.Tensor | None = None):
+        """The step on the 45 SH planes of degree >= 1 with their gradient Y_k(dir) * drgb formed where it is consumed
+        (omfs_adam_step_sh_rest; drgb, view_dir [3][n_pad] as omfs_project_bwd left them): those gradient planes are never written.
+        grads_low: the gradient buffer -- planes 0..13 are then updated from it in the same launch."""
+        m = self.model
+        L.check(L.load().omfs_adam_step_sh_rest(L.ptr(m.params), L.ptr(grads_low), L.ptr(drgb), L.ptr(view_dir), L.ptr(self.m), L.ptr(self.v),
+                                                m.n, m.n_pad, C.byref(self.ap), int(sh_degree), L.stream_ptr()), "omfs_adam_step_sh_rest")
+
     def apply_range(self, grad_shard: torch.Tensor, offset: int, count: int):
         """The update on the flat range [offset, offset + count) of the [59][n_pad] buffers; grad_shard holds that range's
         (summed) gradient.  Data-parallel "sharded" exchange: moments outside the rank's range are not touched."""

@@ -117,6 +117,12 @@ class Trainer:
         self.opt = Adam(self.model, self.lr_planes)
         self.flame_ft = None           # FLAME-parameter fine-tuning (engine/flame_finetune.py)
         self._grad_head = 0            # floats in front of the planes inside grad_store (the FLAME gradients, data parallel)
+        # One GPU: the gradient of the 45 SH planes of degree >= 1 is Y_k(dir) * dL/dcolour per Gaussian; project_bwd leaves the
+        # six values it is made of (drgb1, dir1) and the Adam pass of those planes forms it in place (omfs_adam_step_sh_rest):
+        # 2 x 54 MB of gradient traffic per iteration never happen, parameters and moments come out bit-identical.
+        # OMFS_SH_ADAM=0 (or `sh_adam = False` before the first step): every plane through the gradient buffer, one Adam launch.
+        self.sh_adam = world_size == 1 and process_group is None and os.environ.get("OMFS_SH_ADAM", "1") != "0"
+        self.drgb1 = self.dir1 = None
         self.alloc_grads(self.model.n_pad)
         self.sh_degree_max, self.sh_every, self.sh_degree = sh_degree_max, sh_increase_every, start_sh_degree
         self.step_idx = 0
@@ -194,6 +200,9 @@ class Trainer:
         [FLAME gradients, padded to 64 floats | 59 planes]: with data-parallel FLAME fine-tuning one all-reduce sums both."""
         self.grad_store = torch.zeros(self._grad_head + NPLANES * n_pad, device=self.device)
         self.grads = self.grad_store[self._grad_head:].view(NPLANES, n_pad)
+        if self.sh_adam:
+            self.drgb1 = torch.zeros(3, n_pad, device=self.device)
+            self.dir1 = torch.zeros(3, n_pad, device=self.device)
         if self._grad_head and self.flame_ft is not None:
             self.flame_ft.rebind_grads(self.grad_store[:self._grad_head])
 
@@ -231,16 +240,19 @@ class Trainer:
     def _view_step(self, view: View, cam, fxf: torch.Tensor, g, ft):
         """omfs_view_step of this view (cached with everything it points at: the structs must outlive the call)."""
         target = view.target
-        drgb = L.ptr(self.drgb_scratch) if self.compact_dp else 0      # compact exchange: project_bwd leaves the 45 SH planes out
+        # compact exchange / the in-place SH Adam of one GPU: project_bwd leaves the 45 SH planes out
+        split = self.sh_adam and not self.dp
+        drgb = L.ptr(self.drgb_scratch) if self.compact_dp else (L.ptr(self.drgb1) if split else 0)
+        vdir = L.ptr(self.dir1) if split else 0
         key = (id(view), id(cam), fxf.data_ptr(), g.n, g.n_pad, g.params, g.binding, L.ptr(self.densify_stats), L.ptr(ft.dface) if ft is not None else 0,
-               target.data_ptr(), self.lambda_dssim, tuple(self.reg), self.rast.rb.keys, self.rast.rb.dup_capacity, drgb)
+               target.data_ptr(), self.lambda_dssim, tuple(self.reg), self.rast.rb.keys, self.rast.rb.dup_capacity, drgb, vdir, L.ptr(self.grads))
         hit = self._view_steps.get(key)
         if hit is None:
             if len(self._view_steps) > 8 * max(len(self.views), 1):
                 self._view_steps.clear()
             r = self.rast
             gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
-                                L.ptr(ft.dface) if ft is not None else 0, drgb)
+                                L.ptr(ft.dface) if ft is not None else 0, drgb, vdir)
             rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
             u8 = target.dtype == torch.uint8
             if u8 and self._target_f32 is None:
@@ -518,8 +530,10 @@ class Trainer:
                 L.check(lib.omfs_rgb8_to_image(L.ptr(target), r.width, r.height, L.ptr(self._target_f32), s), "omfs_rgb8_to_image")
                 target = self._target_f32
             r.loss_l1_ssim(target, self.lambda_dssim); tm.mark("loss")
+            split = self.sh_adam and not self.dp
             gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
-                                L.ptr(ft.dface) if ft is not None else 0, L.ptr(self.drgb_scratch) if self.compact_dp else 0)
+                                L.ptr(ft.dface) if ft is not None else 0,
+                                L.ptr(self.drgb_scratch) if self.compact_dp else (L.ptr(self.drgb1) if split else 0), L.ptr(self.dir1) if split else 0)
             L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")
             gather = None
             if self.compact_dp:            # dL/dcolour is final here: its all-gather runs under project_bwd
@@ -591,6 +605,11 @@ class Trainer:
             self.opt.begin_step(1.0 / self.world)
             self.opt.apply_range(self._gshard, self.rank * S, S)
             allgather_shards_(self.model.params.view(-1), self.pg)
+        elif self.sh_adam and not self.dp:
+            # ONE launch: planes 0..13 (geometry, opacity, SH degree 0) from the gradient planes, the other 45 with the gradient
+            # formed in place
+            self.opt.begin_step(1.0)
+            self.opt.apply_sh_rest(self.drgb1, self.dir1, self.sh_degree, grads_low=self.grads)
         else:
             self.opt.step(self.grads, 1.0 / self.world)
         if ft is not None and not ft_pipe:

@@ -271,3 +271,67 @@ def test_backward_without_its_work_tables():
     scale = np.abs(ref).max(0) + 1e-30
     for key, got in outs.items():
         assert (np.abs(got - ref).max(0) <= 1e-5 * scale).all(), key
+
+
+def test_in_place_sh_adam_is_bit_identical_to_the_plain_step():
+    """One GPU: omfs_project_bwd with gb->drgb_out + gb->dir_out leaves the 45 SH gradient planes of degree >= 1 out, and
+    omfs_adam_step_sh_rest forms Y_k(dir) * drgb where it updates them.  From the same gradient records (project_bwd has no
+    atomics: it is a function of its inputs) both routes -- all 59 planes through the gradient buffer and one Adam launch, or
+    14 planes + the in-place step -- give the SAME BITS in parameters and both moments, for every SH degree."""
+    from omfs_4d_video_gen_amd import _lib as L
+    from omfs_4d_video_gen_amd.engine import synthetic
+    from omfs_4d_video_gen_amd.engine.flame_rig import DeviceFlame, FlameRig
+    from omfs_4d_video_gen_amd.engine.gaussians import GaussianModel, P_SH
+    from omfs_4d_video_gen_amd.engine.rasterizer import Adam, Rasterizer, default_lr_planes, make_camera_struct
+    import ctypes as C
+    N, W, H = 20000, 200, 150
+    rig = synthetic.make_rig(8)
+    g = synthetic.make_gaussians(N, rig.faces.shape[0], 8)
+    dflame = DeviceFlame(FlameRig.from_synthetic(rig), synthetic.make_flame_sequence(2, 8))
+    fxf = dflame.face_frames(1, 1)[1][0]
+    lib, s = L.load(), L.stream_ptr()
+    for deg in (3, 1, 0):
+        ccam = make_camera_struct(synthetic.make_camera(W, H, yaw=0.2), sh_degree=deg, bg=(0.0, 0.0, 0.0))
+        model, rast = GaussianModel(g), Rasterizer(N, W, H)
+        rast.forward(model, fxf, ccam)
+        rast._ensure_bwd()
+        rast.dimage.copy_(torch.randn(3, H, W, generator=torch.Generator().manual_seed(deg)).cuda())
+        rast.dsplat.zero_()
+        gb0 = L.GradBuffersC(L.ptr(rast.dsplat), 0, L.ptr(rast.dimage), 0, 0, 0)
+        L.check(lib.omfs_composite_bwd(ccam, rast.rb, gb0, s), "omfs_composite_bwd")
+        records = rast.dsplat.clone()                                     # project_bwd consumes (zeroes) the records: both routes start from a copy
+        n_pad = model.n_pad
+        p0 = model.params.clone()
+        gen = torch.Generator().manual_seed(5)
+        m0 = (torch.randn(59, n_pad, generator=gen) * 1e-3).cuda()
+        v0 = (torch.rand(59, n_pad, generator=gen) * 1e-6).cuda()
+        rp = L.RegParamsC(0.01, 1.0, 1.0, 0.6, L.ptr(rast.n_visible))
+        gm = rast._gauss(model)
+        out = {}
+        for route in ("plain", "in place"):
+            model.params.copy_(p0)
+            opt = Adam(model, default_lr_planes(position_lr=5e-3))
+            opt.m.copy_(m0); opt.v.copy_(v0)
+            opt.step_count = 6
+            grads = torch.zeros(59, n_pad, device="cuda")
+            grads[:, :N] = 7.0                                             # stale values in the planes a route does not write
+            rast.dsplat.copy_(records)
+            drgb, vdir = torch.zeros(3, n_pad, device="cuda"), torch.zeros(3, n_pad, device="cuda")
+            gb = L.GradBuffersC(L.ptr(rast.dsplat), L.ptr(grads), L.ptr(rast.dimage), 0, 0,
+                                L.ptr(drgb) if route == "in place" else 0, L.ptr(vdir) if route == "in place" else 0)
+            L.check(lib.omfs_project_bwd(gm, L.ptr(fxf), ccam, rast.rb, gb, rp, s), "omfs_project_bwd")
+            if route == "plain":
+                opt.step(grads, 0.5)
+            else:
+                assert float(grads[P_SH + 3:, :N].min()) == 7.0 == float(grads[P_SH + 3:, :N].max())      # never written
+                opt.begin_step(0.5)
+                if deg == 1:                                   # the two-launch form
+                    opt.apply_planes(grads, 0, P_SH + 3)
+                    opt.apply_sh_rest(drgb, vdir, deg)
+                else:                                          # one launch, what the trainer issues
+                    opt.apply_sh_rest(drgb, vdir, deg, grads_low=grads)
+            torch.cuda.synchronize()
+            out[route] = (model.params.clone(), opt.m.clone(), opt.v.clone())
+        for a, b, name in zip(out["plain"], out["in place"], ("params", "m", "v")):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (deg, name, float((a - b).abs().max()))
+        assert not torch.equal(out["plain"][0][P_SH + 3:, :N], p0[P_SH + 3:, :N])          # the step did move the SH planes

@@ -103,6 +103,7 @@ def _single_process_sum(world):
     rig, seq, g, views = _scene()
     tr = Trainer(rig, seq, g, views, W, H, start_sh_degree=3)
     tr.use_graph = False                                  # the optimiser is swapped out below: eager iterations only
+    tr.sh_adam = False                                    # ... and it takes every plane from the gradient buffer this function sums
     total = torch.zeros_like(tr.grads)
     real_step = tr.opt.step
     for s in range(STEPS):
