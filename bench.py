@@ -270,6 +270,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     log(f"timed region done: {dt:.3f}s")
+    if args.steps <= 40:
+        log("per-step ms (HIP events): " + " ".join(f"{x:.3f}" for x in per_step))
     trainer.rast.check_status()
     loss_end = trainer.loss_value()
     ms_per_step = dt / args.steps * 1e3
