@@ -27,7 +27,7 @@ def short(v):
 
 names = {k: short(v) for k, v in con.execute(f"select id, kernel_name from {ks}")}
 rows = con.execute(f"select kernel_id, queue_id, start, end from {kt} order by start").fetchall()
-marks = [i for i, r in enumerate(rows) if names[r[0]].startswith("adam_kernel")]
+marks = [i for i, r in enumerate(rows) if names[r[0]].startswith(("adam_kernel", "adam_sh_rest_kernel"))]   # the Gaussians' Adam launch closes an iteration
 units = []
 for a, b in zip(marks[:-1], marks[1:]):
     seg = rows[a + 1:b + 1]

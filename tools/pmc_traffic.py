@@ -29,7 +29,7 @@ STAGES = {
     "bin_scatter": [("bin_scatter_kernel", 2.0)],
     "project": [("project_fwd_kernel", 2.0)],
     "project_bwd": [("project_bwd_kernel", 2.0), ("count_visible_kernel", 2.0)],
-    "adam": [("adam_kernel", 2.0)],
+    "adam": [("adam_kernel", 2.0), ("adam_sh_rest_kernel", 2.0)],
     "flame": [("flame_joints_kernel", 2.0), ("flame_lbs_kernel", 2.0), ("flame_pose_lbs_kernel", 2.0), ("face_frames_kernel", 1.0)],
     "flame_bwd": [("face_frames_bwd_kernel", 1.0), ("flame_skin_bwd_kernel", 2.0), ("basis_t_gemv_kernel", 2.0),
                   ("flame_skin_gemv_kernel", 2.0), ("adam_flat_multi_kernel", 2.0)],

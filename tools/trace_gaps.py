@@ -1,6 +1,6 @@
 """Idle time between consecutive kernels of one HIP queue in a rocprofv3 --kernel-trace database: where the stream waits
 (event waits, host-bound enqueue, tiny-kernel dispatch).  usage: python tools/trace_gaps.py <dir with *_results.db> [marker]
-`marker` = substring of the kernel that closes one unit of work (default adam_kernel; image_to_rgb8 for the render loop)."""
+`marker` = substring of the kernel that closes one unit of work (default: the Gaussians' Adam launch; image_to_rgb8 for the render loop)."""
 import glob
 import sqlite3
 import sys
@@ -8,13 +8,15 @@ import sys
 import numpy as np
 
 db = glob.glob(sys.argv[1].rstrip("/") + "/*results.db")[0]
-marker = sys.argv[2] if len(sys.argv) > 2 else "adam_kernel"
+marker = sys.argv[2] if len(sys.argv) > 2 else None
 con = sqlite3.connect(db)
 tabs = [r[0] for r in con.execute("select name from sqlite_master where type='table'")]
 kt = [t for t in tabs if "kernel_dispatch" in t][0]
 ks = [t for t in tabs if "kernel_symbol" in t][0]
 names = dict(con.execute(f"select id, kernel_name from {ks}").fetchall())
 rows = con.execute(f"select kernel_id, queue_id, start, end from {kt} order by start").fetchall()
+if marker is None:      # the Gaussians' Adam launch: adam_sh_rest_kernel on one GPU, adam_kernel in data-parallel runs
+    marker = "adam_sh_rest_kernel" if any("adam_sh_rest_kernel" in v for v in names.values()) else "adam_kernel"
 idx = [i for i, r in enumerate(rows) if marker in names[r[0]]]
 gaps, tot, span, busy = {}, [], [], []
 for a, b in zip(idx[:-1], idx[1:]):
