@@ -777,8 +777,6 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
     dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
     Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
   }
-  const float Cf0 = Ci0 - T_final * cam.bg[0], Cf1 = Ci1 - T_final * cam.bg[1], Cf2 = Ci2 - T_final * cam.bg[2];
-  const float bgterm = T_final * (dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2]);
   const uint32_t last = last_g > kseg * OMFS_SEG ? min(last_g - kseg * OMFS_SEG, seg_len) : 0u;  // segment-local
   // last contributor: maxima per 4x4 sub-block and for the quadrant bound what has to be visited
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
@@ -793,15 +791,18 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
   const uint32_t n_visit = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
   if (n_visit == 0) return;
   float T = T_final;
-  // The colour accumulated behind the current splat only ever enters through its dot product with dL/dimage, so the three
-  // per-channel recurrences are carried as ONE scalar per pixel, S = <colour behind, dL/dimage> (7 instructions instead of 13)
-  float S = 0.f;
+  // The colour seen behind the current splat only ever enters through its dot product with dL/dimage, so the three per-channel
+  // recurrences are carried as ONE scalar per pixel, S = <colour behind, dL/dimage>.  "Behind" includes the background: behind a
+  // pixel's last contributor S is <background, dL/dimage>, behind a segment boundary it is the rest of the IMAGE colour over the
+  // checkpointed transmittance -- dC/dalpha_i = T_i (c_i - R_i) with R_{i-1} = alpha_i c_i + (1 - alpha_i) R_i holds with the
+  // background inside R, and the separate -T_final <bg, dL> / (1 - alpha) term of the textbook form disappears.
+  float S = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];
   float la = 0.f, lcd = 0.f;                        // last visited splat: alpha, <colour, dL/dimage>
   if (last_g > (kseg + 1) * OMFS_SEG) {             // the pixel goes on behind this segment
     if (!deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
     const float inv = __builtin_amdgcn_rcpf(ck.x);
     T = ck.x;
-    S = ((Cf0 - ck.y) * dL0 + (Cf1 - ck.z) * dL1 + (Cf2 - ck.w) * dL2) * inv;
+    S = ((Ci0 - ck.y) * dL0 + (Ci1 - ck.z) * dL1 + (Ci2 - ck.w) * dL2) * inv;
   }
   int n_pending = 0;
   auto flush_pending = [&]() {
@@ -920,10 +921,10 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
         T = T * r1a;
         const float w = alpha * T;
         v[6] = w * dL0; v[7] = w * dL1; v[8] = w * dL2;  // dL/dcolour
-        S = fma_(la, lcd, (1.f - la) * S);
+        S = fma_(la, lcd - S, S);                               // the splat behind this one joins what is seen behind
         const float cd = fma_(cb.x, dL2, fma_(c.w, dL1, c.z * dL0));
         lcd = cd; la = alpha;
-        const float dLa = fma_(cd - S, T, -r1a * bgterm);
+        const float dLa = (cd - S) * T;
         // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream rasteriser does
         // (DESIGN.md "Frozen conventions").  Only the moments of gL = dL/dG * G over the pixels are reduced here:
         //   S_x = sum gL dx, S_y, S_xx, S_xy, S_yy  (dx = mean - pixel);
@@ -1054,8 +1055,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFM
     dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
     Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
   }
-  const float Cf0 = Ci0 - T_final * cam.bg[0], Cf1 = Ci1 - T_final * cam.bg[1], Cf2 = Ci2 - T_final * cam.bg[2];
-  const float bgterm = T_final * (dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2]);
   const uint32_t last = last_g > kseg * OMFS_SEG ? min(last_g - kseg * OMFS_SEG, seg_len) : 0u;  // segment-local
   const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
   uint32_t smax[4];
@@ -1099,13 +1098,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFM
   // word of a visit's D rows that output column col is built around: Mu, Mv, Muu, Muv, Mvv, M0; the w row's columns 6..8
   const int own_off = col < 5 ? col + 1 : (col == 5 ? 0 : BV * 16 + min(col, 8));
   float T = T_final;
-  float S = 0.f;                          // <colour accumulated behind the current splat, dL/dimage>
+  float S = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];   // <colour seen behind the current splat, background included, dL/dimage>
   float la = 0.f, lcd = 0.f;              // last visited splat: alpha, <colour, dL/dimage>
   if (last_g > (kseg + 1) * OMFS_SEG) {   // the pixel goes on behind this segment
     if (!deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
     const float inv = __builtin_amdgcn_rcpf(ck.x);
     T = ck.x;
-    S = ((Cf0 - ck.y) * dL0 + (Cf1 - ck.z) * dL1 + (Cf2 - ck.w) * dL2) * inv;
+    S = ((Ci0 - ck.y) * dL0 + (Ci1 - ck.z) * dL1 + (Ci2 - ck.w) * dL2) * inv;
   }
   int n_parked = 0;
   auto flush_batch = [&]() {
@@ -1225,11 +1224,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFM
       const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
       T = T * r1a;
       const float w = alpha * T;
-      S = fma_(la, lcd, (1.f - la) * S);
+      S = fma_(la, lcd - S, S);
       const float cd = fma_(cb.x, dL2, fma_(c.w, dL1, c.z * dL0));
       lcd = cd; la = alpha;
       // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream rasteriser does
-      const float dLa = fma_(cd - S, T, -r1a * bgterm);
+      const float dLa = (cd - S) * T;
       const float gL = oG * dLa;                     // opacity folded in; d opacity = sum gL / opacity
       abuf[n_parked][lane] = gL;
       abuf[BV + n_parked][lane] = w;
