@@ -703,6 +703,9 @@ __device__ __forceinline__ void reduce9_groups(float (&v)[9]) {
 // 8 slots per SIMD usable (0.277 -> 0.245 ms; 2, 6, 8, 12 slots: 0.251, 0.251, 0.261, 0.258).  Round 2: the reduction stops
 // at 4-lane groups (18 DPP adds instead of 27; the flush sums 16 partials instead of 8) with 3 pending slots, which keeps
 // the wave-private LDS at 4.5 KB = 35 waves per CU: 0.235 -> 0.230 ms (with 4 slots, 5.1 KB = 31 waves: 0.250; 2 slots: 0.241).
+#ifndef OMFS_BWD_WHATIF
+#define OMFS_BWD_WHATIF 0
+#endif
 #ifndef OMFS_BWD_PEND
 #define OMFS_BWD_PEND 3
 #endif
@@ -816,7 +819,11 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
 #pragma unroll
         for (int p8 = 0; p8 < NGRP; ++p8) sum += src[p8 * 9];
         const float out = sum;   // moments; omfs_project_bwd turns them into d mean2d / d conic
+#if OMFS_BWD_WHATIF & 2
+        asm volatile("" :: "v"(out));
+#else
         if (out != 0.f) atomicAdd(&dsplat[(size_t)pend_id[slot] * 16 + q], out);
+#endif
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -911,6 +918,9 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
       }
 #endif
       if (hit_bal == 0ull) return;    // nobody in this quadrant was touched: nothing to reduce
+#if OMFS_BWD_WHATIF & 8
+      T += p2; return;
+#endif
       {
         // Branch-free: G is masked to 0 for lanes that are not hit, which makes alpha = 0, 1/(1-alpha) = 1 and every
         // gradient term below exactly 0 for them; their colour recurrence takes a no-op step (a splat of alpha 0).
@@ -938,7 +948,13 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
         v[4] = v[1] * dy;
         v[5] = G * dLa;                                 // d opacity
       }
+#if !(OMFS_BWD_WHATIF & 1)
       reduce9_groups(v);   // the last lane of every OMFS_BWD_GROUP-lane group holds the group's sums
+#endif
+#if OMFS_BWD_WHATIF & 4
+      asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
+      return;
+#endif
       if ((lane & (OMFS_BWD_GROUP - 1)) == OMFS_BWD_GROUP - 1) {
         float* dst = &red[n_pending][lane / OMFS_BWD_GROUP][0];
 #pragma unroll
