@@ -23,6 +23,7 @@
 #ifndef OMFS_SPLAT_H
 #define OMFS_SPLAT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -334,6 +335,26 @@ typedef struct omfs_view_set {
 int omfs_extract_drgb(const omfs_raster_buffers* rb, const float* dsplat, int n, int n_pad, float* drgb_out, void* stream);
 int omfs_sh_rest_grads(const omfs_gaussians* g, const float* face_xf_all, int n_faces, const float* cam_pos_table,
                        const omfs_view_set* views, const float* drgb_all, int sh_degree, float* grads, void* stream);
+
+/* The exchange itself, for hosts that are not PyTorch (SURVEY.md section 8b inner contract: `rccl_allreduce_grads`): RCCL behind the
+ * C ABI, bound with dlopen on first use (libomfs_splat.so does not link against librccl; a process that already holds one keeps
+ * it).  One communicator per rank and process:
+ *   rank 0: omfs_comm_unique_id(id) -> 128 bytes, handed to every rank by the host's own means (a file, MPI, a TCP store ...)
+ *   every rank: omfs_comm_create(id, rank, world_size, &comm) (collective: returns when all ranks have joined; the calling thread's
+ *               current HIP device is the rank's GPU), ... omfs_comm_destroy(comm).
+ * The collectives are enqueued on `stream` and return (stream-ordered like every other entry point; fp32, sum):
+ *   omfs_rccl_allreduce_grads : in place over `count` floats -- the [59][n_pad] gradient buffer, a plane range of it, or the
+ *                               trainer's grad_store with the FLAME gradients in front ("full" / "compact" exchange)
+ *   omfs_rccl_allgather       : all [world][count_per_rank] <- every rank's mine [count_per_rank] (the dL/dcolour planes of the
+ *                               compact exchange; the parameter shards of the sharded one, in place when mine = all + rank * count)
+ *   omfs_rccl_reduce_scatter  : shard [count_per_rank] <- this rank's part of the sum of full [world * count_per_rank]
+ * The Python engine goes through torch.distributed by default (the same RCCL); OMFS_DP_IMPL=abi routes its "full" exchange here. */
+int omfs_comm_unique_id(void* id_host128);
+int omfs_comm_create(const void* id_host128, int rank, int world_size, void** comm_out);
+int omfs_comm_destroy(void* comm);
+int omfs_rccl_allreduce_grads(void* comm, float* grads, size_t count, void* stream);
+int omfs_rccl_allgather(void* comm, const float* mine, float* all, size_t count_per_rank, void* stream);
+int omfs_rccl_reduce_scatter(void* comm, const float* full, float* shard, size_t count_per_rank, void* stream);
 
 /* (1-lambda) L1 + lambda (1-SSIM), 11x11 gaussian window, zero padding.
  * Writes dimage [3][H][W] and the scalar loss into loss_out[0].

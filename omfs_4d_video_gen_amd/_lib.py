@@ -134,6 +134,12 @@ SIGNATURES = {
     "omfs_flame_lbs": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, C.c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
     "omfs_extract_drgb": (C.c_int, [C.POINTER(RasterBuffersC), c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
+    "omfs_comm_unique_id": (C.c_int, [c_void_p]),
+    "omfs_comm_create": (C.c_int, [c_void_p, C.c_int, C.c_int, C.POINTER(c_void_p)]),
+    "omfs_comm_destroy": (C.c_int, [c_void_p]),
+    "omfs_rccl_allreduce_grads": (C.c_int, [c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "omfs_rccl_allgather": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
+    "omfs_rccl_reduce_scatter": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "omfs_sh_rest_grads": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.c_int, c_void_p, C.POINTER(ViewSetC), c_void_p, C.c_int,
                                      c_void_p, c_void_p]),
     "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),

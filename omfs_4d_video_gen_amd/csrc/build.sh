@@ -20,6 +20,8 @@ for src in flame project binning composite project_bwd loss_adam simple_flame de
 done
 "$HIPCC" $FLAGS -x hip -c "$here/api.cpp" -o "$here/api.o" &
 objs+=("$here/api.o")
+"$HIPCC" $FLAGS -x hip -c "$here/collectives.cpp" -o "$here/collectives.o" &      # RCCL by dlopen: no link-time dependency
+objs+=("$here/collectives.o")
 wait
-"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}" -ldl
 echo "built $out"

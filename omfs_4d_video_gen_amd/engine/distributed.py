@@ -47,6 +47,52 @@ def frames_of_rank(n_frames: int, rank: int, world: int) -> range:
     return range(rank, n_frames, world)
 
 
+class AbiComm:
+    """The C ABI's own RCCL communicator (`omfs_comm_*`, `omfs_rccl_*`: include/omfs_splat.h) -- what a host that is not
+    PyTorch would hold.  Rank 0 draws the 128-byte id, `group` (any torch.distributed backend) only carries it to the other
+    ranks; with one rank nothing is exchanged at all.  Every collective is enqueued on torch's current stream."""
+
+    def __init__(self, rank: int = 0, world: int = 1, group=None):
+        import ctypes as C
+        from .. import _lib as L
+        self._L, self.rank, self.world = L, int(rank), int(world)
+        ident = (C.c_ubyte * 128)()
+        if self.rank == 0:
+            L.check(L.load().omfs_comm_unique_id(C.cast(ident, C.c_void_p)), "omfs_comm_unique_id")
+        if self.world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        self._comm = C.c_void_p()
+        L.check(L.load().omfs_comm_create(C.cast(ident, C.c_void_p), self.rank, self.world, C.byref(self._comm)), "omfs_comm_create")
+
+    def allreduce_(self, buf: torch.Tensor) -> torch.Tensor:
+        L = self._L
+        L.check(L.load().omfs_rccl_allreduce_grads(self._comm, L.ptr(buf), buf.numel(), L.stream_ptr()), "omfs_rccl_allreduce_grads")
+        return buf
+
+    def allgather_(self, out: torch.Tensor, mine: torch.Tensor) -> torch.Tensor:
+        L = self._L
+        if out.numel() != self.world * mine.numel():
+            raise ValueError("out must hold world_size pieces of mine's size")
+        L.check(L.load().omfs_rccl_allgather(self._comm, L.ptr(mine), L.ptr(out), mine.numel(), L.stream_ptr()), "omfs_rccl_allgather")
+        return out
+
+    def reduce_scatter_(self, shard: torch.Tensor, full: torch.Tensor) -> torch.Tensor:
+        L = self._L
+        if full.numel() != self.world * shard.numel():
+            raise ValueError("full must hold world_size shards of shard's size")
+        L.check(L.load().omfs_rccl_reduce_scatter(self._comm, L.ptr(full), L.ptr(shard), shard.numel(), L.stream_ptr()),
+                "omfs_rccl_reduce_scatter")
+        return shard
+
+    def close(self):
+        if self._comm:
+            torch.cuda.synchronize()
+            self._L.check(self._L.load().omfs_comm_destroy(self._comm), "omfs_comm_destroy")
+            self._comm = None
+
+
 def allreduce_sum_(buf: torch.Tensor, group=None, async_op: bool = False):
     """In-place sum over ranks of the gradient SoA (or a contiguous plane range of it).  With async_op the work handle
     is returned (call .wait() before reading buf)."""

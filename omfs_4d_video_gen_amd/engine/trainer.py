@@ -144,6 +144,14 @@ class Trainer:
         # "sharded": reduce-scatter of the gradient buffer, Adam on this rank's contiguous 1/W of the [59][n_pad] elements,
         # all-gather of the updated parameters (the Adam moments of the other shards are not maintained on this rank)
         self.sharded_dp = self.dp and mode == "sharded"
+        # OMFS_DP_IMPL=abi: the "full" exchange through the C ABI's own RCCL communicator (omfs_rccl_allreduce_grads) instead of
+        # torch.distributed -- the path a host without PyTorch takes; the process group then only carries the communicator's id
+        self._abi_comm = None
+        if self.dp and os.environ.get("OMFS_DP_IMPL", "torch") == "abi":
+            if self.compact_dp or self.sharded_dp:
+                raise ValueError("OMFS_DP_IMPL=abi drives the full exchange: set OMFS_DP_EXCHANGE=full")
+            from .distributed import AbiComm
+            self._abi_comm = AbiComm(self.rank, self.world, process_group)
         self._dp_patterns = {}
         self._view_steps = {}
         self._gshard = None
@@ -586,6 +594,8 @@ class Trainer:
                         raise ValueError("sharded exchange needs 59 * n_pad divisible by 4 * world_size")
                     self._gshard = torch.empty(S, device=self.device)
                 reduce_scatter_sum_(self._gshard, flat, self.pg)
+            elif self._abi_comm is not None:
+                self._abi_comm.allreduce_(self.grad_store)    # the same collective, issued by the library (omfs_rccl_allreduce_grads)
             else:
                 allreduce_sum_(self.grad_store, self.pg)      # all 59 planes (+ the FLAME gradients in front of them)
             if ft is not None and self.sharded_dp:       # every rank touched a different timestep: dense (tiny) tensors, summed

@@ -158,23 +158,29 @@ def test_sharded_exchange_resumes_from_whole_moments_like_a_continuous_run():
 
 
 def _worker_rccl(port, q, exchange):
+    impl = "torch"
+    if exchange == "full-abi":            # the full exchange issued by the library's own communicator (omfs_rccl_allreduce_grads)
+        exchange, impl = "full", "abi"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", OMFS_DP_EXCHANGE=exchange,
-                      OMFS_DP_FORCE="1")
+                      OMFS_DP_FORCE="1", OMFS_DP_IMPL=impl)
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     from omfs_4d_video_gen_amd.engine.trainer import Trainer
     rig, seq, g, views = _scene()
     tr = Trainer(rig, seq, g, views, W, H, start_sh_degree=3, rank=0, world_size=1, process_group=dist.group.WORLD)
     assert tr.dp and tr.compact_dp == (exchange == "compact") and tr.sharded_dp == (exchange == "sharded")
+    assert (tr._abi_comm is not None) == (impl == "abi")
     for _ in range(STEPS):
         tr.step()
     torch.cuda.synchronize()
     tr.rast.check_status()
     q.put(tr.model.params.cpu().numpy())
+    if tr._abi_comm is not None:
+        tr._abi_comm.close()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["compact", "full", "sharded"])
+@pytest.mark.parametrize("exchange", ["compact", "full", "sharded", "full-abi"])
 def test_exchange_path_over_rccl_with_one_rank_equals_the_plain_step(exchange):
     """The collectives of the data-parallel step issued on the real backend ("nccl" = RCCL; one rank is all a one-GPU
     box has): asynchronous all-gather under project_bwd, asynchronous all-reduce of the 14 planes under the SH update.
@@ -198,6 +204,35 @@ def test_exchange_path_over_rccl_with_one_rank_equals_the_plain_step(exchange):
     torch.cuda.synchronize()
     want = tr.model.params.cpu().numpy()
     assert np.allclose(got, want, rtol=2e-4, atol=2e-6), np.abs(got - want).max()
+
+
+def _worker_abi_comm(q):
+    torch.cuda.set_device(0)
+    from omfs_4d_video_gen_amd.engine.distributed import AbiComm
+    comm = AbiComm(0, 1)
+    x = torch.arange(4096, dtype=torch.float32, device="cuda") * 0.25
+    ref = x.clone()
+    comm.allreduce_(x)                                      # sum over one rank
+    out = torch.zeros_like(ref)
+    comm.allgather_(out, ref)
+    shard = torch.zeros_like(ref)
+    comm.reduce_scatter_(shard, ref)
+    torch.cuda.synchronize()
+    ok = bool(torch.equal(x, ref) and torch.equal(out, ref) and torch.equal(shard, ref))
+    comm.close()
+    q.put(ok)
+
+
+def test_c_abi_communicator_collectives_with_one_rank():
+    """omfs_comm_* / omfs_rccl_* (RCCL bound by dlopen inside libomfs_splat.so, no torch.distributed anywhere): with one rank
+    every collective is the identity.  In a child process: RCCL keeps threads and device state of its own."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_abi_comm, args=(q,))
+    p.start()
+    assert q.get(timeout=180)
+    p.join(60)
+    assert p.exitcode == 0
 
 
 def test_three_exchange_modes_give_the_same_replicas():

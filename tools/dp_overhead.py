@@ -32,9 +32,11 @@ def run(mode, steps):
         views.append(v)
     del tr
     pg = None
-    if mode != "plain":
+    os.environ["OMFS_SH_ADAM"] = "0" if mode == "plain_all_planes" else "1"
+    os.environ["OMFS_DP_IMPL"] = "abi" if mode == "full-abi" else "torch"
+    if not mode.startswith("plain"):
         os.environ["OMFS_DP_FORCE"] = "1"
-        os.environ["OMFS_DP_EXCHANGE"] = mode
+        os.environ["OMFS_DP_EXCHANGE"] = "full" if mode == "full-abi" else mode
         pg = dist.group.WORLD
     else:
         os.environ.pop("OMFS_DP_FORCE", None)
@@ -64,10 +66,13 @@ def main():
     os.environ.setdefault("MASTER_PORT", "29533")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    out = {m: run(m, a.steps) for m in ("plain", "compact", "full", "sharded")}
-    base = out["plain"]["ms_per_step"]
+    # plain = the single-GPU step as benchmarked (45 SH gradient planes formed inside the Adam launch); plain_all_planes = the
+    # same with all 59 planes through the gradient buffer, which is what every exchange mode starts from; full-abi = the full
+    # exchange issued by the library's own communicator (omfs_rccl_allreduce_grads) instead of torch.distributed
+    out = {m: run(m, a.steps) for m in ("plain", "plain_all_planes", "compact", "full", "full-abi", "sharded")}
+    base = out["plain_all_planes"]["ms_per_step"]
     rec = {"workload": "bench default (300k Gaussians, 1920x1080, 16 views, FLAME fine-tuning on)", "steps": a.steps, "modes": out,
-           "overhead_us_over_plain": {m: round((v["ms_per_step"] - base) * 1e3, 1) for m, v in out.items() if m != "plain"},
+           "overhead_us_over_plain_all_planes": {m: round((v["ms_per_step"] - base) * 1e3, 1) for m, v in out.items() if not m.startswith("plain")},
            "note": "one-rank RCCL group (OMFS_DP_FORCE=1): the exchange path without link time; UNMEASURED on more than one GPU"}
     print(json.dumps(rec))
     if a.out:
