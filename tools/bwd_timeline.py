@@ -69,3 +69,18 @@ for impl in ("dpp", "mfma"):
     edges = np.linspace(t0.min(), t1.max(), 11)
     print("   working waves in flight per tenth of the span:", [int(((t0[real] < edges[i + 1]) & (t1[real] > edges[i])).sum()) for i in range(10)])
     print("   working waves STARTED per tenth of the span:  ", [int(((t0[real] >= edges[i]) & (t0[real] < edges[i + 1])).sum()) for i in range(10)])
+    # who makes the tail: visits and lifetimes by start time, and the last finishers
+    rows = []
+    for i in range(10):
+        sel = real & (t0 >= edges[i]) & (t0 < edges[i + 1])
+        rows.append(f"{int(w[sel].mean()) if sel.any() else 0}/{dur[sel].mean() if sel.any() else 0:.0f}")
+    print("   mean visits / mean lifetime (us) of the working waves by the tenth they START in:", rows)
+    order = np.argsort(t1)[::-1]
+    lastn = order[:500]
+    st = (t0[lastn] - t0.min()) * 10e-3
+    print(f"   the 500 last finishers: end {((t1[lastn] - t0.min()) * 10e-3).min():.0f}-{span:.0f} us; started at p10 {np.percentile(st, 10):.0f} p50 {np.percentile(st, 50):.0f} "
+          f"p90 {np.percentile(st, 90):.0f} us; visits p10 {np.percentile(w[lastn], 10):.0f} p50 {np.percentile(w[lastn], 50):.0f} p90 {np.percentile(w[lastn], 90):.0f}; "
+          f"lifetime p50 {np.percentile(dur[lastn], 50):.0f} us")
+    idx = np.nonzero(ok)[0]
+    print(f"   their position in the grid (wave index / 1000): p10 {np.percentile(idx[lastn], 10) / 1e3:.0f} p50 {np.percentile(idx[lastn], 50) / 1e3:.0f} "
+          f"p90 {np.percentile(idx[lastn], 90) / 1e3:.0f} of {idx.max() / 1e3:.0f}; working waves lie at p50 {np.percentile(idx[real], 50) / 1e3:.0f} p99 {np.percentile(idx[real], 99) / 1e3:.0f}")
