@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+import helpers as H
+
 from omfs_4d_video_gen_amd.engine import synthetic
 
 pytestmark = pytest.mark.gpu
@@ -156,8 +158,7 @@ def test_graph_replay_of_whole_iterations_matches_eager_steps(finetune):
     assert lg[-4:].mean() < 0.9 * lg[:4].mean()
     for lo, hi in ((0, 3), (3, 6), (6, 10), (10, 11), (11, 59)):
         a, b = tg.model.params[lo:hi, :n].cpu().numpy(), te.model.params[lo:hi, :n].cpu().numpy()
-        d = np.abs(a - b)
-        assert d.mean() <= 3e-4 * max(1.0, np.abs(b).max()) and d.max() <= 0.1, (lo, d.mean(), d.max())
+        H.assert_same_up_to_atomic_noise(a, b, 3e-4, 0.1, lo)
     if finetune:
         for k in ("expr", "pose", "translation"):
             a, b = tg.flame_ft.params[k].cpu().numpy(), te.flame_ft.params[k].cpu().numpy()
