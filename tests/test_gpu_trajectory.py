@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-import helpers as H
+import helpers
 
 from omfs_4d_video_gen_amd.engine import synthetic
 
@@ -158,7 +158,7 @@ def test_graph_replay_of_whole_iterations_matches_eager_steps(finetune):
     assert lg[-4:].mean() < 0.9 * lg[:4].mean()
     for lo, hi in ((0, 3), (3, 6), (6, 10), (10, 11), (11, 59)):
         a, b = tg.model.params[lo:hi, :n].cpu().numpy(), te.model.params[lo:hi, :n].cpu().numpy()
-        H.assert_same_up_to_atomic_noise(a, b, 3e-4, 0.1, lo)
+        helpers.assert_same_up_to_atomic_noise(a, b, 3e-4, 0.1, lo)
     if finetune:
         for k in ("expr", "pose", "translation"):
             a, b = tg.flame_ft.params[k].cpu().numpy(), te.flame_ft.params[k].cpu().numpy()
