@@ -359,7 +359,7 @@ def main():
                 roofline["valu_issue_util"] = vals["valu_issue_util"]
                 # `limiter` is what the counters say actually holds the kernel; the VALU-side figures say how far that is from
                 # useful work: issue slots used x the fraction of lanes an issued instruction does something for
-                roofline["limiter"] = "valu_issue" if vals["valu_issue_util"] >= 0.6 else "latency / memory"
+                roofline["limiter"] = ("valu_issue + lds_pipe" if dom == "composite_bwd" else "valu_issue") if vals["valu_issue_util"] >= 0.6 else "latency / memory"
                 valu = {"issue_util": vals["valu_issue_util"], "valu_winst_per_launch": round(vals.get("SQ_INSTS_VALU", 0)),
                         "salu_inst_per_launch": round(vals.get("SQ_INSTS_SALU", 0)), "lds_inst_per_launch": round(vals.get("SQ_INSTS_LDS", 0))}
                 vc = os.path.join(ROOT, "profiles", "visit_counters.json")
@@ -370,6 +370,8 @@ def main():
                         valu["useful_lane_issue_frac"] = round(vals["valu_issue_util"] * vj["hit_lanes_per_visit"] / 64.0, 3)
                         valu["visits_per_launch"] = vj.get("visits_per_launch")
                         valu["source"] = vj.get("source")
+                    if vj.get("cycle_account_per_visit_and_cu"):      # both pipes the kernel leans on, per visit and CU
+                        valu["cycles_per_visit_and_cu"] = {k: vj["cycle_account_per_visit_and_cu"][k] for k in ("vector_units", "lds_pipe", "launch_takes")}
                 roofline["valu"] = valu
 
                 roofline["valu_note"] = "SQ_ACTIVE_INST_VALU*4/(1024 SIMDs x kernel cycles), " + os.path.basename(mix)
