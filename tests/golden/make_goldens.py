@@ -20,6 +20,11 @@ What is captured: outputs of the reference's own pure functions
 Only DATA is written (npz / json); no reference source text is stored.
 
   python tests/golden/make_goldens.py [section ...]     # sections: preprocess render_surgery train_ghost flame_fitter surface
+  python tests/golden/make_goldens.py --out DIR         # write everything into DIR instead (the reproducibility test)
+
+`python tests/golden/make_goldens.py && git diff --exit-code tests/golden` is clean: every patch of a reference module is undone at
+the end of its section (_Monkey), temporary paths are normalised, and `-m "not gpu"` runs exactly that comparison whenever
+/root/reference is present (tests/test_reference_goldens.py::test_generator_reproduces_the_committed_goldens).
 
 flame_fitter imports cv2 and mediapipe at module level; neither is used by the functions
 captured here, so two empty placeholder modules are registered before the import.
@@ -37,8 +42,9 @@ from pathlib import Path
 
 import numpy as np
 
-HERE = Path(__file__).resolve().parent
-ROOT = HERE.parent.parent
+SRC = Path(__file__).resolve().parent          # this directory: scenarios.py lives here
+HERE = SRC                                      # where the vectors are written (main() may redirect it: --out DIR)
+ROOT = SRC.parent.parent
 REF = Path("/root/reference/02_Visual_Engine")
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(REF))
@@ -209,27 +215,35 @@ def golden_train_ghost(out):
                                                  "capture_output": kw.get("capture_output"), "text": kw.get("text")})
         return FakeResult()
 
-    tg.validate_setup = lambda: None
-    tg.subprocess.run = fake_run
+    # every patch of the reference's module goes through _Monkey and is undone before the next section runs: a leaked
+    # `validate_setup = lambda: None` made the later `surface` section record "returned None" for the two refusals
+    monkey = _Monkey()
+    monkey(tg, "validate_setup", lambda: None)
+    monkey(tg.subprocess, "run", fake_run)
     argv = {}
     for iters, masks in ((3000, False), (5000, False), (30000, True), (600000, False)):
         d = tmp / f"train_{iters}"
         make_fixture_dataset(d, n_frames=60, with_masks=masks)
         outdir = tmp / f"model_{iters}"
-        with redirect_stdout(io.StringIO()) as buf:
-            tg.train(str(d), str(outdir), iterations=iters, resolution=-1)
+        try:
+            with redirect_stdout(io.StringIO()) as buf:
+                tg.train(str(d), str(outdir), iterations=iters, resolution=-1)
+        except BaseException:
+            monkey.restore()
+            raise
         cmd = captured["calls"][-1]["cmd"]
         cmd_rel = [c.replace(str(d.resolve()), "<DATA>").replace(str(outdir.resolve()), "<MODEL>").replace(str(tg.REPO_DIR), "<ENGINE>") for c in cmd[1:]]
         man = json.loads(next((outdir / "experiment_manifests").iterdir()).read_text())
         argv[str(iters)] = {"argv_after_python": cmd_rel, "has_masks": masks, "manifest_keys": sorted(man.keys()),
                             "manifest_extra": man["extra"], "fingerprint_keys": sorted(man["dataset_fingerprint"].keys()),
                             "kw": {k: captured["calls"][-1][k] for k in ("has_pythonpath", "capture_output", "text")},
-                            "stdout_lines": [l for l in buf.getvalue().splitlines() if l.startswith("[train_ghost]") and "manifest" not in l and "Command" not in l]}
+                            "stdout_lines": [l.replace(str(tmp), "<TMP>") for l in buf.getvalue().splitlines()
+                                             if l.startswith("[train_ghost]") and "manifest" not in l and "Command" not in l]}
     out["train_argv"] = argv
 
     class FailResult:
         returncode = 3
-    tg.subprocess.run = lambda cmd, **kw: FailResult()
+    monkey(tg.subprocess, "run", lambda cmd, **kw: FailResult())
     d = tmp / "train_fail"
     make_fixture_dataset(d, n_frames=60)
     try:
@@ -237,7 +251,9 @@ def golden_train_ghost(out):
             tg.train(str(d), str(tmp / "model_fail"), iterations=100)
     except RuntimeError as e:
         out["train_failure_message"] = str(e)
-    shutil.rmtree(tmp, ignore_errors=True)
+    finally:
+        monkey.restore()
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def golden_flame_fitter(out):
@@ -293,7 +309,7 @@ def golden_flame_fitter(out):
         lmk2d_valid=np.array([l is not None for l in lmk2d]), image_size=np.array([W, H]), head_pose_init=np.array(poses, np.float32),
         **{f"fit{it}_{k}": v for it, r in fits.items() for k, v in r.items() if k not in ("static_offset", "dynamic_offset")},
         fit_static_offset_shape=np.array(fits[3]["static_offset"].shape), fit_dynamic_offset_shape=np.array(fits[3]["dynamic_offset"].shape))
-    sys.path.insert(0, str(HERE))
+    sys.path.insert(0, str(SRC))
     import scenarios as SC
     (tmp / "detect").mkdir()
     detect = SC.detect_landmarks(ff, tmp / "detect")
@@ -359,7 +375,7 @@ def golden_preprocess(out):
 
 def golden_surface(out):
     """The rest of the importable call surface (Missing 1), through the shared scenario drivers."""
-    sys.path.insert(0, str(HERE))
+    sys.path.insert(0, str(SRC))
     import scenarios as SC
     vr = importlib.import_module("validation_reporting")
     rs = importlib.import_module("render_surgery")
@@ -413,9 +429,16 @@ SECTIONS = {"preprocess": golden_preprocess, "render_surgery": golden_render_sur
 
 
 def main():
+    global HERE
+    args = sys.argv[1:]
+    if "--out" in args:                          # tests/test_reference_goldens.py::test_generator_reproduces_the_committed_goldens
+        i = args.index("--out")
+        HERE = Path(args[i + 1]).resolve()
+        HERE.mkdir(parents=True, exist_ok=True)
+        del args[i:i + 2]
     target = HERE / "reference_goldens.json"
-    wanted = sys.argv[1:] or list(SECTIONS)
-    out = json.loads(target.read_text()) if target.exists() and sys.argv[1:] else {}
+    wanted = args or list(SECTIONS)
+    out = json.loads(target.read_text()) if target.exists() and args else {}
     for name in wanted:
         SECTIONS[name](out)
     with open(target, "w") as f:
