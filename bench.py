@@ -56,7 +56,10 @@ def stage_bytes(N, n_pad, D, P, n_tiles, F, D_visit, sh_adam=False):
         "bin_scan": n_tiles * 20,
         "bin_scatter": N * 48 + D * 8,
         "tile_sort": D * 8 + D * 4,
-        "composite_fwd": D * 4 + D * 36 + P * 12 + P * 8,
+        # walked entries only: the forward stops a tile where its last pixel saturates, exactly as the backward does (D_visit =
+        # per tile the deepest last contributor, the quantity the backward is charged for; rounds 1-4 charged all D entries, which
+        # put this stage's "algorithmic" bytes ABOVE its PMC traffic)
+        "composite_fwd": D_visit * 4 + D_visit * 36 + P * 12 + P * 8,
         "loss": 3 * P * (8 + 12) + 3 * P * (12 + 8 + 4),
         # visited entries only: id + 36-byte record gathered, one 40-byte gradient record added per visited entry (float atomics);
         # entries behind a tile's last contributor are never read.  (Round 1-3 charged the atomics for all D entries.)
@@ -145,6 +148,11 @@ def cpu_baseline_train(snap):
         parity = {"stated": helpers.STATED_TOLERANCE, "measured_on_this_step": {k: (round(v, 10) if isinstance(v, float) else v) for k, v in st.items()},
                   "oracle": "oracle/splat_oracle.c (parity UNPINNED: the reference holds no rasteriser; DESIGN.md section 0)"}
     return dt, int(ts[-1]), parity
+
+
+def _lib_identity():
+    from omfs_4d_video_gen_amd import _lib
+    return _lib.library_identity()
 
 
 _T0 = time.perf_counter()
@@ -404,6 +412,7 @@ def main():
         "step_algorithmic_bytes": int(total_bytes),
         "step_hbm_frac": round(total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "final_loss": round(loss_end, 6),
+        "library": _lib_identity(),
     }
 
     # ---- aux: render_surgery fps on the same scene (frames shard across ranks, no collective)
@@ -569,11 +578,26 @@ def main():
     if world > 1:
         from omfs_4d_video_gen_amd.engine.distributed import replicas_in_sync
         out["replicas_in_sync"] = replicas_in_sync(trainer.model.params)
+    # The line is printed in any case -- and the run then FAILS when its own live parity check does: a kernel that no longer
+    # matches the oracle must not leave a green record with a fast number behind.
+    failed = []
+    if "parity" in out and not out["parity"]["measured_on_this_step"].get("holds", False):
+        failed.append("parity.measured_on_this_step.holds is false (GPU image of the bench step vs the C oracle, stated tolerance)")
+    if "cpu_baseline" in out and not out["cpu_baseline"]["D_equals_gpu_tile_pairs_D"]:
+        failed.append(f"tile-pair counts differ: D_cpu={out['cpu_baseline']['D']} D_gpu={D} (tile lists are bit-exact by contract)")
+    if out.get("replicas_in_sync") is False:
+        failed.append("data-parallel replicas diverged")
+    if failed:
+        out["failed_checks"] = failed
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if failed:
+        for f in failed:
+            print(f"[bench] FAILED CHECK: {f}", file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -203,6 +203,7 @@ typedef struct omfs_raster_buffers {
                              which may be anything -- zero it once).                                                    */
 } omfs_raster_buffers;
 #define OMFS_RB_FORWARD_ONLY 1u
+#define OMFS_RB_NO_DEPTH_HINT 2u   /* omfs_composite_fwd ignores the priority hint of a caller-owned quad_depth table (A/B measurements) */
 
 /* deform + project + colour for one view -> g0,g1,g2. face_xf [n_faces][16]. */
 int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_camera* cam,

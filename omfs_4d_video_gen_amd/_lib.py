@@ -13,7 +13,9 @@ import os
 import torch  # noqa: F401  (must be loaded before the HIP library, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libomfs_splat.so")
+# OMFS_LIB_PATH: another build of the SAME ABI (A/B variants under tools/_ab/so/): the tools point the binding at a candidate
+# instead of overwriting the in-tree library, so that nothing run afterwards silently describes a stale variant.
+LIB_PATH = os.environ.get("OMFS_LIB_PATH") or os.path.join(_HERE, "libomfs_splat.so")
 ABI_VERSION = 7
 LOSS_TAIL = 16384              # OMFS_LOSS_TAIL: loss partials behind the three maps of omfs_loss_l1_ssim's scratch
 RB_FORWARD_ONLY = 1
@@ -211,6 +213,47 @@ def load() -> C.CDLL:
         raise OmfsError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+EXPERIMENTS_PATH = os.path.join(_HERE, "libomfs_experiments.so")
+BWD_IMPLS = ("dpp", "mfma", "entries")     # "dpp" is the product's omfs_composite_bwd; the others live in libomfs_experiments.so
+_exp = None
+
+
+def load_experiments() -> C.CDLL:
+    """Second implementations of the composite backward pass (csrc/composite_experiments.hip): tests and tools only --
+    nothing under engine/ calls this."""
+    global _exp
+    if _exp is None:
+        if not os.path.exists(EXPERIMENTS_PATH):
+            raise OmfsError(f"{EXPERIMENTS_PATH} not found: build it with omfs_4d_video_gen_amd/csrc/build.sh")
+        load()
+        lib = C.CDLL(EXPERIMENTS_PATH)
+        lib.omfs_experiment_composite_bwd.restype = C.c_int
+        lib.omfs_experiment_composite_bwd.argtypes = [C.c_char_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC), C.POINTER(GradBuffersC), c_void_p]
+        lib.omfs_experiment_last_error.restype = C.c_char_p
+        _exp = lib
+    return _exp
+
+
+def composite_bwd(impl: str, cam, rb, gb, stream) -> None:
+    """omfs_composite_bwd ("dpp") or one of the experimental implementations of the same contract, by name."""
+    if impl == "dpp":
+        check(load().omfs_composite_bwd(cam, rb, gb, stream), "omfs_composite_bwd")
+        return
+    lib = load_experiments()
+    rc = lib.omfs_experiment_composite_bwd(impl.encode(), cam, rb, gb, stream)
+    if rc != 0:
+        raise OmfsError(f"omfs_experiment_composite_bwd({impl}) failed ({rc}): {lib.omfs_experiment_last_error().decode()}")
+
+
+def library_identity() -> dict:
+    """Which library this process runs: path, ABI version, sha256 prefix of the file (bench.py prints it into its line)."""
+    import hashlib
+    load()
+    with open(LIB_PATH, "rb") as f:
+        h = hashlib.sha256(f.read()).hexdigest()[:16]
+    return {"path": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)), "abi_version": ABI_VERSION, "sha256_16": h}
 
 
 def check(rc: int, what: str) -> None:

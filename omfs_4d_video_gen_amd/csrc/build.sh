@@ -25,3 +25,7 @@ objs+=("$here/collectives.o")
 wait
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}" -ldl
 echo "built $out"
+# Second implementations of the composite backward pass (matrix-core reduction, lanes = list entries): a library of their own, loaded
+# only by tests/ and tools/ -- the shipped library holds ONE backward pass and no switch that changes gradients.
+"$HIPCC" $FLAGS -mllvm -amdgpu-sched-strategy=max-ilp ${EXTRA_HIPCC_FLAGS:-} -shared -o "$here/../libomfs_experiments.so" "$here/composite_experiments.hip"
+echo "built $here/../libomfs_experiments.so"

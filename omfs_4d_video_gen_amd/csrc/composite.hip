@@ -13,139 +13,11 @@
 // power = -0.5(A dx^2 + C dy^2) - B dx dy, skip power > 0; alpha = min(0.99, o exp(power)), skip
 // alpha < 1/255; stop a pixel before a splat that would take T below 1e-4; out = C + T bg.
 // Evaluated here as alpha = exp2(power*log2e + log2 o): same value to ~1e-6 relative.
-#include <cstdlib>
-#include "common.hpp"
+#include "composite_common.hpp"
+
 
 namespace omfs {
 
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LOG2_INV255 = -7.994353436858858f;  // log2(1/255)
-
-struct CompCam {
-  int width, height, gx;
-  float bg[3];
-};
-
-// 4-bit coverage mask of one splat over the four 4x4-pixel sub-blocks of ONE 8x8 quadrant: bit
-// s = (kx&1) + 2(ky&1).  A bit is set when the ellipse {q(d) <= 2 ln(255 o)} -- outside of which
-// alpha < 1/255 -- can overlap the sub-block.  Conservative by construction (blocks are widened by half a
-// pixel, the ellipse by a rounding slack): a cleared bit means no pixel of the sub-block can receive a
-// contribution, so skipping the splat for it changes nothing.  The ellipse is cut by the 3 horizontal
-// lines that bound the quadrant's 2 block rows (one sqrt each); inside a row band the x-extent of the
-// convex set is attained on the two lines or at the ellipse's leftmost / rightmost point.
-__device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, float B, float C, float lo, int qx0, int qy0) {
-  const float qmax = 2.f * 0.6931471805599453f * (lo - LOG2_INV255);
-  if (!(qmax >= 0.f)) return 0u;            // opacity below 1/255: never contributes
-  const float det = A * C - B * B;
-  if (!(A > 0.f && C > 0.f && det > 0.f)) return 0xFu;   // degenerate conic: never cull
-  const float Q = qmax * 1.0002f + 0.02f;
-  const float idet = __builtin_amdgcn_rcpf(det), iA = __builtin_amdgcn_rcpf(A);
-  // v_sqrt_f32 (1 ulp): the slack factors below are three orders of magnitude larger than its error
-  const float vmax = __builtin_amdgcn_sqrtf(Q * A * idet) * 1.0001f, umax = __builtin_amdgcn_sqrtf(Q * C * idet) * 1.0001f;
-  const float vl = B * umax * __builtin_amdgcn_rcpf(C);   // v of the leftmost point (u = -umax); the rightmost is at -vl
-  float vline[3], ulo[3], uhi[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    vline[k] = ((float)qy0 - 0.5f + 4.f * (float)k) - my;
-    const float vc = fminf(fmaxf(vline[k], -vmax), vmax);
-    const float sq = __builtin_amdgcn_sqrtf(fmaxf(A * Q - det * vc * vc, 0.f));
-    ulo[k] = (-B * vc - sq) * iA;
-    uhi[k] = (-B * vc + sq) * iA;
-  }
-  const float x0 = ((float)qx0 - 0.5f) - mx;   // left edge of block column 0, relative to the splat centre
-  uint32_t m = 0;
-#pragma unroll
-  for (int ky = 0; ky < 2; ++ky) {
-    const float v0 = vline[ky], v1 = vline[ky + 1];
-    if (v0 > vmax || v1 < -vmax) continue;
-    const float a = fmaxf(v0, -vmax), b = fminf(v1, vmax);
-    float xlo = (a <= vl && vl <= b) ? -umax : fminf(ulo[ky], ulo[ky + 1]);
-    float xhi = (a <= -vl && -vl <= b) ? umax : fmaxf(uhi[ky], uhi[ky + 1]);
-    xlo -= 0.02f + 1e-4f * fabsf(xlo);
-    xhi += 0.02f + 1e-4f * fabsf(xhi);
-#pragma unroll
-    for (int kx = 0; kx < 2; ++kx) {
-      const float L = x0 + 4.f * (float)kx;
-      if (xhi >= L && xlo <= L + 4.f) m |= 1u << (kx + 2 * ky);
-    }
-  }
-  return m;
-}
-
-#ifdef OMFS_DEBUG_COUNTERS
-__device__ unsigned long long omfs_dbg[32];   // bwd: visits, visits with a hit, hit lanes; fwd: visits, visits with a hit, hit lanes
-#define OMFS_DBG_ADD(i, v) do { if (lane_id() == 0) atomicAdd(&omfs_dbg[i], (unsigned long long)(v)); } while (0)
-#else
-#define OMFS_DBG_ADD(i, v) do { } while (0)
-#endif
-#ifdef OMFS_DEBUG_TIMELINE
-// per-wave (workgroup for the deep forward) start / end on the 100 MHz real-time counter: tools/wave_timeline.py
-constexpr int OMFS_DBG_TL = 1 << 19;
-__device__ unsigned long long omfs_dbg_tl[3][2][OMFS_DBG_TL];
-__device__ uint32_t omfs_dbg_work[3][OMFS_DBG_TL];       // splats visited by the wave
-struct DbgSpan {
-  int k; uint32_t i; unsigned long long t0; uint32_t work;
-  __device__ DbgSpan(int k_, uint32_t i_) : k(k_), i(i_), t0(__builtin_amdgcn_s_memrealtime()), work(0) {}
-  __device__ ~DbgSpan() {
-    if (threadIdx.x == 0 && i < (uint32_t)OMFS_DBG_TL) {
-      omfs_dbg_tl[k][0][i] = t0; omfs_dbg_tl[k][1][i] = __builtin_amdgcn_s_memrealtime(); omfs_dbg_work[k][i] = work;
-    }
-  }
-};
-#define OMFS_DBG_SPAN(k) DbgSpan omfs_dbg_span_(k, blockIdx.x)
-#define OMFS_DBG_WORK() (++omfs_dbg_span_.work)
-// composite_fwd only: shader-clock cycles per phase (0 waiting for the gather, 1 staging, 2 walking, 3 everything else)
-__device__ uint32_t omfs_dbg_phase[4][OMFS_DBG_TL];
-struct DbgPhase {
-  unsigned long long t; uint32_t acc[4];
-  __device__ DbgPhase() : t(__builtin_readcyclecounter()), acc{0u, 0u, 0u, 0u} {}
-  __device__ void mark(int i) { const unsigned long long n = __builtin_readcyclecounter(); acc[i] += (uint32_t)(n - t); t = n; }
-  __device__ ~DbgPhase() {
-    mark(3);
-    if (threadIdx.x == 0 && blockIdx.x < (uint32_t)OMFS_DBG_TL)
-      for (int i = 0; i < 4; ++i) omfs_dbg_phase[i][blockIdx.x] = acc[i];
-  }
-};
-#define OMFS_DBG_PHASES() DbgPhase omfs_dbg_phase_
-#define OMFS_DBG_PHASE(i) omfs_dbg_phase_.mark(i)
-// composite_fwd only: at the end of 64-entry step s (s < 8), 10 ns ticks since the wave started and entries walked so far
-__device__ uint32_t omfs_dbg_step[2][8][OMFS_DBG_TL];
-#define OMFS_DBG_STEP(s) do { if (threadIdx.x == 0 && blockIdx.x < (uint32_t)OMFS_DBG_TL && (s) < 8u) { \
-    omfs_dbg_step[0][s][blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - omfs_dbg_span_.t0); \
-    omfs_dbg_step[1][s][blockIdx.x] = omfs_dbg_span_.work; } } while (0)
-#define OMFS_DBG_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#else
-#define OMFS_DBG_SPAN(k) do { } while (0)
-#define OMFS_DBG_WORK() do { } while (0)
-#define OMFS_DBG_PHASES() do { } while (0)
-#define OMFS_DBG_PHASE(i) do { } while (0)
-#define OMFS_DBG_STEP(s) do { } while (0)
-#define OMFS_DBG_WAIT_VM() do { } while (0)
-#endif
-// Which (unit, quadrant) a workgroup takes, unit = tile position or list segment.  Workgroups go round-robin to the 8 XCDs
-// (linear id mod 8), each with its own L2, and the four quadrants of a unit gather the SAME list entries and records: with
-// (unit, quadrant) = (id / 4, id % 4) the four land on four XCDs and every record is fetched into four L2s.  Here a group of
-// 32 R consecutive workgroups takes 8 R consecutive units, XCD k the run of R units k R .. k R + R - 1 of the group with all
-// four quadrants of each (the grid is a multiple of 4; a last partial group keeps the plain form: a bijection either way).
-#ifndef OMFS_XCD_RUN
-#define OMFS_XCD_RUN 1
-#endif
-__device__ __forceinline__ void unit_quadrant_of_block(uint32_t& unit, int& quad) {
-#ifndef OMFS_NO_XCD_ORDER
-  constexpr uint32_t R = OMFS_XCD_RUN, G = 32u * R;
-  const uint32_t lin = blockIdx.x, group = lin / G;
-  if ((group + 1) * G <= gridDim.x) {
-    const uint32_t in = lin - group * G, k = in & 7u, a = in >> 3;       // a = 0 .. 4 R - 1 on XCD k
-    unit = (group * 8u + k) * R + (a >> 2);
-    quad = (int)(a & 3u);
-    return;
-  }
-#endif
-  unit = blockIdx.x >> 2;
-  quad = (int)(blockIdx.x & 3u);
-}
-
-constexpr int WB = 64;   // splats staged per wave and step
 #ifndef OMFS_FWD_SEQ_SEGS
 #define OMFS_FWD_SEQ_SEGS 4
 #endif
@@ -154,23 +26,6 @@ constexpr int WB = 64;   // splats staged per wave and step
 #endif
 constexpr int FWD_SEQ_SEGS = OMFS_FWD_SEQ_SEGS;   // list segments the one-wave forward walks before handing over
 constexpr int DEEP_WAVES = OMFS_DEEP_WAVES;       // segments evaluated in parallel per deep quadrant
-
-// Lowest set bit of a wave-uniform 64-bit mask: returns its index + 1 (0 for an empty mask) and clears it.  Two scalar
-// instructions (s_ff1_i32_b64 yields -1 for an empty mask, s_bitset0_b64 then clears bit 63 of a mask that is already 0)
-// where `ffsll(m); m &= m - 1` compiles to seven: the scalar unit retires one instruction per ~4 cycles and SIMD
-// (tools/micro/valu_rate.hip), so the bit scans of the visit loops are not free.
-__device__ __forceinline__ int pop_lowest_bit(unsigned long long& m) {
-  int i;
-  asm("s_ff1_i32_b64 %0, %1" : "=s"(i) : "s"(m));
-  asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(i));
-  return i + 1;
-}
-
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-  return v;
-}
 
 // Forward.  One 64-lane workgroup (= one wave) per (tile, 8x8 quadrant); lane l owns pixel (l&7, l>>3) of
 // the quadrant.  No workgroup barrier exists: a wave whose pixels have all saturated simply exits and
@@ -641,25 +496,6 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
   }
 }
 
-// (tile, segment within the tile's list) of global list segment `seg`: one load from the table the forward pass left
-// (composite_fwd_kernel), or -- no table, or the sentinel of an over-long list -- the launch-order position p with
-// order_seg0[p] <= seg < order_seg0[p+1] by bisection (~13 dependent L2-resident loads).
-__device__ __forceinline__ void segment_tile(uint32_t seg, int n_tiles, const uint32_t* __restrict__ tile_order,
-                                             const uint32_t* __restrict__ order_seg0, const uint32_t* __restrict__ seg_table,
-                                             uint32_t& tile, uint32_t& kseg) {
-  if (seg_table) {
-    const uint32_t e = seg_table[seg];
-    if (e != 0xFFFFFFFFu) { tile = e & 0xFFFFu; kseg = e >> 16; return; }
-  }
-  int lo = 0, hi = n_tiles;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (order_seg0[mid] <= seg) lo = mid; else hi = mid;
-  }
-  tile = tile_order[lo];
-  kseg = seg - order_seg0[lo];
-}
-
 // Sums of 9 values over each group of 8 consecutive lanes, left in the group's last lane.  v_add_f32 with a DPP
 // source (row_shr 1, 2, 4; lanes shifted in from outside read as 0) -- one instruction per value and step; the
 // compiler's own lowering of the same pattern is a v_mov_dpp plus a packed add.  A VGPR written by a VALU
@@ -703,9 +539,6 @@ __device__ __forceinline__ void reduce9_groups(float (&v)[9]) {
 // 8 slots per SIMD usable (0.277 -> 0.245 ms; 2, 6, 8, 12 slots: 0.251, 0.251, 0.261, 0.258).  Round 2: the reduction stops
 // at 4-lane groups (18 DPP adds instead of 27; the flush sums 16 partials instead of 8) with 3 pending slots, which keeps
 // the wave-private LDS at 4.5 KB = 35 waves per CU: 0.235 -> 0.230 ms (with 4 slots, 5.1 KB = 31 waves: 0.250; 2 slots: 0.241).
-#ifndef OMFS_BWD_WHATIF
-#define OMFS_BWD_WHATIF 0
-#endif
 #ifndef OMFS_BWD_PEND
 #define OMFS_BWD_PEND 3
 #endif
@@ -819,11 +652,7 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
 #pragma unroll
         for (int p8 = 0; p8 < NGRP; ++p8) sum += src[p8 * 9];
         const float out = sum;   // moments; omfs_project_bwd turns them into d mean2d / d conic
-#if OMFS_BWD_WHATIF & 2
-        asm volatile("" :: "v"(out));
-#else
         if (out != 0.f) atomicAdd(&dsplat[(size_t)pend_id[slot] * 16 + q], out);
-#endif
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -918,9 +747,6 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
       }
 #endif
       if (hit_bal == 0ull) return;    // nobody in this quadrant was touched: nothing to reduce
-#if OMFS_BWD_WHATIF & 8
-      T += p2; return;
-#endif
       {
         // Branch-free: G is masked to 0 for lanes that are not hit, which makes alpha = 0, 1/(1-alpha) = 1 and every
         // gradient term below exactly 0 for them; their colour recurrence takes a no-op step (a splat of alpha 0).
@@ -948,13 +774,7 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
         v[4] = v[1] * dy;
         v[5] = G * dLa;                                 // d opacity
       }
-#if !(OMFS_BWD_WHATIF & 1)
       reduce9_groups(v);   // the last lane of every OMFS_BWD_GROUP-lane group holds the group's sums
-#endif
-#if OMFS_BWD_WHATIF & 4
-      asm volatile("" :: "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]));
-      return;
-#endif
       if ((lane & (OMFS_BWD_GROUP - 1)) == OMFS_BWD_GROUP - 1) {
         float* dst = &red[n_pending][lane / OMFS_BWD_GROUP][0];
 #pragma unroll
@@ -974,290 +794,6 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
   OMFS_DBG_ADD(11, max(max(rowtot_dbg[0], rowtot_dbg[1]), max(rowtot_dbg[2], rowtot_dbg[3])));
   OMFS_DBG_ADD(14, 1);
 #endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Backward, matrix-core reduction (round 4; the round-3 experiment lost on residency: 16-visit batches, two coefficient sets,
-// 13 KB of LDS and 146 VGPRs per wave).  Same decomposition as composite_bwd_kernel -- one wave per (segment, quadrant), lanes =
-// pixels, back-to-front walk from the forward's checkpoints -- but the nine per-splat sums are no longer reduced across lanes
-// with DPP adds.  They are LINEAR in two per-pixel values with coefficients that depend on the pixel only:
-//     gL = opacity * G * dL/dalpha-term,   w = alpha * T                       (per visit and pixel)
-//     M0 = sum gL, Mu = sum gL u, Mv = sum gL v, Muu, Muv, Mvv                  (u, v = pixel position about the quadrant centre)
-//     dC_k = sum w * dL/dimage_k(pixel)
-// i.e. [rows x pixels] . [pixels x 9].  Per visit a lane only parks (gL, w) in LDS (two rows of a 16-row ring: rows 0..7 the gL
-// of eight visits, rows 8..15 their w); every eight visits the wave reads the ring back TRANSPOSED (lane = (row, 16-pixel
-// group): the A operand of v_mfma_f32_16x16x4_f32) and multiplies by ONE constant coefficient matrix held in 16 registers (B
-// operand: lane = (16-pixel group, column); columns 0..5 the monomials, 6..8 dL/dimage): 16 matrix instructions per eight
-// visits, exact fp32 products and accumulation, executed by the matrix cores beside the vector ALU this kernel is bound by.
-// D[row][column]: a gL row carries its six moments in columns 0..5, a w row its three colour sums in columns 6..8 (the other
-// entries of the tile are computed and ignored).  The moments about the quadrant centre become the moments about the splat's
-// own mean (S_x = X M0 - Mu, S_xx = X^2 M0 - 2 X Mu + Muu, ...; X, Y = mean - centre, |u|, |v| <= 3.5) in sixteen lanes per
-// visit -- the 64-byte dsplat record shape the float atomics want.  Replaces per visit: 9 products, 18 v_add_f32_dpp, 9 LDS
-// stores by a quarter of the lanes and the 16-partial flush sums.  The colour recurrence is carried as ONE scalar per pixel,
-// S = <colour behind the splat, dL/dimage> (it only ever enters through that dot product): 7 instructions instead of 13.
-// b where the lane's bit of the wave-uniform mask is set, a elsewhere: ONE v_cndmask_b32 with the mask in a scalar register pair
-// (a nest of `cond ? x : y` over lane-only conditions is otherwise turned into divergent control flow)
-__device__ __forceinline__ float lane_select(float a, float b, unsigned long long mask) {
-  float r;
-  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
-  return r;
-}
-#define COLS(bits16) (0x0001000100010001ull * (unsigned long long)(bits16))   // lanes whose column (lane & 15) is in the 16-bit set
-#ifndef OMFS_BWD_BV
-#define OMFS_BWD_BV 8
-#endif
-constexpr int BV = OMFS_BWD_BV;        // visits per matrix batch (<= 8): rows 0..BV-1 gL, BV..2BV-1 w of the 16-row A tile
-constexpr int AROW = 68;               // floats per ring row: 64 pixels + 4 (rows 0..7 start in distinct 16-byte bank groups)
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-#ifndef OMFS_BWD_MFMA_WAVES
-#define OMFS_BWD_MFMA_WAVES 5
-#endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFMA_WAVES, 8))) void composite_bwd_mfma_kernel(
-    CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_seg0,
-    const float4* __restrict__ seg_ckpt, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ sorted_ids,
-    const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ g2, const float* __restrict__ image,
-    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dimage,
-    float* __restrict__ dsplat, const uint32_t* __restrict__ seg_table, const uint32_t* __restrict__ quad_max) {
-  __shared__ float4 s0[WB];               // mean.x, mean.y, -0.5 log2e A, -log2e B
-  __shared__ float4 s1[WB];               // -0.5 log2e C, log2 opacity, red, green
-  __shared__ float4 s2[WB];               // blue, opacity, Gaussian id (bits), -
-  __shared__ __attribute__((aligned(16))) float abuf[2 * BV][AROW];   // the ring; reused as D [16][16] inside a flush
-  __shared__ float4 svis[BV];             // per parked visit: mean.x, mean.y, opacity, Gaussian id (bits)
-  OMFS_DBG_SPAN(2);
-  uint32_t seg; int quad;
-  unit_quadrant_of_block(seg, quad);
-  if (seg >= order_seg0[n_tiles]) return;
-  uint32_t tile, kseg;
-  segment_tile(seg, n_tiles, tile_order, order_seg0, seg_table, tile, kseg);
-  const int lane = threadIdx.x;
-  // Depth of this quadrant (deepest last contributor of its pixels; one scalar load of the word the forward pass left): the
-  // exact "does anything of this quadrant reach this segment" test and the number of entries to visit, known before any of
-  // the pixel state has arrived -- so the whole head of the wave is ONE batch of loads (pixel state, checkpoint, the first
-  // list entries and their records) instead of three dependent rounds through a memory system busy with gathers and atomics.
-  const uint32_t qdepth = quad_max ? quad_max[tile * 4 + quad] : 0xFFFFFFFFu;
-  if (qdepth <= kseg * OMFS_SEG) return;
-  const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
-  const uint32_t beg = tbeg + kseg * OMFS_SEG, seg_len = min(tend, beg + OMFS_SEG) - beg;
-  const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
-  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
-  const bool inside = px < cam.width && py < cam.height;
-  const float fx = (float)px, fy = (float)py;
-  const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
-  const float T_final = inside ? final_T[o] : 0.f;
-  const uint32_t last_g = inside ? n_contrib[o] : 0u;     // tile-wide, 1-based
-  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f, Ci0 = 0.f, Ci1 = 0.f, Ci2 = 0.f;
-  if (quad_max && inside) {                               // with the depth word the wave is known to have work: load ahead
-    dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
-    Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
-  }
-  const bool deeper = quad_max && qdepth > (kseg + 1) * OMFS_SEG;     // wave-uniform: some pixel goes on behind this segment
-  float4 ck = make_float4(1.f, 0.f, 0.f, 0.f);
-  if (deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
-  // the first step to be staged is the LAST 64-entry step of the visited range
-  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
-  float r2 = 0.f;
-  uint32_t rid = 0;
-  int pre_step = -1;
-  if (quad_max) {
-    const uint32_t n_up = min(qdepth - kseg * OMFS_SEG, seg_len);
-    pre_step = (int)((n_up - 1u) / WB);
-    if ((uint32_t)lane < n_up - (uint32_t)pre_step * WB) {
-      rid = sorted_ids[beg + (uint32_t)pre_step * WB + lane];
-      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
-    }
-  }
-  if (__ballot(last_g > kseg * OMFS_SEG) == 0ull) return;   // nothing of this quadrant reaches this segment (no depth word: decided here)
-  if (!quad_max && inside) {
-    dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
-    Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
-  }
-  const uint32_t last = last_g > kseg * OMFS_SEG ? min(last_g - kseg * OMFS_SEG, seg_len) : 0u;  // segment-local
-  const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
-  uint32_t smax[4];
-#pragma unroll
-  for (int sb = 0; sb < 4; ++sb) {
-    uint32_t v = sidx == sb ? last : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
-    smax[sb] = __builtin_amdgcn_readfirstlane(v);
-  }
-  const uint32_t n_visit = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
-  if (n_visit == 0) return;
-  // ---- the constant B operand: lane (grp = lane >> 4 = k, col = lane & 15), step s -> pixel 16 grp + s, column col
-  const int col = lane & 15, grp = lane >> 4;
-  float cb_[16];
-  {
-    float* sdl = &abuf[0][0];             // [3][64] dL/dimage of the quadrant's pixels (the ring is not in use yet)
-    sdl[lane] = dL0; sdl[64 + lane] = dL1; sdl[128 + lane] = dL2;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // branch-free: column col = a0 + a1 u + a2 u^2 times b0 + b1 v + b2 v^2 with one-hot (a, b) per lane -- (eu, ev) = (0,0) (1,0)
-    // (0,1) (2,0) (1,1) (0,2) for columns 0..5, all zero beyond -- plus, in columns 6..8, the pixel's dL/dimage
-    const float a0 = (col == 0 || col == 2 || col == 5) ? 1.f : 0.f, a1 = (col == 1 || col == 4) ? 1.f : 0.f, a2 = col == 3 ? 1.f : 0.f;
-    const float b0 = (col == 0 || col == 1 || col == 3) ? 1.f : 0.f, b1 = (col == 2 || col == 4) ? 1.f : 0.f, b2 = col == 5 ? 1.f : 0.f;
-    const bool wcol = col >= 6 && col < 9;
-    const float isw = wcol ? 1.f : 0.f;
-    const float4* dsrc = reinterpret_cast<const float4*>(sdl + (wcol ? (col - 6) * 64 : 0) + 16 * grp);
-    const float4 d0 = dsrc[0], d1 = dsrc[1], d2 = dsrc[2], d3 = dsrc[3];
-    const float dv[16] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x, d3.y, d3.z, d3.w};
-    const float v0 = (float)(2 * grp) - 3.5f, v1 = v0 + 1.f;      // pixel 16 grp + s lies in quadrant row 2 grp + (s >> 3)
-    const float fv0 = fma_(b2, v0 * v0, fma_(b1, v0, b0)), fv1 = fma_(b2, v1 * v1, fma_(b1, v1, b0));
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float u = (float)(s & 7) - 3.5f;                       // compile-time
-      const float fu = fma_(a2, u * u, fma_(a1, u, a0));
-      cb_[s] = fma_(dv[s], isw, fu * ((s >> 3) ? fv1 : fv0));
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  const float cx = (float)qx0 + 3.5f, cy = (float)qy0 + 3.5f;
-  // word of a visit's D rows that output column col is built around: Mu, Mv, Muu, Muv, Mvv, M0; the w row's columns 6..8
-  const int own_off = col < 5 ? col + 1 : (col == 5 ? 0 : BV * 16 + min(col, 8));
-  float T = T_final;
-  float S = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];   // <colour seen behind the current splat, background included, dL/dimage>
-  float la = 0.f, lcd = 0.f;              // last visited splat: alpha, <colour, dL/dimage>
-  if (last_g > (kseg + 1) * OMFS_SEG) {   // the pixel goes on behind this segment
-    if (!deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
-    const float inv = __builtin_amdgcn_rcpf(ck.x);
-    T = ck.x;
-    S = ((Ci0 - ck.y) * dL0 + (Ci1 - ck.z) * dL1 + (Ci2 - ck.w) * dL2) * inv;
-  }
-  int n_parked = 0;
-  auto flush_batch = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // A operand: lane (row = col, grp) reads 16 consecutive pixels of its ring row
-    const float4* row = reinterpret_cast<const float4*>(&abuf[col < 2 * BV ? col : 2 * BV - 1][16 * grp]);   // rows beyond 2 BV: unused
-    const float4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
-    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.x, cb_[0], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.y, cb_[1], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.z, cb_[2], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.w, cb_[3], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.x, cb_[4], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.y, cb_[5], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.z, cb_[6], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.w, cb_[7], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.x, cb_[8], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.y, cb_[9], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.z, cb_[10], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.w, cb_[11], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.x, cb_[12], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.y, cb_[13], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.z, cb_[14], acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.w, cb_[15], acc, 0, 0, 0);
-    // D: register r of lane (grp, col) = row 4 grp + r, column col.  The tile goes through LDS (the ring is consumed) so that the
-    // sixteen lanes of a visit's output record see its six moments.
-    __builtin_amdgcn_wave_barrier();
-    float* dbuf = &abuf[0][0];            // [16 rows][16 columns]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dbuf[(4 * grp + r) * 16 + col] = acc[r];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int h = 0; h < (BV + 3) / 4; ++h) {
-      const int i = min(4 * h + grp, BV - 1);     // visit of this lane's 16-lane record (clamped: a pass beyond BV emits nothing)
-      // Branch-free (a select chain over the column compiles to seven divergent paths): column col of the record is
-      //   out = c_own * own + cA * M0 + cB * Mu + cC * Mv
-      // with own = the D entry the column is built around (Mu, Mv, Muu, Muv, Mvv, M0, colour sums: one LDS word at a per-lane
-      // offset) and coefficients that are products of X, Y selected by lane-only predicates (scalar masks, one v_cndmask each):
-      //   S_x = X M0 - Mu | S_y = Y M0 - Mv | S_xx = X^2 M0 - 2X Mu + Muu | S_xy = XY M0 - Y Mu - X Mv + Muv | S_yy = Y^2 M0 - 2Y Mv + Mvv
-      //   d opacity = M0 / opacity | colour sums as they are
-      const float4 m = *reinterpret_cast<const float4*>(&dbuf[i * 16]);          // M0, Mu, Mv, (Muu)
-      const float own = dbuf[i * 16 + own_off];
-      const float4 vis = svis[i];
-      const float X = vis.x - cx, Y = vis.y - cy;
-      // lane-only predicates as literal lane masks (column = lane & 15): one v_cndmask_b32 per select, no control flow
-      const float P = lane_select(lane_select(0.f, Y, COLS(0x0012)), X, COLS(0x000D));       // columns {1,4}: Y, {0,2,3}: X
-      const float Q = lane_select(lane_select(1.f, Y, COLS(0x0018)), X, COLS(0x0004));       // columns {3,4}: Y, {2}: X
-      const float cB = lane_select(lane_select(0.f, -Y, COLS(0x0008)), -2.f * X, COLS(0x0004));
-      const float cC = lane_select(lane_select(0.f, -2.f * Y, COLS(0x0010)), -X, COLS(0x0008));
-      const float c_own = lane_select(lane_select(1.f, __builtin_amdgcn_rcpf(vis.z), COLS(0x0020)), -1.f, COLS(0x0003));
-      const float out = fma_(P * Q, m.x, fma_(cB, m.y, fma_(cC, m.z, c_own * own)));
-      if (4 * h + grp < n_parked && col < 9 && out != 0.f) atomicAdd(&dsplat[(size_t)__float_as_uint(vis.w) * 16 + col], out);
-    }
-    __builtin_amdgcn_wave_barrier();
-    n_parked = 0;
-  };
-  const int n_steps = (int)((n_visit + WB - 1) / WB);
-  if (n_steps - 1 != pre_step) {          // no depth word (or a stale one): gather the first step now
-    const int cnt0 = (int)min((uint32_t)WB, n_visit - (uint32_t)(n_steps - 1) * WB);
-    if (lane < cnt0) {
-      rid = sorted_ids[beg + (uint32_t)(n_steps - 1) * WB + lane];
-      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
-    }
-  }
-  for (int st = n_steps - 1; st >= 0; --st) {
-    const uint32_t cbase = (uint32_t)st * WB;                       // list position of bit 0, 0-based
-    const int cnt = (int)min((uint32_t)WB, n_visit - cbase);
-    uint32_t mask = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < cnt) {
-      const float A = r0.z, B = r0.w, C = r1.x;
-      const float lo2 = __log2f(fmaxf(r1.y, 1e-30f));
-      s0[lane] = make_float4(r0.x, r0.y, -0.5f * LOG2E * A, -LOG2E * B);
-      s1[lane] = make_float4(-0.5f * LOG2E * C, lo2, r1.z, r1.w);
-      s2[lane] = make_float4(r2, r1.y, __uint_as_float(rid), 0.f);
-      mask = quadrant_mask(r0.x, r0.y, A, B, C, lo2, qx0, qy0);
-    }
-    unsigned long long m = 0ull;
-#pragma unroll
-    for (int sb = 0; sb < 4; ++sb) {
-      const unsigned long long bal = __ballot((mask >> sb) & 1u);
-      if (smax[sb] > cbase) {
-        const uint32_t lim = smax[sb] - cbase;
-        m |= bal & (lim >= 64u ? ~0ull : ((1ull << lim) - 1ull));
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (st > 0) {   // every earlier step is full
-      rid = sorted_ids[beg + cbase - WB + lane];
-      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
-    }
-    int jbn = m ? 63 - __builtin_clzll(m) : 0;
-    float4 recA0 = s0[jbn], recA1 = s1[jbn], recA2 = s2[jbn], recB0 = recA0, recB1 = recA1, recB2 = recA2;
-    auto visit = [&](const float4& an, const float4& cn, const float4& cbn, float4& nx0, float4& nx1, float4& nx2) {
-      const int jb = jbn;
-      OMFS_DBG_WORK();
-      m &= ~(1ull << jb);
-      const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
-      const float4 a = an;
-      const float4 c = cn;
-      const float4 cb = cbn;
-      jbn = 63 - __builtin_clzll(m | 1ull);   // prefetch the next splat's record
-      nx0 = s0[jbn]; nx1 = s1[jbn]; nx2 = s2[jbn];
-      const float dx = a.x - fx, dy = a.y - fy;
-      const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
-      const float e = p2 + c.y;
-      const bool hit = contributor <= last && p2 <= 0.f && e >= LOG2_INV255;
-      if (__ballot(hit) == 0ull) return;    // nobody in this quadrant was touched: nothing to park
-      // Branch-free: G is masked to 0 for lanes that are not hit, which makes alpha = 0, 1/(1-alpha) = 1 and both parked values
-      // exactly 0 for them; their recurrence takes a no-op step (a splat of alpha 0).
-      const float G = hit ? __builtin_amdgcn_exp2f(p2) : 0.f;
-      const float oG = cb.y * G;                              // opacity * G
-      const float alpha = fminf(0.99f, oG);
-      const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
-      T = T * r1a;
-      const float w = alpha * T;
-      S = fma_(la, lcd - S, S);
-      const float cd = fma_(cb.x, dL2, fma_(c.w, dL1, c.z * dL0));
-      lcd = cd; la = alpha;
-      // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream rasteriser does
-      const float dLa = (cd - S) * T;
-      const float gL = oG * dLa;                     // opacity folded in; d opacity = sum gL / opacity
-      abuf[n_parked][lane] = gL;
-      abuf[BV + n_parked][lane] = w;
-      if (lane == 0) svis[n_parked] = make_float4(a.x, a.y, cb.y, cb.z);
-      if (++n_parked == BV) flush_batch();
-    };
-    while (m) {
-      visit(recA0, recA1, recA2, recB0, recB1, recB2);
-      if (!m) break;
-      visit(recB0, recB1, recB2, recA0, recA1, recA2);
-    }
-  }
-  if (n_parked) flush_batch();
 }
 
 __global__ void image_to_rgb8_kernel(const float* __restrict__ image, int width, int height, uint8_t* __restrict__ rgb8) {
@@ -1298,26 +834,6 @@ __global__ void image_to_png_rows_kernel(const float* __restrict__ image, int wi
   }
 }
 
-// The segment table of the backward pass lives in `keys`: the (depth, id) pairs are dead once omfs_tile_sort has produced
-// sorted_ids, and the next frame's binning rewrites them.  2 * dup_capacity words hold seg_capacity entries unless the pair
-// capacity is tiny against the tile count (then: no table, the backward bisects).
-static uint32_t* segment_table(const omfs_raster_buffers* rb) {
-  return (rb->keys && rb->order_seg0 && 2ull * rb->dup_capacity >= (unsigned long long)rb->seg_capacity) ? rb->keys : nullptr;
-}
-// ... followed by one word per (tile, quadrant): the quadrant's depth (see composite_fwd_kernel)
-static uint32_t* quadrant_depths(const omfs_raster_buffers* rb, int n_tiles) {
-  if (rb->quad_depth) return rb->quad_depth;       // the caller's own table (per view: also the forward's priority hint)
-  return (segment_table(rb) && 2ull * rb->dup_capacity >= (unsigned long long)rb->seg_capacity + 4ull * (unsigned long long)n_tiles)
-             ? rb->keys + rb->seg_capacity : nullptr;
-}
-
-static CompCam make_compcam(const omfs_camera* c) {
-  CompCam k;
-  k.width = c->width; k.height = c->height; k.gx = cdiv(c->width, OMFS_TILE);
-  for (int i = 0; i < 3; ++i) k.bg[i] = c->bg[i];
-  return k;
-}
-
 }  // namespace omfs
 
 using namespace omfs;
@@ -1334,7 +850,7 @@ extern "C" int omfs_composite_fwd(const omfs_camera* cam, const omfs_raster_buff
                      rb->tile_start, rb->sorted_ids, (const float4*)rb->g0, (const float4*)rb->g1,
                      (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, (float4*)rb->seg_ckpt, keep_ckpt,
                      rb->order_seg0, keep_ckpt ? segment_table(rb) : nullptr, keep_ckpt ? quadrant_depths(rb, n_tiles) : nullptr,
-                     (keep_ckpt && rb->quad_depth && !getenv("OMFS_NO_FWD_HINT")) ? 1 : 0);
+                     (keep_ckpt && rb->quad_depth && !(rb->flags & OMFS_RB_NO_DEPTH_HINT)) ? 1 : 0);
   OMFS_CHECK_HIP(hipGetLastError());
   // quadrants whose list is longer than FWD_SEQ_SEGS segments and still unsaturated (the rest exit at once)
   hipLaunchKernelGGL(composite_fwd_deep_kernel, dim3(n_tiles * 4), dim3(DEEP_WAVES * 64), 0, (hipStream_t)stream, cc, rb->tile_order,
@@ -1353,62 +869,21 @@ extern "C" int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buff
   CompCam cc = make_compcam(cam);
   const int n_tiles = cc.gx * cdiv(cam->height, OMFS_TILE);
   OMFS_REQUIRE(rb->order_seg0 && rb->seg_capacity >= (uint32_t)n_tiles + rb->dup_capacity / OMFS_SEG, "segment buffers");
-  // one wave per (list segment, quadrant); the grid covers the segment capacity, waves beyond the device-side
-  // total (order_seg0[n_tiles]) exit at once.  Two implementations of the same decomposition: the cross-lane reduction with DPP
-  // adds (default) or on the matrix cores (OMFS_BWD_IMPL=mfma: 37 % fewer vector instructions, but 95 VGPRs and 7.4 KB of LDS
-  // per wave leave 5 waves per SIMD where the DPP form keeps 8, and the kernel is bound by the lifetime of its 23 k working
-  // waves, not by instruction issue: 0.221 against 0.200 ms, profiles/r04_bwd_*; kept as a second opinion for the tests)
-  const char* impl = getenv("OMFS_BWD_IMPL");      // read per call: tools switch between the two inside one process
-  if (!(impl && impl[0] == 'm'))
-    hipLaunchKernelGGL(composite_bwd_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
-                       rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
-                       (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat, segment_table(rb), quadrant_depths(rb, n_tiles));
-  else
-    hipLaunchKernelGGL(composite_bwd_mfma_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
-                       rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
-                       (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat, segment_table(rb), quadrant_depths(rb, n_tiles));
+  // one wave per (list segment, quadrant); the grid covers the segment capacity, waves beyond the device-side total
+  // (order_seg0[n_tiles]) exit at once.  ONE implementation lives in this library; the second opinions the tests hold it
+  // against (matrix-core reduction, lanes = list entries) are built into libomfs_experiments.so (composite_experiments.hip).
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
+                     rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
+                     (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat, segment_table(rb), quadrant_depths(rb, n_tiles));
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
 
 #ifdef OMFS_DEBUG_TIMELINE
-extern "C" int omfs_debug_timeline(int kernel, unsigned long long* out, int n, int reset) {   // out [2][n]
-  OMFS_REQUIRE(kernel >= 0 && kernel < 3 && n > 0 && n <= OMFS_DBG_TL, "args");
-  for (int e = 0; e < 2; ++e)
-    OMFS_CHECK_HIP(hipMemcpyFromSymbol(out + (size_t)e * n, HIP_SYMBOL(omfs_dbg_tl), (size_t)n * 8,
-                                       ((size_t)kernel * 2 + e) * OMFS_DBG_TL * 8));
-  if (out && n > 0 && reset == 4) {      // reset == 4: out as uint32 [2][8][n] = per-step ticks and entries of composite_fwd
-    for (int i = 0; i < 16; ++i)
-      OMFS_CHECK_HIP(hipMemcpyFromSymbol((uint32_t*)out + (size_t)i * n, HIP_SYMBOL(omfs_dbg_step), (size_t)n * 4, (size_t)i * OMFS_DBG_TL * 4));
-    void* p = nullptr;
-    OMFS_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(omfs_dbg_step)));
-    OMFS_CHECK_HIP(hipMemset(p, 0, sizeof(uint32_t) * 16 * OMFS_DBG_TL));
-    return OMFS_OK;
-  }
-  if (out && n > 0 && reset == 3) {      // reset == 3: out [4][n/2] (as uint32 [4][n]) = the phase cycles of composite_fwd
-    for (int i = 0; i < 4; ++i)
-      OMFS_CHECK_HIP(hipMemcpyFromSymbol((uint32_t*)out + (size_t)i * n, HIP_SYMBOL(omfs_dbg_phase), (size_t)n * 4, (size_t)i * OMFS_DBG_TL * 4));
-    return OMFS_OK;
-  }
-  if (out && n > 0 && reset >= 2) {      // reset == 2: out [n] also receives the work counters after the two time rows
-    OMFS_CHECK_HIP(hipMemcpyFromSymbol(out + (size_t)2 * n, HIP_SYMBOL(omfs_dbg_work), (size_t)n * 4, (size_t)kernel * OMFS_DBG_TL * 4));
-    return OMFS_OK;
-  }
-  if (reset) {
-    void* p = nullptr;
-    OMFS_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(omfs_dbg_tl)));
-    OMFS_CHECK_HIP(hipMemset(p, 0, sizeof(unsigned long long) * 3 * 2 * OMFS_DBG_TL));
-  }
-  return OMFS_OK;
-}
+extern "C" int omfs_debug_timeline(int kernel, unsigned long long* out, int n, int reset) { return dbg_timeline_read(kernel, out, n, reset); }
 #endif
-
 #ifdef OMFS_DEBUG_COUNTERS
-extern "C" int omfs_debug_counters(unsigned long long* out8, int reset) {
-  OMFS_CHECK_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(omfs_dbg), 256));
-  if (reset) { unsigned long long z[32] = {0}; OMFS_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(omfs_dbg), z, 256)); }
-  return OMFS_OK;
-}
+extern "C" int omfs_debug_counters(unsigned long long* out8, int reset) { return dbg_counters_read(out8, reset); }
 #endif
 
 extern "C" int omfs_image_to_rgb8(const float* image, int width, int height, uint8_t* rgb8, void* stream) {

@@ -1,0 +1,337 @@
+// libomfs_experiments.so -- second implementations of the composite BACKWARD pass, independently written against the same
+// decomposition, buffers and checkpoints as composite_bwd_kernel (composite.hip).  They are test and measurement infrastructure:
+// tests/test_gpu_backward.py holds the product kernel against them, tools/bwd_time.py times them beside it.  Nothing here is
+// linked into libomfs_splat.so, so the shipped library has exactly one backward pass and no build switch that changes gradients.
+//
+//   "mfma"     the cross-lane reduction on the f32 matrix cores (round 4; 0.221 against 0.200 ms: DESIGN.md section 6.1b)
+//   "entries"  lanes = list entries, pixels streamed through the lanes (round 5, VERDICT r4 Next 1; below)
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "composite_common.hpp"
+
+namespace omfs {
+static thread_local char g_exp_error[512] = "";
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_exp_error, sizeof(g_exp_error), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward, matrix-core reduction (round 4; the round-3 experiment lost on residency: 16-visit batches, two coefficient sets,
+// 13 KB of LDS and 146 VGPRs per wave).  Same decomposition as composite_bwd_kernel -- one wave per (segment, quadrant), lanes =
+// pixels, back-to-front walk from the forward's checkpoints -- but the nine per-splat sums are no longer reduced across lanes
+// with DPP adds.  They are LINEAR in two per-pixel values with coefficients that depend on the pixel only:
+//     gL = opacity * G * dL/dalpha-term,   w = alpha * T                       (per visit and pixel)
+//     M0 = sum gL, Mu = sum gL u, Mv = sum gL v, Muu, Muv, Mvv                  (u, v = pixel position about the quadrant centre)
+//     dC_k = sum w * dL/dimage_k(pixel)
+// i.e. [rows x pixels] . [pixels x 9].  Per visit a lane only parks (gL, w) in LDS (two rows of a 16-row ring: rows 0..7 the gL
+// of eight visits, rows 8..15 their w); every eight visits the wave reads the ring back TRANSPOSED (lane = (row, 16-pixel
+// group): the A operand of v_mfma_f32_16x16x4_f32) and multiplies by ONE constant coefficient matrix held in 16 registers (B
+// operand: lane = (16-pixel group, column); columns 0..5 the monomials, 6..8 dL/dimage): 16 matrix instructions per eight
+// visits, exact fp32 products and accumulation, executed by the matrix cores beside the vector ALU this kernel is bound by.
+// D[row][column]: a gL row carries its six moments in columns 0..5, a w row its three colour sums in columns 6..8 (the other
+// entries of the tile are computed and ignored).  The moments about the quadrant centre become the moments about the splat's
+// own mean (S_x = X M0 - Mu, S_xx = X^2 M0 - 2 X Mu + Muu, ...; X, Y = mean - centre, |u|, |v| <= 3.5) in sixteen lanes per
+// visit -- the 64-byte dsplat record shape the float atomics want.  Replaces per visit: 9 products, 18 v_add_f32_dpp, 9 LDS
+// stores by a quarter of the lanes and the 16-partial flush sums.  The colour recurrence is carried as ONE scalar per pixel,
+// S = <colour behind the splat, dL/dimage> (it only ever enters through that dot product): 7 instructions instead of 13.
+// b where the lane's bit of the wave-uniform mask is set, a elsewhere: ONE v_cndmask_b32 with the mask in a scalar register pair
+// (a nest of `cond ? x : y` over lane-only conditions is otherwise turned into divergent control flow)
+__device__ __forceinline__ float lane_select(float a, float b, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+  return r;
+}
+#define COLS(bits16) (0x0001000100010001ull * (unsigned long long)(bits16))   // lanes whose column (lane & 15) is in the 16-bit set
+#ifndef OMFS_BWD_BV
+#define OMFS_BWD_BV 8
+#endif
+constexpr int BV = OMFS_BWD_BV;        // visits per matrix batch (<= 8): rows 0..BV-1 gL, BV..2BV-1 w of the 16-row A tile
+constexpr int AROW = 68;               // floats per ring row: 64 pixels + 4 (rows 0..7 start in distinct 16-byte bank groups)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+#ifndef OMFS_BWD_MFMA_WAVES
+#define OMFS_BWD_MFMA_WAVES 5
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFMA_WAVES, 8))) void composite_bwd_mfma_kernel(
+    CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_seg0,
+    const float4* __restrict__ seg_ckpt, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ sorted_ids,
+    const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ g2, const float* __restrict__ image,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dimage,
+    float* __restrict__ dsplat, const uint32_t* __restrict__ seg_table, const uint32_t* __restrict__ quad_max) {
+  __shared__ float4 s0[WB];               // mean.x, mean.y, -0.5 log2e A, -log2e B
+  __shared__ float4 s1[WB];               // -0.5 log2e C, log2 opacity, red, green
+  __shared__ float4 s2[WB];               // blue, opacity, Gaussian id (bits), -
+  __shared__ __attribute__((aligned(16))) float abuf[2 * BV][AROW];   // the ring; reused as D [16][16] inside a flush
+  __shared__ float4 svis[BV];             // per parked visit: mean.x, mean.y, opacity, Gaussian id (bits)
+  OMFS_DBG_SPAN(2);
+  uint32_t seg; int quad;
+  unit_quadrant_of_block(seg, quad);
+  if (seg >= order_seg0[n_tiles]) return;
+  uint32_t tile, kseg;
+  segment_tile(seg, n_tiles, tile_order, order_seg0, seg_table, tile, kseg);
+  const int lane = threadIdx.x;
+  // Depth of this quadrant (deepest last contributor of its pixels; one scalar load of the word the forward pass left): the
+  // exact "does anything of this quadrant reach this segment" test and the number of entries to visit, known before any of
+  // the pixel state has arrived -- so the whole head of the wave is ONE batch of loads (pixel state, checkpoint, the first
+  // list entries and their records) instead of three dependent rounds through a memory system busy with gathers and atomics.
+  const uint32_t qdepth = quad_max ? quad_max[tile * 4 + quad] : 0xFFFFFFFFu;
+  if (qdepth <= kseg * OMFS_SEG) return;
+  const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
+  const uint32_t beg = tbeg + kseg * OMFS_SEG, seg_len = min(tend, beg + OMFS_SEG) - beg;
+  const int qx0 = (tile % cam.gx) * OMFS_TILE + (quad & 1) * 8, qy0 = (tile / cam.gx) * OMFS_TILE + (quad >> 1) * 8;
+  const int px = qx0 + (lane & 7), py = qy0 + (lane >> 3);
+  const bool inside = px < cam.width && py < cam.height;
+  const float fx = (float)px, fy = (float)py;
+  const size_t plane = (size_t)cam.width * cam.height, o = (size_t)py * cam.width + px;
+  const float T_final = inside ? final_T[o] : 0.f;
+  const uint32_t last_g = inside ? n_contrib[o] : 0u;     // tile-wide, 1-based
+  float dL0 = 0.f, dL1 = 0.f, dL2 = 0.f, Ci0 = 0.f, Ci1 = 0.f, Ci2 = 0.f;
+  if (quad_max && inside) {                               // with the depth word the wave is known to have work: load ahead
+    dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
+    Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
+  }
+  const bool deeper = quad_max && qdepth > (kseg + 1) * OMFS_SEG;     // wave-uniform: some pixel goes on behind this segment
+  float4 ck = make_float4(1.f, 0.f, 0.f, 0.f);
+  if (deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
+  // the first step to be staged is the LAST 64-entry step of the visited range
+  float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0;
+  float r2 = 0.f;
+  uint32_t rid = 0;
+  int pre_step = -1;
+  if (quad_max) {
+    const uint32_t n_up = min(qdepth - kseg * OMFS_SEG, seg_len);
+    pre_step = (int)((n_up - 1u) / WB);
+    if ((uint32_t)lane < n_up - (uint32_t)pre_step * WB) {
+      rid = sorted_ids[beg + (uint32_t)pre_step * WB + lane];
+      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+    }
+  }
+  if (__ballot(last_g > kseg * OMFS_SEG) == 0ull) return;   // nothing of this quadrant reaches this segment (no depth word: decided here)
+  if (!quad_max && inside) {
+    dL0 = dimage[o]; dL1 = dimage[plane + o]; dL2 = dimage[2 * plane + o];
+    Ci0 = image[o]; Ci1 = image[plane + o]; Ci2 = image[2 * plane + o];
+  }
+  const uint32_t last = last_g > kseg * OMFS_SEG ? min(last_g - kseg * OMFS_SEG, seg_len) : 0u;  // segment-local
+  const int sidx = ((lane >> 2) & 1) | (((lane >> 5) & 1) << 1);
+  uint32_t smax[4];
+#pragma unroll
+  for (int sb = 0; sb < 4; ++sb) {
+    uint32_t v = sidx == sb ? last : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, 64));
+    smax[sb] = __builtin_amdgcn_readfirstlane(v);
+  }
+  const uint32_t n_visit = max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+  if (n_visit == 0) return;
+  // ---- the constant B operand: lane (grp = lane >> 4 = k, col = lane & 15), step s -> pixel 16 grp + s, column col
+  const int col = lane & 15, grp = lane >> 4;
+  float cb_[16];
+  {
+    float* sdl = &abuf[0][0];             // [3][64] dL/dimage of the quadrant's pixels (the ring is not in use yet)
+    sdl[lane] = dL0; sdl[64 + lane] = dL1; sdl[128 + lane] = dL2;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // branch-free: column col = a0 + a1 u + a2 u^2 times b0 + b1 v + b2 v^2 with one-hot (a, b) per lane -- (eu, ev) = (0,0) (1,0)
+    // (0,1) (2,0) (1,1) (0,2) for columns 0..5, all zero beyond -- plus, in columns 6..8, the pixel's dL/dimage
+    const float a0 = (col == 0 || col == 2 || col == 5) ? 1.f : 0.f, a1 = (col == 1 || col == 4) ? 1.f : 0.f, a2 = col == 3 ? 1.f : 0.f;
+    const float b0 = (col == 0 || col == 1 || col == 3) ? 1.f : 0.f, b1 = (col == 2 || col == 4) ? 1.f : 0.f, b2 = col == 5 ? 1.f : 0.f;
+    const bool wcol = col >= 6 && col < 9;
+    const float isw = wcol ? 1.f : 0.f;
+    const float4* dsrc = reinterpret_cast<const float4*>(sdl + (wcol ? (col - 6) * 64 : 0) + 16 * grp);
+    const float4 d0 = dsrc[0], d1 = dsrc[1], d2 = dsrc[2], d3 = dsrc[3];
+    const float dv[16] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w, d2.x, d2.y, d2.z, d2.w, d3.x, d3.y, d3.z, d3.w};
+    const float v0 = (float)(2 * grp) - 3.5f, v1 = v0 + 1.f;      // pixel 16 grp + s lies in quadrant row 2 grp + (s >> 3)
+    const float fv0 = fma_(b2, v0 * v0, fma_(b1, v0, b0)), fv1 = fma_(b2, v1 * v1, fma_(b1, v1, b0));
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float u = (float)(s & 7) - 3.5f;                       // compile-time
+      const float fu = fma_(a2, u * u, fma_(a1, u, a0));
+      cb_[s] = fma_(dv[s], isw, fu * ((s >> 3) ? fv1 : fv0));
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  const float cx = (float)qx0 + 3.5f, cy = (float)qy0 + 3.5f;
+  // word of a visit's D rows that output column col is built around: Mu, Mv, Muu, Muv, Mvv, M0; the w row's columns 6..8
+  const int own_off = col < 5 ? col + 1 : (col == 5 ? 0 : BV * 16 + min(col, 8));
+  float T = T_final;
+  float S = dL0 * cam.bg[0] + dL1 * cam.bg[1] + dL2 * cam.bg[2];   // <colour seen behind the current splat, background included, dL/dimage>
+  float la = 0.f, lcd = 0.f;              // last visited splat: alpha, <colour, dL/dimage>
+  if (last_g > (kseg + 1) * OMFS_SEG) {   // the pixel goes on behind this segment
+    if (!deeper) ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg + 1) * 256 + quad * 64 + lane];
+    const float inv = __builtin_amdgcn_rcpf(ck.x);
+    T = ck.x;
+    S = ((Ci0 - ck.y) * dL0 + (Ci1 - ck.z) * dL1 + (Ci2 - ck.w) * dL2) * inv;
+  }
+  int n_parked = 0;
+  auto flush_batch = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // A operand: lane (row = col, grp) reads 16 consecutive pixels of its ring row
+    const float4* row = reinterpret_cast<const float4*>(&abuf[col < 2 * BV ? col : 2 * BV - 1][16 * grp]);   // rows beyond 2 BV: unused
+    const float4 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.x, cb_[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.y, cb_[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.z, cb_[2], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.w, cb_[3], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.x, cb_[4], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.y, cb_[5], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.z, cb_[6], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.w, cb_[7], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.x, cb_[8], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.y, cb_[9], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.z, cb_[10], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.w, cb_[11], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.x, cb_[12], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.y, cb_[13], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.z, cb_[14], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.w, cb_[15], acc, 0, 0, 0);
+    // D: register r of lane (grp, col) = row 4 grp + r, column col.  The tile goes through LDS (the ring is consumed) so that the
+    // sixteen lanes of a visit's output record see its six moments.
+    __builtin_amdgcn_wave_barrier();
+    float* dbuf = &abuf[0][0];            // [16 rows][16 columns]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dbuf[(4 * grp + r) * 16 + col] = acc[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int h = 0; h < (BV + 3) / 4; ++h) {
+      const int i = min(4 * h + grp, BV - 1);     // visit of this lane's 16-lane record (clamped: a pass beyond BV emits nothing)
+      // Branch-free (a select chain over the column compiles to seven divergent paths): column col of the record is
+      //   out = c_own * own + cA * M0 + cB * Mu + cC * Mv
+      // with own = the D entry the column is built around (Mu, Mv, Muu, Muv, Mvv, M0, colour sums: one LDS word at a per-lane
+      // offset) and coefficients that are products of X, Y selected by lane-only predicates (scalar masks, one v_cndmask each):
+      //   S_x = X M0 - Mu | S_y = Y M0 - Mv | S_xx = X^2 M0 - 2X Mu + Muu | S_xy = XY M0 - Y Mu - X Mv + Muv | S_yy = Y^2 M0 - 2Y Mv + Mvv
+      //   d opacity = M0 / opacity | colour sums as they are
+      const float4 m = *reinterpret_cast<const float4*>(&dbuf[i * 16]);          // M0, Mu, Mv, (Muu)
+      const float own = dbuf[i * 16 + own_off];
+      const float4 vis = svis[i];
+      const float X = vis.x - cx, Y = vis.y - cy;
+      // lane-only predicates as literal lane masks (column = lane & 15): one v_cndmask_b32 per select, no control flow
+      const float P = lane_select(lane_select(0.f, Y, COLS(0x0012)), X, COLS(0x000D));       // columns {1,4}: Y, {0,2,3}: X
+      const float Q = lane_select(lane_select(1.f, Y, COLS(0x0018)), X, COLS(0x0004));       // columns {3,4}: Y, {2}: X
+      const float cB = lane_select(lane_select(0.f, -Y, COLS(0x0008)), -2.f * X, COLS(0x0004));
+      const float cC = lane_select(lane_select(0.f, -2.f * Y, COLS(0x0010)), -X, COLS(0x0008));
+      const float c_own = lane_select(lane_select(1.f, __builtin_amdgcn_rcpf(vis.z), COLS(0x0020)), -1.f, COLS(0x0003));
+      const float out = fma_(P * Q, m.x, fma_(cB, m.y, fma_(cC, m.z, c_own * own)));
+      if (4 * h + grp < n_parked && col < 9 && out != 0.f) atomicAdd(&dsplat[(size_t)__float_as_uint(vis.w) * 16 + col], out);
+    }
+    __builtin_amdgcn_wave_barrier();
+    n_parked = 0;
+  };
+  const int n_steps = (int)((n_visit + WB - 1) / WB);
+  if (n_steps - 1 != pre_step) {          // no depth word (or a stale one): gather the first step now
+    const int cnt0 = (int)min((uint32_t)WB, n_visit - (uint32_t)(n_steps - 1) * WB);
+    if (lane < cnt0) {
+      rid = sorted_ids[beg + (uint32_t)(n_steps - 1) * WB + lane];
+      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+    }
+  }
+  for (int st = n_steps - 1; st >= 0; --st) {
+    const uint32_t cbase = (uint32_t)st * WB;                       // list position of bit 0, 0-based
+    const int cnt = (int)min((uint32_t)WB, n_visit - cbase);
+    uint32_t mask = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < cnt) {
+      const float A = r0.z, B = r0.w, C = r1.x;
+      const float lo2 = __log2f(fmaxf(r1.y, 1e-30f));
+      s0[lane] = make_float4(r0.x, r0.y, -0.5f * LOG2E * A, -LOG2E * B);
+      s1[lane] = make_float4(-0.5f * LOG2E * C, lo2, r1.z, r1.w);
+      s2[lane] = make_float4(r2, r1.y, __uint_as_float(rid), 0.f);
+      mask = quadrant_mask(r0.x, r0.y, A, B, C, lo2, qx0, qy0);
+    }
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) {
+      const unsigned long long bal = __ballot((mask >> sb) & 1u);
+      if (smax[sb] > cbase) {
+        const uint32_t lim = smax[sb] - cbase;
+        m |= bal & (lim >= 64u ? ~0ull : ((1ull << lim) - 1ull));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (st > 0) {   // every earlier step is full
+      rid = sorted_ids[beg + cbase - WB + lane];
+      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+    }
+    int jbn = m ? 63 - __builtin_clzll(m) : 0;
+    float4 recA0 = s0[jbn], recA1 = s1[jbn], recA2 = s2[jbn], recB0 = recA0, recB1 = recA1, recB2 = recA2;
+    auto visit = [&](const float4& an, const float4& cn, const float4& cbn, float4& nx0, float4& nx1, float4& nx2) {
+      const int jb = jbn;
+      OMFS_DBG_WORK();
+      m &= ~(1ull << jb);
+      const uint32_t contributor = cbase + (uint32_t)jb + 1u;  // 1-based list position
+      const float4 a = an;
+      const float4 c = cn;
+      const float4 cb = cbn;
+      jbn = 63 - __builtin_clzll(m | 1ull);   // prefetch the next splat's record
+      nx0 = s0[jbn]; nx1 = s1[jbn]; nx2 = s2[jbn];
+      const float dx = a.x - fx, dy = a.y - fy;
+      const float p2 = fma_(a.z * dx, dx, fma_(c.x * dy, dy, a.w * dx * dy));
+      const float e = p2 + c.y;
+      const bool hit = contributor <= last && p2 <= 0.f && e >= LOG2_INV255;
+      if (__ballot(hit) == 0ull) return;    // nobody in this quadrant was touched: nothing to park
+      // Branch-free: G is masked to 0 for lanes that are not hit, which makes alpha = 0, 1/(1-alpha) = 1 and both parked values
+      // exactly 0 for them; their recurrence takes a no-op step (a splat of alpha 0).
+      const float G = hit ? __builtin_amdgcn_exp2f(p2) : 0.f;
+      const float oG = cb.y * G;                              // opacity * G
+      const float alpha = fminf(0.99f, oG);
+      const float r1a = __builtin_amdgcn_rcpf(1.f - alpha);   // 1/(1-alpha), ~1 ulp
+      T = T * r1a;
+      const float w = alpha * T;
+      S = fma_(la, lcd - S, S);
+      const float cd = fma_(cb.x, dL2, fma_(c.w, dL1, c.z * dL0));
+      lcd = cd; la = alpha;
+      // alpha = min(0.99, o*G) is differentiated straight through the clamp, as the upstream rasteriser does
+      const float dLa = (cd - S) * T;
+      const float gL = oG * dLa;                     // opacity folded in; d opacity = sum gL / opacity
+      abuf[n_parked][lane] = gL;
+      abuf[BV + n_parked][lane] = w;
+      if (lane == 0) svis[n_parked] = make_float4(a.x, a.y, cb.y, cb.z);
+      if (++n_parked == BV) flush_batch();
+    };
+    while (m) {
+      visit(recA0, recA1, recA2, recB0, recB1, recB2);
+      if (!m) break;
+      visit(recB0, recB1, recB2, recA0, recA1, recA2);
+    }
+  }
+  if (n_parked) flush_batch();
+}
+}  // namespace omfs
+
+using namespace omfs;
+
+extern "C" const char* omfs_experiment_last_error(void) { return omfs::g_exp_error; }
+#ifdef OMFS_DEBUG_TIMELINE
+extern "C" int omfs_experiment_debug_timeline(int kernel, unsigned long long* out, int n, int reset) { return dbg_timeline_read(kernel, out, n, reset); }
+#endif
+#ifdef OMFS_DEBUG_COUNTERS
+extern "C" int omfs_experiment_debug_counters(unsigned long long* out8, int reset) { return dbg_counters_read(out8, reset); }
+#endif
+
+// Same contract as omfs_composite_bwd (include/omfs_splat.h): must follow omfs_composite_fwd of the same lists in training mode;
+// adds into gb->dsplat.  impl: "mfma" | "entries".
+extern "C" int omfs_experiment_composite_bwd(const char* impl, const omfs_camera* cam, const omfs_raster_buffers* rb,
+                                             const omfs_grad_buffers* gb, void* stream) {
+  OMFS_REQUIRE(impl && cam && rb && gb, "null pointer");
+  OMFS_REQUIRE(rb->g0 && rb->g1 && rb->g2 && rb->tile_order && rb->tile_start && rb->sorted_ids && rb->image &&
+                   rb->final_T && rb->n_contrib && rb->seg_ckpt && gb->dimage && gb->dsplat, "buffers");
+  CompCam cc = make_compcam(cam);
+  const int n_tiles = cc.gx * cdiv(cam->height, OMFS_TILE);
+  OMFS_REQUIRE(rb->order_seg0 && rb->seg_capacity >= (uint32_t)n_tiles + rb->dup_capacity / OMFS_SEG, "segment buffers");
+  if (!strcmp(impl, "mfma")) {
+    hipLaunchKernelGGL(composite_bwd_mfma_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
+                       rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
+                       (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat, segment_table(rb), quadrant_depths(rb, n_tiles));
+  } else {
+    return set_error(OMFS_ERR_ARG, "omfs_experiment_composite_bwd: unknown implementation '%s'", impl);
+  }
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}

@@ -257,6 +257,11 @@ def main(argv=None):
         over = trainer.rast.overflowed()
         if world > 1:
             import torch.distributed as dist
+            if getattr(trainer, "_abi_comm", None) is not None:
+                # OMFS_DP_IMPL=abi: the gradient collectives run on the library's own communicator on the compute stream, this
+                # flag on torch's.  Two communicators must never have kernels of both enqueued in different orders on different
+                # ranks: drain the device first (the call above has read the status word, i.e. synced already -- made explicit)
+                torch.cuda.synchronize()
             flag = torch.tensor([1.0 if over else 0.0], device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             return bool(flag.item() > 0), over
@@ -275,6 +280,8 @@ def main(argv=None):
         return back
 
     it = it0
+    if trainer.graph_iters != 1:
+        raise ValueError("engine/train.py counts ONE iteration per Trainer.step(): graph_iters must stay 1 (a measurement switch of bench.py)")
     while it < args.iterations:
         it += 1
         trainer.step()
@@ -334,6 +341,7 @@ def main(argv=None):
     trainer.rast.check_status()
     if rank == 0:
         print(f"\nTraining complete. [{time.time() - t0:.1f} s]")
+    trainer.close()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -150,8 +150,10 @@ class Trainer:
         if self.dp and os.environ.get("OMFS_DP_IMPL", "torch") == "abi":
             if self.compact_dp or self.sharded_dp:
                 raise ValueError("OMFS_DP_IMPL=abi drives the full exchange: set OMFS_DP_EXCHANGE=full")
+            import atexit
             from .distributed import AbiComm
             self._abi_comm = AbiComm(self.rank, self.world, process_group)
+            atexit.register(self.close)          # a run that never calls close() still destroys the communicator before HIP unloads
         self._dp_patterns = {}
         self._view_steps = {}
         self._gshard = None
@@ -168,9 +170,12 @@ class Trainer:
         # whole iterations as hipGraphs (one per view and buffer parity; single GPU): the step-dependent scalars -- position
         # learning rate, Adam bias corrections -- live in an omfs_step_state on the device, advanced by the graph's first node
         self.use_graph = world_size == 1 and os.environ.get("OMFS_STEP_GRAPH", "0") == "1"
-        # OMFS_GRAPH_ITERS=G (even, single-view training only): ONE graph holds G consecutive iterations, which divides the idle
-        # time ROCm leaves in front of every graph launch (~0.1 ms) by G; a `step()` that replays advances G iterations
-        self.graph_iters = max(1, int(os.environ.get("OMFS_GRAPH_ITERS", "1"))) if len(views) == 1 else 1
+        # graph_iters = G > 1 (even; single-view training only): ONE graph holds G consecutive iterations, which divides the idle
+        # time ROCm leaves in front of every graph launch (~0.1 ms) by G; a `step()` that replays then advances step_idx by G.
+        # A measurement switch (bench.py --graph_aux sets the attribute; there is no environment variable): engine/train.py
+        # counts one iteration per step() and refuses G > 1, and a step whose G iterations would span an SH-degree change is
+        # taken eagerly, one iteration at a time (see step()).
+        self.graph_iters = 1
         self._graphs, self._graph_seen = {}, set()
         self._state = torch.zeros(L.STEP_STATE_WORDS, dtype=torch.int32, device=self.device)
         self._state_step, self._frames_ready = -1, None
@@ -438,11 +443,17 @@ class Trainer:
         view = self.view_for_step(it)
         if it > 0 and it % self.sh_every == 0 and self.sh_degree < self.sh_degree_max:
             self.sh_degree += 1
+        G = self.graph_iters
+        if G > 1 and (G % 2 or len(self.views) != 1):
+            raise ValueError(f"graph_iters={G}: several iterations per graph need an even count (two FLAME buffer sets alternate) and a single view")
+        # a replay of G iterations must not run past the iteration that raises the SH degree (the graph holds ONE degree): the
+        # steps in front of such a boundary are taken eagerly, one at a time, so `it % sh_every == 0` is seen above
+        spans_sh_change = G > 1 and self.sh_degree < self.sh_degree_max and (it // self.sh_every) != ((it + G - 1) // self.sh_every)
         qd = self._qdepth.get(id(view))
         if qd is None:
             qd = self._qdepth[id(view)] = torch.zeros(self.rast.n_tiles, 4, dtype=torch.int32, device=self.device)
         self.rast.rb.quad_depth = L.ptr(qd)
-        if self._graph_eligible():
+        if self._graph_eligible() and not spans_sh_change:
             try:
                 done = self._step_graph(it)
                 if done:
@@ -630,6 +641,12 @@ class Trainer:
     def loss_value(self) -> float:
         """Host sync: loss of the last step on this rank."""
         return float(self.rast.loss.item())
+
+    def close(self) -> None:
+        """Release what the process would otherwise only drop at exit: the C ABI's own RCCL communicator (OMFS_DP_IMPL=abi)."""
+        comm, self._abi_comm = self._abi_comm, None
+        if comm is not None:
+            comm.close()
 
 
 class Renderer:

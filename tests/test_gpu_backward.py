@@ -126,10 +126,10 @@ def test_adam_matches_torch_adam():
 
 
 def test_both_backward_implementations_agree():
-    """omfs_composite_bwd has two independently written cross-lane reductions of the same decomposition (DPP adds, the default;
-    the f32 matrix cores with OMFS_BWD_IMPL=mfma, read per call): on a scene with long lists (deep forward, many segments) their
-    64-byte gradient records agree to 1e-5 of the largest entry per column -- float-atomic order noise only."""
-    import os
+    """The product's omfs_composite_bwd (cross-lane reduction with DPP adds) against the independently written second
+    implementations of the same contract in libomfs_experiments.so (the f32 matrix-core reduction; lanes = list entries): on a
+    scene with long lists (deep forward, many segments) their 64-byte gradient records agree to 1e-5 of the largest entry per
+    column -- float-atomic order noise only."""
     from omfs_4d_video_gen_amd import _lib as L
     from omfs_4d_video_gen_amd.engine import synthetic
     from omfs_4d_video_gen_amd.engine.flame_rig import DeviceFlame, FlameRig
@@ -150,24 +150,18 @@ def test_both_backward_implementations_agree():
     rast.dimage.copy_(torch.randn(3, H, W, generator=torch.Generator().manual_seed(3)).cuda())
     gb = L.GradBuffersC(L.ptr(rast.dsplat), 0, L.ptr(rast.dimage), 0, 0, 0)
     out = {}
-    old = os.environ.get("OMFS_BWD_IMPL")
-    try:
-        for impl in ("dpp", "mfma"):
-            os.environ["OMFS_BWD_IMPL"] = impl
-            rast.dsplat.zero_()
-            L.check(L.load().omfs_composite_bwd(ccam, rast.rb, gb, L.stream_ptr()), "omfs_composite_bwd")
-            torch.cuda.synchronize()
-            out[impl] = rast.dsplat.cpu().numpy().copy()
-    finally:
-        if old is None:
-            os.environ.pop("OMFS_BWD_IMPL", None)
-        else:
-            os.environ["OMFS_BWD_IMPL"] = old
-    a, b = out["dpp"][:, :9], out["mfma"][:, :9]
+    for impl in L.BWD_IMPLS:
+        rast.dsplat.zero_()
+        L.composite_bwd(impl, ccam, rast.rb, gb, L.stream_ptr())
+        torch.cuda.synchronize()
+        out[impl] = rast.dsplat.cpu().numpy().copy()
+    a = out["dpp"][:, :9]
     assert np.abs(a).max() > 0
-    for q in range(9):
-        scale = np.abs(a[:, q]).max()
-        assert np.abs(a[:, q] - b[:, q]).max() <= 1e-5 * scale + 1e-12, (q, np.abs(a[:, q] - b[:, q]).max(), scale)
+    for impl in L.BWD_IMPLS[1:]:
+        b = out[impl][:, :9]
+        for q in range(9):
+            scale = np.abs(a[:, q]).max()
+            assert np.abs(a[:, q] - b[:, q]).max() <= 1e-5 * scale + 1e-12, (impl, q, np.abs(a[:, q] - b[:, q]).max(), scale)
 
 
 def test_quadrant_depth_table_is_exact_and_its_hint_changes_nothing():
@@ -256,14 +250,10 @@ def test_backward_without_its_work_tables():
         r.dimage.copy_(dimage)
         r.dsplat.zero_()
         gb = L.GradBuffersC(L.ptr(r.dsplat), 0, L.ptr(r.dimage), 0, 0, 0)
-        for impl in ("dpp", "mfma"):
-            os.environ["OMFS_BWD_IMPL"] = impl
-            try:
-                r.dsplat.zero_()
-                L.check(L.load().omfs_composite_bwd(ccam, r.rb, gb, L.stream_ptr()), "omfs_composite_bwd")
-                torch.cuda.synchronize()
-            finally:
-                os.environ.pop("OMFS_BWD_IMPL", None)
+        for impl in L.BWD_IMPLS:
+            r.dsplat.zero_()
+            L.composite_bwd(impl, ccam, r.rb, gb, L.stream_ptr())
+            torch.cuda.synchronize()
             r.check_status()
             outs[(name, impl)] = r.dsplat.cpu().numpy()[:, :9].copy()
     ref = outs[("both tables", "dpp")]

@@ -136,7 +136,7 @@ def test_fit_video_and_its_command_line_match_the_reference(setup, tmp_path, mon
     assert got["no_model"] == want["no_model"] and got["missing_required_argument_exit_code"] == want["missing_required_argument_exit_code"]
     for k in ("keys", "shapes", "dtypes"):
         assert got["cli"][k] == want["cli"][k], k
-    num = re.compile(r"-?\\d+\\.\\d+")
+    num = re.compile(r"-?\d+\.\d+")
     assert len(got["cli"]["stdout"]) == len(want["cli"]["stdout"])
     for g, w in zip(got["cli"]["stdout"], want["cli"]["stdout"]):
         assert num.sub("#", g) == num.sub("#", w), (g, w)

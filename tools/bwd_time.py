@@ -1,5 +1,5 @@
-"""Time omfs_composite_bwd alone on the bench scene after `--pretrain` training steps, for both implementations of its cross-lane
-reduction (OMFS_BWD_IMPL=dpp | mfma, read per call): HIP events around `--reps` launches on a fixed state.
+"""Time the composite backward pass alone on the bench scene after `--pretrain` training steps: the product's omfs_composite_bwd
+("dpp") and the second implementations of libomfs_experiments.so ("mfma", "entries"); HIP events around `--reps` launches on a fixed state.
 usage (GPU box): python tools/bwd_time.py [--pretrain 200] [--reps 50] [--tag name]"""
 import argparse
 import json
@@ -18,7 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--pretrain", type=int, default=200)
 ap.add_argument("--reps", type=int, default=50)
 ap.add_argument("--tag", default="")
-ap.add_argument("--impls", default="dpp,mfma")
+ap.add_argument("--impls", default="dpp,mfma,entries")
 a = ap.parse_args()
 N, W, H = 300000, 1920, 1080
 srig = synthetic.make_rig(0)
@@ -42,13 +42,12 @@ gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(t.grads), L.ptr(r.dimage), 0, 0, 0)
 out = {"tag": a.tag, "D": int(r.tile_start[-1])}
 ref = None
 for impl in a.impls.split(","):
-    os.environ["OMFS_BWD_IMPL"] = impl
     times = []
     for k in range(a.reps + 5):
         r.dsplat.zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd")
+        L.composite_bwd(impl, cam, r.rb, gb, s)
         e1.record()
         torch.cuda.synchronize()
         if k >= 5:

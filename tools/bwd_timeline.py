@@ -32,16 +32,15 @@ torch.cuda.synchronize()
 r, lib, s = t.rast, L.load(), L.stream_ptr()
 cam = t._cam(t.view_for_step(t.step_idx - 1), t.sh_degree)
 gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(t.grads), L.ptr(r.dimage), 0, 0, 0)
-cd = ctypes.CDLL(os.path.join(os.path.dirname(L.__file__), "libomfs_splat.so"))
+cd = ctypes.CDLL(L.LIB_PATH)
 NTL = 1 << 19
 buf = (ctypes.c_ulonglong * (3 * NTL))()
 for impl in ("dpp", "mfma"):
-    os.environ["OMFS_BWD_IMPL"] = impl
     for _ in range(3):
-        L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "bwd")
+        L.composite_bwd(impl, cam, r.rb, gb, s)
     torch.cuda.synchronize()
     cd.omfs_debug_timeline(2, buf, NTL, 1)          # reset
-    L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "bwd")
+    L.composite_bwd(impl, cam, r.rb, gb, s)
     torch.cuda.synchronize()
     assert cd.omfs_debug_timeline(2, buf, NTL, 2) == 0
     raw = np.frombuffer(buf, dtype=np.uint64)

@@ -17,7 +17,7 @@ for _ in range(20): t.step()
 torch.cuda.synchronize()
 lib = L.load()._lib if hasattr(L.load(), "_lib") else L.load()
 buf = (ctypes.c_ulonglong * 32)()
-cd = ctypes.CDLL(os.path.join(os.path.dirname(L.__file__), "libomfs_splat.so"))
+cd = ctypes.CDLL(L.LIB_PATH)
 cd.omfs_debug_counters(buf, 1)
 for _ in range(16): t.step()
 torch.cuda.synchronize()

@@ -25,7 +25,7 @@ t = Trainer(rig, seq, synthetic.make_gaussians(N, rig.n_faces, 0), views, W, H, 
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 20):
     t.step()
 torch.cuda.synchronize()
-cd = ctypes.CDLL(os.path.join(os.path.dirname(L.__file__), "libomfs_splat.so"))
+cd = ctypes.CDLL(L.LIB_PATH)
 buf = (ctypes.c_ulonglong * (3 * 16384))()
 cd.omfs_debug_sort_timeline(0, buf, 1)
 t.step()

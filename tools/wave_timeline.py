@@ -25,7 +25,7 @@ t = Trainer(rig, seq, synthetic.make_gaussians(N, rig.n_faces, 0), views, W, H, 
 for _ in range(20):
     t.step()
 torch.cuda.synchronize()
-cd = ctypes.CDLL(os.path.join(os.path.dirname(L.__file__), "libomfs_splat.so"))
+cd = ctypes.CDLL(L.LIB_PATH)
 NTL = 1 << 19
 buf = (ctypes.c_ulonglong * (3 * NTL))()
 cd.omfs_debug_timeline(0, buf, NTL, 1)
