@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define OMFS_ABI_VERSION 7
+#define OMFS_ABI_VERSION 8
 #define OMFS_TILE 16
 #define OMFS_SEG 128     /* list entries per backward segment                                          */
 #define OMFS_NPLANES 59
@@ -255,6 +255,15 @@ typedef struct omfs_grad_buffers {
                              colour was evaluated with (0 for invisible Gaussians).  With drgb_out it is everything the gradient
                              of the 45 SH planes of degree >= 1 is made of, Y_k(dir) * drgb[c]: omfs_adam_step_sh_rest forms
                              it where it is consumed, so those planes are never written nor read; may be NULL          */
+  long long* dsplat_fx;   /* optional [n][16] (ABI 8), zero before the first use: DETERMINISTIC accumulation.  omfs_composite_bwd then
+                             adds every contribution as a 64-bit fixed-point integer (columns 0..4 scaled by 2^38, 5..8 by 2^46;
+                             integer addition is associative, so the sums do not depend on the order the waves arrive in),
+                             converts the totals into `dsplat` and leaves this buffer zero again.  Two runs of the same training
+                             are then bit-identical (with omfs_face_frames_bwd_fx and the split FLAME backward, which has no
+                             float atomics); results differ from the float-atomic path by the quantisation (<= 2^-39 resp.
+                             2^-47 per contribution) and saturate beyond +-2^24 resp. +-2^16.  A few us slower.  May be NULL. */
+  uint32_t n_records;     /* with dsplat_fx: the number of Gaussians the records were projected for (rows of dsplat / dsplat_fx
+                             the conversion walks); ignored otherwise                                                      */
 } omfs_grad_buffers;
 
 /* Must follow omfs_composite_fwd of the SAME lists run in training mode (flags without OMFS_RB_FORWARD_ONLY), with `keys`
@@ -292,6 +301,11 @@ int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buffers* rb, co
  *                          tensors of which one row is written per step never need clearing */
 int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t* faces, int n_faces, const float* dface,
                          const int32_t* face_start, const int32_t* face_gauss, float* dverts, void* stream);
+/* The same with DETERMINISTIC accumulation (ABI 8): the per-corner contributions are added into dverts_fx [v_pad][4] as 64-bit
+ * fixed-point integers (scale 2^40; zero before the first call, left zero), then converted into dverts (overwritten rows:
+ * those of vertices that received a contribution).  See omfs_grad_buffers.dsplat_fx. */
+int omfs_face_frames_bwd_fx(const float* verts, int v_pad, const int32_t* faces, int n_faces, const float* dface,
+                            const int32_t* face_start, const int32_t* face_gauss, float* dverts, long long* dverts_fx, void* stream);
 int omfs_flame_skin_bwd(const omfs_flame_rig* rig, const float* v_shaped, const float* joint_xf, float* dverts,
                         float* dv_shaped, float* sums, void* stream);
 int omfs_flame_rodrigues(const float* axis_angle, int n, float* rotmats, void* stream);

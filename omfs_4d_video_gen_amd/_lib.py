@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OMFS_LIB_PATH: another build of the SAME ABI (A/B variants under tools/_ab/so/): the tools point the binding at a candidate
 # instead of overwriting the in-tree library, so that nothing run afterwards silently describes a stale variant.
 LIB_PATH = os.environ.get("OMFS_LIB_PATH") or os.path.join(_HERE, "libomfs_splat.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 LOSS_TAIL = 16384              # OMFS_LOSS_TAIL: loss partials behind the three maps of omfs_loss_l1_ssim's scratch
 RB_FORWARD_ONLY = 1
 NPLANES = 59
@@ -66,7 +66,7 @@ class RasterBuffersC(C.Structure):
 
 class GradBuffersC(C.Structure):
     _fields_ = [("dsplat", c_void_p), ("grads", c_void_p), ("dimage", c_void_p), ("densify_stats", c_void_p),
-                ("dface", c_void_p), ("drgb_out", c_void_p), ("dir_out", c_void_p)]
+                ("dface", c_void_p), ("drgb_out", c_void_p), ("dir_out", c_void_p), ("dsplat_fx", c_void_p), ("n_records", C.c_uint32)]
 
 
 class ViewSetC(C.Structure):
@@ -146,6 +146,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p]),
     "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_face_frames_bwd": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "omfs_face_frames_bwd_fx": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_flame_skin_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_flame_rodrigues": (C.c_int, [c_void_p, C.c_int, c_void_p, c_void_p]),
     "omfs_flame_param_bwd": (C.c_int, [C.POINTER(FlameRigC), c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -546,6 +546,16 @@ __device__ __forceinline__ void reduce9_groups(float (&v)[9]) {
 #define OMFS_BWD_WAVES 8
 #endif
 #define OMFS_BWD_ATTR __attribute__((amdgpu_waves_per_eu(OMFS_BWD_WAVES, 8)))
+// FX: deterministic accumulation (omfs_grad_buffers.dsplat_fx).  The nine sums of a visited splat are added as 64-bit
+// fixed-point integers instead of floats: integer addition is associative, so the totals do not depend on the order in which
+// the waves arrive.  Everything in front of the flush is the same code.
+constexpr float FX_SCALE_MOMENT = 274877906944.f;        // 2^38: columns 0..4 (moments of dL/dG G; saturate at +-2^24)
+constexpr float FX_SCALE_COLOUR = 70368744177664.f;      // 2^46: columns 5..8 (d opacity, d colour; saturate at +-2^16)
+__device__ __forceinline__ long long to_fixed(float v, float scale) {
+  const float s = fminf(fmaxf(v * scale, -4.6e18f), 4.6e18f);     // |.| < 2^62: the cast below is defined, 2 in-range values never wrap
+  return (long long)__builtin_rintf(s);
+}
+template <bool FX>
 __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order,
                                                            const uint32_t* __restrict__ order_seg0,
                                                            const float4* __restrict__ seg_ckpt,
@@ -556,7 +566,8 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
                                                            const float* __restrict__ final_T,
                                                            const uint32_t* __restrict__ n_contrib,
                                                            const float* __restrict__ dimage, float* __restrict__ dsplat,
-                                                           const uint32_t* __restrict__ seg_table, const uint32_t* __restrict__ quad_max) {
+                                                           const uint32_t* __restrict__ seg_table, const uint32_t* __restrict__ quad_max,
+                                                           long long* __restrict__ dsplat_fx) {
   constexpr int PEND = OMFS_BWD_PEND;     // reduced splats parked before a flush
   __shared__ float4 s0[WB];
   __shared__ float4 s1[WB];
@@ -652,7 +663,13 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
 #pragma unroll
         for (int p8 = 0; p8 < NGRP; ++p8) sum += src[p8 * 9];
         const float out = sum;   // moments; omfs_project_bwd turns them into d mean2d / d conic
-        if (out != 0.f) atomicAdd(&dsplat[(size_t)pend_id[slot] * 16 + q], out);
+        if (FX) {
+          if (out != 0.f)
+            atomicAdd(reinterpret_cast<unsigned long long*>(dsplat_fx) + (size_t)pend_id[slot] * 16 + q,
+                      (unsigned long long)to_fixed(out, q < 5 ? FX_SCALE_MOMENT : FX_SCALE_COLOUR));
+        } else {
+          if (out != 0.f) atomicAdd(&dsplat[(size_t)pend_id[slot] * 16 + q], out);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -796,6 +813,18 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
 #endif
 }
 
+// Deterministic mode: the fixed-point totals become the float records omfs_project_bwd reads; the accumulator is left zero.
+__global__ void dsplat_from_fixed_kernel(long long* __restrict__ fx, float* __restrict__ dsplat, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n16) return;
+  const int q = (int)(i & 15);
+  if (q >= 9) return;
+  const long long v = fx[i];
+  if (v == 0) return;
+  fx[i] = 0;
+  dsplat[i] = (float)((double)v * (q < 5 ? 1.0 / 274877906944.0 : 1.0 / 70368744177664.0));
+}
+
 __global__ void image_to_rgb8_kernel(const float* __restrict__ image, int width, int height, uint8_t* __restrict__ rgb8) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = width * height;
@@ -872,9 +901,23 @@ extern "C" int omfs_composite_bwd(const omfs_camera* cam, const omfs_raster_buff
   // one wave per (list segment, quadrant); the grid covers the segment capacity, waves beyond the device-side total
   // (order_seg0[n_tiles]) exit at once.  ONE implementation lives in this library; the second opinions the tests hold it
   // against (matrix-core reduction, lanes = list entries) are built into libomfs_experiments.so (composite_experiments.hip).
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
-                     rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
-                     (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat, segment_table(rb), quadrant_depths(rb, n_tiles));
+  const dim3 grid(rb->seg_capacity * 4);
+  if (!gb->dsplat_fx) {
+    hipLaunchKernelGGL(composite_bwd_kernel<false>, grid, dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
+                       rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
+                       (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat,
+                       segment_table(rb), quadrant_depths(rb, n_tiles), (long long*)nullptr);
+  } else {
+    // deterministic accumulation: fixed-point integer atomics, then the totals into the float records
+    OMFS_REQUIRE(gb->n_records > 0, "deterministic accumulation needs omfs_grad_buffers.n_records (Gaussians the records were projected for)");
+    hipLaunchKernelGGL(composite_bwd_kernel<true>, grid, dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
+                       rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
+                       (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat,
+                       segment_table(rb), quadrant_depths(rb, n_tiles), gb->dsplat_fx);
+    OMFS_CHECK_HIP(hipGetLastError());
+    const size_t n16 = (size_t)gb->n_records * 16;
+    hipLaunchKernelGGL(dsplat_from_fixed_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gb->dsplat_fx, gb->dsplat, n16);
+  }
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include "composite_common.hpp"
 
 namespace omfs {
@@ -303,6 +304,194 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFM
   }
   if (n_parked) flush_batch();
 }
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward, lanes = LIST ENTRIES (round 5; VERDICT r4 Next 1: the per-splat form published with "Taming 3DGS").
+// One wave per 128-entry list segment of a tile, walked FRONT TO BACK in two passes of 64 entries: lane l holds entry
+// 64 pass + l of the segment in registers for the whole pass (its record is gathered straight into the lane: no staging),
+// and the tile's pixels STREAM through the lanes, one pixel per lane and step: at step t lane l evaluates pixel t - l.  The
+// running pixel state -- the transmittance T in front of the entry and Rem = <everything composited behind it, dL/dimage>
+// (background included; un-normalised) -- is handed from lane l to lane l + 1 by two DPP moves (wave_shr:1), lane 0 picks
+// the next pixel's state up from LDS; what does not change along the walk (dL/dimage, position, last contributor) is read
+// by every lane from an LDS table at index t - l (consecutive lanes read consecutive records: conflict-free).  Each lane
+// keeps ITS entry's nine sums in registers, so there is NO cross-lane reduction and no per-visit parking; once per pass the
+// 64 x 9 sums go through LDS into the 16-lanes-per-64-byte-record shape the float atomics want.
+//   per (entry, pixel):  w = alpha T,  Rem -= w <c, dL>,  dL/dalpha = T <c, dL> - Rem / (1 - alpha),  T *= 1 - alpha
+//   start of the segment: T and <C, dL> from the forward's checkpoint in front of it (1 and 0 for the first segment), and
+//   Rem = <final image, dL/dimage> - <C, dL>.
+// Only pixels whose last contributor lies in or behind the segment enter the stream (ballot compaction while the table is
+// built), entries behind the tile's deepest last contributor are not loaded.  The table is padded by 64 inert pixels (last
+// contributor 0) in front and behind, so the skewed start and end of the pipeline need no branch: a pass over n pixels takes
+// n + 63 steps of all 64 lanes whatever the number of entries it holds -- the fill the design pays.
+constexpr int ENT_PAD = 64;                    // inert pixels in front of / behind the stream
+constexpr int ENT_TABLE = ENT_PAD + 256 + ENT_PAD + 8;
+#ifndef OMFS_ENT_WAVES
+#define OMFS_ENT_WAVES 3
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_ENT_WAVES, 8))) void composite_bwd_entries_kernel(
+    CompCam cam, int n_tiles, const uint32_t* __restrict__ tile_order, const uint32_t* __restrict__ order_seg0,
+    const float4* __restrict__ seg_ckpt, const uint32_t* __restrict__ tile_start, const uint32_t* __restrict__ sorted_ids,
+    const float4* __restrict__ g0, const float4* __restrict__ g1, const float4* __restrict__ g2, const float* __restrict__ image,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dimage,
+    float* __restrict__ dsplat, const uint32_t* __restrict__ seg_table, const uint32_t* __restrict__ quad_max) {
+  __shared__ float4 pstat[ENT_TABLE];          // dL/dimage (3), packed: byte 0 = x in the tile, 1 = y, 2 = last contributor relative to the segment (0 .. 255)
+  __shared__ float2 pstate[ENT_TABLE];         // T, Rem in front of the pass
+  __shared__ float fl[64][13];                 // the pass's sums, [entry][value] (stride 13: conflict-free both ways)
+  __shared__ uint32_t fid[64];
+  OMFS_DBG_SPAN(2);
+  const uint32_t seg = blockIdx.x;
+  if (seg >= order_seg0[n_tiles]) return;
+  uint32_t tile, kseg;
+  segment_tile(seg, n_tiles, tile_order, order_seg0, seg_table, tile, kseg);
+  const int lane = threadIdx.x;
+  const uint32_t tbeg = tile_start[tile], tend = tile_start[tile + 1];
+  const uint32_t first = kseg * OMFS_SEG;                         // entries in front of this segment (tile-wide, 0-based)
+  const uint32_t seg_len = min(tend - tbeg - first, (uint32_t)OMFS_SEG);
+  // deepest last contributor of the tile: nothing behind it is visited
+  uint32_t depth = 0xFFFFFFFFu;
+  if (quad_max) {
+    const uint32_t* q = quad_max + tile * 4;
+    depth = max(max(q[0], q[1]), max(q[2], q[3]));
+  }
+  if (depth <= first) return;
+  const uint32_t n_ent = min(depth - first, seg_len);             // entries of this segment that some pixel reaches
+  const int tx0 = (tile % cam.gx) * OMFS_TILE, ty0 = (tile / cam.gx) * OMFS_TILE;
+  const size_t plane = (size_t)cam.width * cam.height;
+  // ---- the pixel table: four rounds of 64 pixels (round = 8x8 quadrant, the checkpoints' layout), compacted to the pixels that reach the segment
+  const float4 inert = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = lane; i < ENT_TABLE; i += 64) { pstat[i] = inert; pstate[i] = make_float2(0.f, 0.f); }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int n_pix = 0;
+#pragma unroll
+  for (int quad = 0; quad < 4; ++quad) {
+    const int xl = (quad & 1) * 8 + (lane & 7), yl = (quad >> 1) * 8 + (lane >> 3);
+    const int px = tx0 + xl, py = ty0 + yl;
+    const bool inside = px < cam.width && py < cam.height;
+    const size_t o = (size_t)py * cam.width + px;
+    const uint32_t last_g = inside ? n_contrib[o] : 0u;
+    const bool alive = last_g > first;
+    const unsigned long long bal = __ballot(alive);
+    if (alive) {
+      const float dL0 = dimage[o], dL1 = dimage[plane + o], dL2 = dimage[2 * plane + o];
+      const float cdot = fma_(image[2 * plane + o], dL2, fma_(image[plane + o], dL1, image[o] * dL0));
+      float T0 = 1.f, p0 = 0.f;
+      if (kseg > 0) {
+        const float4 ck = seg_ckpt[((size_t)(tbeg / OMFS_SEG) + tile + kseg) * 256 + quad * 64 + lane];
+        T0 = ck.x;
+        p0 = fma_(ck.w, dL2, fma_(ck.z, dL1, ck.y * dL0));
+      }
+      const uint32_t rel = min(last_g - first, 255u);
+      const int slot = ENT_PAD + n_pix + __popcll(bal & ((1ull << lane) - 1ull));
+      pstat[slot] = make_float4(dL0, dL1, dL2, __uint_as_float((uint32_t)xl | (uint32_t)yl << 8 | rel << 16));
+      pstate[slot] = make_float2(T0, cdot - p0);
+    }
+    n_pix += __popcll(bal);
+  }
+  if (n_pix == 0) return;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int n_steps = (n_pix + 63 + 3) & ~3;                      // in fours (the tail pad absorbs the extra steps)
+  const int n_pass = n_ent > 64u ? 2 : 1;
+  // counters of tools/entries_profile.py (-DOMFS_DEBUG_COUNTERS): units, passes, streamed pixels, entries, wave-steps, hit lanes
+  OMFS_DBG_ADD(14, 1); OMFS_DBG_ADD(15, n_pass); OMFS_DBG_ADD(8, n_pix); OMFS_DBG_ADD(9, n_ent); OMFS_DBG_ADD(0, n_pass * n_steps);
+  for (int pass = 0; pass < n_pass; ++pass) {
+    // ---- this lane's entry
+    const uint32_t e_rel = (uint32_t)pass * 64u + (uint32_t)lane;   // position inside the segment
+    const bool have = e_rel < n_ent;
+    float mxl = 0.f, myl = 0.f, qa = 0.f, qb = 0.f, qc = 0.f, lo = -1e30f, cr = 0.f, cg = 0.f, cb = 0.f, opac = 1.f;
+    uint32_t id = 0;
+    if (have) {
+      id = sorted_ids[tbeg + first + e_rel];
+      const float4 r0 = g0[id], r1 = g1[id];
+      const float r2 = g2[id].x;
+      mxl = r0.x - (float)tx0; myl = r0.y - (float)ty0;             // exact: both are multiples of ulp(mean) (see DESIGN)
+      qa = -0.5f * LOG2E * r0.z; qb = -LOG2E * r0.w; qc = -0.5f * LOG2E * r1.x;
+      opac = r1.y;
+      lo = __log2f(fmaxf(r1.y, 1e-30f));
+      cr = r1.z; cg = r1.w; cb = r2;
+    }
+    const float crel = (float)(e_rel + 1u);                          // 1-based, relative to the segment
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f;
+    float T = 0.f, Rem = 0.f;
+    const bool more = pass + 1 < n_pass;
+    int idx = ENT_PAD - lane;                                        // table index of pixel t - lane at t = 0
+    // The table reads of the NEXT four steps are issued in front of the current four (a lane-63 store below may not be moved
+    // across a later read by the compiler, although no read of this pass ever follows it to the same slot): LDS latency is
+    // then covered by a whole iteration of arithmetic.
+    float4 sn[4];
+    float2 pn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sn[u] = pstat[idx + u]; pn[u] = pstate[idx + u]; }
+    auto stream = [&](auto keep) {
+      constexpr bool KEEP = decltype(keep)::value;
+      for (int t = 0; t < n_steps; t += 4) {
+        float4 sc[4];
+        float2 pc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sc[u] = sn[u]; pc[u] = pn[u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sn[u] = pstat[idx + 4 + u]; pn[u] = pstate[idx + 4 + u]; }   // the tail pad covers the last over-read
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 st = sc[u];
+          // lane l takes the state lane l - 1 left; lane 0 keeps what it read from the table (no valid DPP source: `old` stays)
+          T = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pc[u].x), __float_as_int(T), 0x138, 0xF, 0xF, false));
+          Rem = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(pc[u].y), __float_as_int(Rem), 0x138, 0xF, 0xF, false));
+          OMFS_DBG_WORK();
+          const uint32_t pk = __float_as_uint(st.w);
+          const float fxl = (float)(pk & 0xFFu), fyl = (float)((pk >> 8) & 0xFFu), lastrel = (float)((pk >> 16) & 0xFFu);   // v_cvt_f32_ubyte0 / 1 / 2
+          const float dx = mxl - fxl, dy = myl - fyl;
+          const float p2 = fma_(qa * dx, dx, fma_(qc * dy, dy, qb * dx * dy));
+          const float e = p2 + lo;
+          float ev = p2 <= 0.f ? e : -1e30f;
+          ev = ev >= LOG2_INV255 ? ev : -1e30f;
+          ev = crel <= lastrel ? ev : -1e30f;
+          const float oG = __builtin_amdgcn_exp2f(ev);                 // 0 unless the pixel takes the splat
+#ifdef OMFS_DEBUG_COUNTERS
+          { const unsigned long long hb = __ballot(oG > 0.f); OMFS_DBG_ADD(2, __popcll(hb)); OMFS_DBG_ADD(1, hb != 0ull); }
+#endif
+          const float alpha = fminf(0.99f, oG);
+          const float om = 1.f - alpha;
+          const float ra = __builtin_amdgcn_rcpf(om);
+          const float w = alpha * T;
+          const float cd = fma_(cb, st.z, fma_(cg, st.y, cr * st.x));
+          Rem = fma_(-w, cd, Rem);
+          const float dLa = fma_(T, cd, -(Rem * ra));
+          const float gL = oG * dLa;                                   // alpha's clamp differentiated straight through (frozen convention)
+          const float gx = gL * dx, gy = gL * dy;
+          v0 += gx; v1 += gy;
+          v2 = fma_(gx, dx, v2); v3 = fma_(gx, dy, v3); v4 = fma_(gy, dy, v4);
+          v5 += gL;
+          v6 = fma_(w, st.x, v6); v7 = fma_(w, st.y, v7); v8 = fma_(w, st.z, v8);
+          T *= om;
+          if (KEEP && lane == 63) pstate[idx + u] = make_float2(T, Rem);   // the state behind entry 64 pass + 63: the next pass starts there
+        }
+        idx += 4;
+      }
+    };
+    if (more) stream(std::true_type{}); else stream(std::false_type{});
+    // ---- 64 x 9 sums -> 16 lanes per 64-byte record
+    __builtin_amdgcn_wave_barrier();
+    fl[lane][0] = v0; fl[lane][1] = v1; fl[lane][2] = v2; fl[lane][3] = v3; fl[lane][4] = v4;
+    fl[lane][5] = v5 * __builtin_amdgcn_rcpf(opac);                  // d opacity = sum G dL/dalpha = sum (o G dL/dalpha) / o
+    fl[lane][6] = v6; fl[lane][7] = v7; fl[lane][8] = v8;
+    fid[lane] = id;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t n_here = min(n_ent - (uint32_t)pass * 64u, 64u);
+    for (uint32_t base = 0; base < n_here; base += 4) {
+      const uint32_t rec = base + (uint32_t)(lane >> 4);
+      const int q = lane & 15;
+      if (rec < n_here && q < 9) {
+        const float out = fl[rec][q];
+        if (out != 0.f) atomicAdd(&dsplat[(size_t)fid[rec] * 16 + q], out);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace omfs
 
 using namespace omfs;
@@ -327,6 +516,11 @@ extern "C" int omfs_experiment_composite_bwd(const char* impl, const omfs_camera
   OMFS_REQUIRE(rb->order_seg0 && rb->seg_capacity >= (uint32_t)n_tiles + rb->dup_capacity / OMFS_SEG, "segment buffers");
   if (!strcmp(impl, "mfma")) {
     hipLaunchKernelGGL(composite_bwd_mfma_kernel, dim3(rb->seg_capacity * 4), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
+                       rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
+                       (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat, segment_table(rb), quadrant_depths(rb, n_tiles));
+  } else if (!strcmp(impl, "entries")) {
+    // one wave per list segment (not per quadrant): the grid covers the segment capacity
+    hipLaunchKernelGGL(composite_bwd_entries_kernel, dim3(rb->seg_capacity), dim3(64), 0, (hipStream_t)stream, cc, n_tiles,
                        rb->tile_order, rb->order_seg0, (const float4*)rb->seg_ckpt, rb->tile_start, rb->sorted_ids, (const float4*)rb->g0,
                        (const float4*)rb->g1, (const float4*)rb->g2, rb->image, rb->final_T, rb->n_contrib, gb->dimage, gb->dsplat, segment_table(rb), quadrant_depths(rb, n_tiles));
   } else {

@@ -358,9 +358,13 @@ __global__ void face_frames_kernel(const float* __restrict__ verts, int v_pad, c
 // Every lane then holds all thirteen sums (row permutes) and evaluates the small gradient of the frame record
 // (R columns a0, n, a2; centre; scale) w.r.t. the three vertices; lanes 0..8 add one component each into dverts with a
 // float atomic (a vertex belongs to ~6 faces).  The clamps of safe_normalize3 are not differentiated.
+// FX (omfs_face_frames_bwd_fx): the nine corner contributions are added as 64-bit fixed-point integers (scale 2^40) -- integer
+// addition is associative, the totals do not depend on the order the faces arrive in -- and converted by dverts_from_fixed_kernel.
+template <bool FX>
 __global__ __launch_bounds__(256) void face_frames_bwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, int n_faces,
                                                               const float* __restrict__ dface, const int32_t* __restrict__ face_start,
-                                                              const int32_t* __restrict__ face_gauss, float* __restrict__ dverts) {
+                                                              const int32_t* __restrict__ face_gauss, float* __restrict__ dverts,
+                                                              long long* __restrict__ dverts_fx) {
   const int f = (blockIdx.x * blockDim.x + threadIdx.x) >> 4;
   const int q = threadIdx.x & 15, lane = threadIdx.x & 63, row0 = lane & 48;
   const bool live = f < n_faces;
@@ -436,8 +440,22 @@ __global__ __launch_bounds__(256) void face_frames_bwd_kernel(const float* __res
     const float c3 = dc[k] * third;
     const float val = vtx == 0 ? c3 - de1[k] - de2[k] : (vtx == 1 ? c3 + de1[k] : c3 + de2[k]);
     const int iv = vtx == 0 ? i0 : (vtx == 1 ? i1 : i2);
-    atomicAdd(&dverts[(size_t)iv * 4 + k], val);
+    if (FX) {
+      const float sc = fminf(fmaxf(val * 1099511627776.f, -4.6e18f), 4.6e18f);     // 2^40; |.| < 2^62
+      atomicAdd(reinterpret_cast<unsigned long long*>(dverts_fx) + (size_t)iv * 4 + k, (unsigned long long)(long long)__builtin_rintf(sc));
+    } else {
+      atomicAdd(&dverts[(size_t)iv * 4 + k], val);
+    }
   }
+}
+
+__global__ void dverts_from_fixed_kernel(long long* __restrict__ fx, float* __restrict__ dverts, int n4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4 || (i & 3) == 3) return;
+  const long long v = fx[i];
+  if (v == 0) return;
+  fx[i] = 0;
+  dverts[i] = (float)((double)v * (1.0 / 1099511627776.0));
 }
 
 // One thread per vertex: v_posed = M_v [v_shaped; 1] + ..., M_v = sum_j w_vj X_j; v_shaped [v_pad][4] was stored by
@@ -976,8 +994,20 @@ extern "C" int omfs_face_frames_bwd(const float* verts, int v_pad, const int32_t
                                     const int32_t* face_start, const int32_t* face_gauss, float* dverts, void* stream) {
   OMFS_REQUIRE(verts && faces && dface && face_start && face_gauss && dverts, "null pointer");
   OMFS_REQUIRE(n_faces > 0 && v_pad > 0, "shape");
-  hipLaunchKernelGGL(face_frames_bwd_kernel, dim3(cdiv(n_faces * 16, 256)), dim3(256), 0, (hipStream_t)stream, verts, faces,
-                     n_faces, dface, face_start, face_gauss, dverts);
+  hipLaunchKernelGGL(face_frames_bwd_kernel<false>, dim3(cdiv(n_faces * 16, 256)), dim3(256), 0, (hipStream_t)stream, verts, faces,
+                     n_faces, dface, face_start, face_gauss, dverts, (long long*)nullptr);
+  OMFS_CHECK_HIP(hipGetLastError());
+  return OMFS_OK;
+}
+
+extern "C" int omfs_face_frames_bwd_fx(const float* verts, int v_pad, const int32_t* faces, int n_faces, const float* dface,
+                                       const int32_t* face_start, const int32_t* face_gauss, float* dverts, long long* dverts_fx, void* stream) {
+  OMFS_REQUIRE(verts && faces && dface && face_start && face_gauss && dverts && dverts_fx, "null pointer");
+  OMFS_REQUIRE(n_faces > 0 && v_pad > 0, "shape");
+  hipLaunchKernelGGL(face_frames_bwd_kernel<true>, dim3(cdiv(n_faces * 16, 256)), dim3(256), 0, (hipStream_t)stream, verts, faces,
+                     n_faces, dface, face_start, face_gauss, dverts, dverts_fx);
+  OMFS_CHECK_HIP(hipGetLastError());
+  hipLaunchKernelGGL(dverts_from_fixed_kernel, dim3(cdiv(v_pad * 4, 256)), dim3(256), 0, (hipStream_t)stream, dverts_fx, dverts, v_pad * 4);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

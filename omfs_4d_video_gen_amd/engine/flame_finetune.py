@@ -62,6 +62,13 @@ class FlameFineTuner:
         # cross-lane reduction is needed (omfs_flame_skin_param_bwd)
         self.basis_t = up(dflame.h_basis.transpose(2, 1, 0).reshape(3 * V, self.n_coef))
         self.fused = os.environ.get("OMFS_FLAME_SPLIT", "0") != "1"
+        # OMFS_DETERMINISTIC=1: the split launches (per-wave partial rows and block reductions in a fixed order: no float atomics)
+        # behind a fixed-point omfs_face_frames_bwd_fx -- the FLAME gradients are then bit-reproducible from run to run
+        self.deterministic = os.environ.get("OMFS_DETERMINISTIC", "0") == "1"
+        self.dverts_fx = None
+        if self.deterministic:
+            self.fused = False
+            self.dverts_fx = torch.zeros(dflame.v_pad, 4, dtype=torch.int64, device=dflame.device)
         dflame.keep_v_shaped = True
         dflame.pose = self.pose                              # the joints launch refreshes rotmats from these
         dflame._scratch.clear()
@@ -137,8 +144,12 @@ class FlameFineTuner:
         joint_all, _, _, _, vs_all = df._buffers(nb)        # written by the FLAME forward kernels
         joint_xf, v_shaped = joint_all[col], vs_all[col]
         # dverts was left zeroed by the last omfs_flame_skin_bwd, the gradient rows by the last Adam launch
-        L.check(lib.omfs_face_frames_bwd(L.ptr(verts), df.v_pad, L.ptr(df.faces), df.rig.n_faces, L.ptr(self.dface),
-                                         L.ptr(self.face_start), L.ptr(self.face_gauss), L.ptr(self.dverts), s), "omfs_face_frames_bwd")
+        if self.dverts_fx is not None:
+            L.check(lib.omfs_face_frames_bwd_fx(L.ptr(verts), df.v_pad, L.ptr(df.faces), df.rig.n_faces, L.ptr(self.dface), L.ptr(self.face_start),
+                                                L.ptr(self.face_gauss), L.ptr(self.dverts), L.ptr(self.dverts_fx), s), "omfs_face_frames_bwd_fx")
+        else:
+            L.check(lib.omfs_face_frames_bwd(L.ptr(verts), df.v_pad, L.ptr(df.faces), df.rig.n_faces, L.ptr(self.dface),
+                                             L.ptr(self.face_start), L.ptr(self.face_gauss), L.ptr(self.dverts), s), "omfs_face_frames_bwd")
         if self.fused:     # skinning backward + basis^T product + serial front: one launch
             L.check(lib.omfs_flame_skin_param_bwd(df.c_rig, L.ptr(self.basis_t), self.n_coef, L.ptr(v_shaped), L.ptr(joint_xf),
                                                   L.ptr(self.dverts), L.ptr(self.expr[t]), L.ptr(self.pose[t]), L.ptr(self.dcoef),

@@ -78,6 +78,8 @@ class Rasterizer:
                                    L.ptr(self.final_T), L.ptr(self.n_contrib), 0, 0, 0)
         # backward-side buffers are created on first use
         self.dsplat = None
+        self.dsplat_fx = None
+        self.deterministic = os.environ.get("OMFS_DETERMINISTIC", "0") == "1"
         self.dimage = None
         self.loss = None
         self.loss_scratch = None
@@ -182,6 +184,9 @@ class Rasterizer:
         if self.dsplat is None:
             dev = self.device
             self.dsplat = torch.zeros(self.n_capacity, 16, device=dev)
+            # OMFS_DETERMINISTIC=1: 64-bit fixed-point accumulators beside the float records (omfs_grad_buffers.dsplat_fx): the
+            # gradient sums no longer depend on the order the waves arrive in, two runs of the same training are bit-identical
+            self.dsplat_fx = torch.zeros(self.n_capacity, 16, dtype=torch.int64, device=dev) if self.deterministic else None
             self.dimage = torch.zeros(3, self.height, self.width, device=dev)
             self.loss = torch.zeros(1, device=dev)
             self.loss_scratch = torch.zeros(3 * 3 * self.height * self.width + L.LOSS_TAIL, device=dev)    # three maps + one loss partial per strip
@@ -196,6 +201,12 @@ class Rasterizer:
                 "omfs_loss_l1_ssim")
         return self.loss
 
+    def grad_buffers(self, grads, dimage, densify_stats=None, dface=None, drgb_out=None, dir_out=None) -> "L.GradBuffersC":
+        """omfs_grad_buffers of this rasteriser's backward pass (with the fixed-point accumulators in deterministic mode)."""
+        self._ensure_bwd()
+        return L.GradBuffersC(L.ptr(self.dsplat), L.ptr(grads), L.ptr(dimage), L.ptr(densify_stats), L.ptr(dface), L.ptr(drgb_out),
+                              L.ptr(dir_out), L.ptr(self.dsplat_fx), self.n_capacity if self.dsplat_fx is not None else 0)
+
     def backward(self, model: GaussianModel, face_xf: torch.Tensor, cam: L.CameraC, grads: torch.Tensor,
                  dimage: torch.Tensor | None = None, reg=(0.01, 1.0, 1.0, 0.6), dface: torch.Tensor | None = None):
         """dL/dimage (default: self.dimage from loss_l1_ssim) -> grads [59][n_pad] (overwritten);
@@ -209,7 +220,7 @@ class Rasterizer:
         if grads.shape != (NPLANES, model.n_pad) or grads.dtype != torch.float32 or not grads.is_contiguous():
             raise ValueError("grads must be a contiguous float32 [59][n_pad] tensor")
         self.dsplat.zero_()
-        gb = L.GradBuffersC(L.ptr(self.dsplat), L.ptr(grads), L.ptr(dimg), 0, L.ptr(dface))
+        gb = self.grad_buffers(grads, dimg, dface=dface)
         L.check(lib.omfs_composite_bwd(cam, self.rb, gb, s), "omfs_composite_bwd")
         L.check(lib.omfs_count_visible(self.rb, self.n, L.ptr(self.n_visible), s), "omfs_count_visible")
         rp = L.RegParamsC(float(reg[0]), float(reg[1]), float(reg[2]), float(reg[3]), L.ptr(self.n_visible))

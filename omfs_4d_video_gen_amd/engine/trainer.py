@@ -264,8 +264,8 @@ class Trainer:
             if len(self._view_steps) > 8 * max(len(self.views), 1):
                 self._view_steps.clear()
             r = self.rast
-            gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
-                                L.ptr(ft.dface) if ft is not None else 0, drgb, vdir)
+            gb = r.grad_buffers(self.grads, r.dimage, self.densify_stats, ft.dface if ft is not None else None)
+            gb.drgb_out, gb.dir_out = drgb, vdir
             rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
             u8 = target.dtype == torch.uint8
             if u8 and self._target_f32 is None:
@@ -342,8 +342,7 @@ class Trainer:
                 L.check(lib.omfs_rgb8_to_image(L.ptr(target), r.width, r.height, L.ptr(self._target_f32), s), "omfs_rgb8_to_image")
                 target = self._target_f32
             r.loss_l1_ssim(target, self.lambda_dssim)
-            gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
-                                L.ptr(ft.dface) if ft is not None else 0, 0)
+            gb = r.grad_buffers(self.grads, r.dimage, self.densify_stats, ft.dface if ft is not None else None)
             L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd")
             rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
             L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd")
@@ -550,9 +549,8 @@ class Trainer:
                 target = self._target_f32
             r.loss_l1_ssim(target, self.lambda_dssim); tm.mark("loss")
             split = self.sh_adam and not self.dp
-            gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(self.grads), L.ptr(r.dimage), L.ptr(self.densify_stats),
-                                L.ptr(ft.dface) if ft is not None else 0,
-                                L.ptr(self.drgb_scratch) if self.compact_dp else (L.ptr(self.drgb1) if split else 0), L.ptr(self.dir1) if split else 0)
+            gb = r.grad_buffers(self.grads, r.dimage, self.densify_stats, ft.dface if ft is not None else None,
+                                self.drgb_scratch if self.compact_dp else (self.drgb1 if split else None), self.dir1 if split else None)
             L.check(lib.omfs_composite_bwd(cam, r.rb, gb, s), "omfs_composite_bwd"); tm.mark("composite_bwd")
             gather = None
             if self.compact_dp:            # dL/dcolour is final here: its all-gather runs under project_bwd

@@ -173,3 +173,21 @@ def assert_same_up_to_atomic_noise(a, b, mean_rel, tail_abs, what=""):
     scale = max(1.0, float(np.abs(b).max()))
     q = float(np.quantile(d, 0.999)) if d.size else 0.0
     assert d.mean() <= mean_rel * scale and q <= tail_abs and d.max() <= 20.0 * tail_abs + 1e-3, (what, float(d.mean()), q, float(d.max()), scale)
+
+
+def build_cli_dataset(d):
+    """A dataset in the reference's on-disk layout for the engine's command lines: 60 frames, 96x72, rendered by the engine itself
+    from a 'ground-truth' Gaussian set (GPU)."""
+    from omfs_4d_video_gen_amd.engine import io_formats as IO
+    from omfs_4d_video_gen_amd.engine import synthetic
+    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
+    from omfs_4d_video_gen_amd.engine.trainer import Renderer, View
+    T, W, H = 60, 96, 72
+    rig = synthetic.make_rig(0)
+    seq = synthetic.make_flame_sequence(T, 2)
+    cams = [synthetic.make_camera(W, H, yaw=0.3 * np.sin(i / 9.0)) for i in range(T)]
+    gt = synthetic.make_gaussians(20000, rig.faces.shape[0], 5)
+    r = Renderer(FlameRig.from_synthetic(rig), seq, gt, W, H, bg=(1.0, 1.0, 1.0))
+    imgs = [r.render(View(cams[i], i), rgb8=True).cpu().numpy().copy() for i in range(T)]
+    IO.write_dataset(d, cams, list(range(T)), imgs, seq, fg_masks=True)
+    return d

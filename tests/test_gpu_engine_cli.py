@@ -25,19 +25,7 @@ ROOT = Path(__file__).resolve().parents[1]
 @pytest.fixture(scope="module")
 def dataset(tmp_path_factory):
     """60 frames, 96x72, rendered by the engine itself from a 'ground-truth' Gaussian set."""
-    from omfs_4d_video_gen_amd.engine import io_formats as IO
-    from omfs_4d_video_gen_amd.engine.flame_rig import FlameRig
-    from omfs_4d_video_gen_amd.engine.trainer import Renderer, View
-    d = tmp_path_factory.mktemp("data")
-    T, W, H = 60, 96, 72
-    rig = synthetic.make_rig(0)
-    seq = synthetic.make_flame_sequence(T, 2)
-    cams = [synthetic.make_camera(W, H, yaw=0.3 * np.sin(i / 9.0)) for i in range(T)]
-    gt = synthetic.make_gaussians(20000, rig.faces.shape[0], 5)
-    r = Renderer(FlameRig.from_synthetic(rig), seq, gt, W, H, bg=(1.0, 1.0, 1.0))
-    imgs = [r.render(View(cams[i], i), rgb8=True).cpu().numpy().copy() for i in range(T)]
-    IO.write_dataset(d, cams, list(range(T)), imgs, seq, fg_masks=True)
-    return d
+    return H.build_cli_dataset(tmp_path_factory.mktemp("data"))
 
 
 def test_train_render_validate_pipeline(dataset, tmp_path, monkeypatch, capfd):
