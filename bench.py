@@ -230,7 +230,10 @@ def main():
 
     log(f"inputs built: N={N} {W}x{H} F={F}")
     # targets: the same scene rendered from a second seeded Gaussian set (data = synthetic)
-    tr = Renderer(rig, seq, g_target, W, H)
+    # Renderers of the bench (targets, render aux): forward only, nothing is sized by their pair capacity but memory -- and nothing
+    # here redoes a frame as engine/render.py does -- so they get ample room (24 pairs per Gaussian and unit of area)
+    render_cap = max(1 << 20, int(24 * N * max(1.0, W * H / float(1920 * 1080))))
+    tr = Renderer(rig, seq, g_target, W, H, dup_capacity=render_cap)
     views = []
     for i, cam in enumerate(cams):
         v = View(cam, timestep=i % T)
@@ -243,23 +246,39 @@ def main():
     log("targets rendered")
     # upstream's default for --bind_to_mesh (the reference's argv passes no opt-out, train_ghost.py:227-237): the per-timestep
     # FLAME parameters are optimised with the Gaussians, so FLAME LBS + triangle frames are posed INSIDE the timed step
-    trainer = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3,
-                      rank=rank, world_size=world, process_group=pg, finetune_flame=not args.frozen_flame,
-                      coherent_order=args.coherent_order)
-
     def barrier():
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
 
-    # untimed set-up: every view is visited twice so that its iteration is captured as a hipGraph before the W warm-up and
-    # the K timed steps start (first visit eager, second visit capture + replay: engine/trainer.py)
-    n_prime = 2 * len(views) + 2 if getattr(trainer, "use_graph", False) and world == 1 else 0
-    for i in range(n_prime + args.warmup):
-        trainer.step()
-        if i == 0:
-            torch.cuda.synchronize()
-            log("first step done")
+    # The pair capacity starts at the engine's default (20 pairs per Gaussian at 1080p: engine/rasterizer.py).  A scene that exceeds
+    # it during the warm-up renders empty lists from then on: the capacity is doubled and the warm-up starts again with a fresh
+    # trainer -- as engine/train.py rolls an overflowed interval back -- so the timed region never holds an overflowed iteration
+    # (checked again after it).
+    dup_capacity = None
+    while True:
+        trainer = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3,
+                          rank=rank, world_size=world, process_group=pg, finetune_flame=not args.frozen_flame,
+                          coherent_order=args.coherent_order, dup_capacity=dup_capacity)
+        # untimed set-up: every view is visited twice so that its iteration is captured as a hipGraph before the W warm-up and
+        # the K timed steps start (first visit eager, second visit capture + replay: engine/trainer.py)
+        n_prime = 2 * len(views) + 2 if getattr(trainer, "use_graph", False) and world == 1 else 0
+        for i in range(n_prime + args.warmup):
+            trainer.step()
+            if i == 0:
+                torch.cuda.synchronize()
+                log("first step done")
+        torch.cuda.synchronize()
+        over = torch.tensor([1.0 if trainer.rast.overflowed() else 0.0], device="cuda")
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(over, op=dist.ReduceOp.MAX)
+        if float(over.item()) == 0.0:
+            break
+        dup_capacity = 2 * trainer.rast.dup_capacity
+        log(f"tile-list capacity {trainer.rast.dup_capacity} exceeded during the warm-up: again with {dup_capacity}")
+        trainer.close()
+        del trainer
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     log("warmup done")
     # one HIP event per step on the launch stream (K + 1 records, ~1 us of queue each): the spread of the K timed steps
@@ -420,7 +439,7 @@ def main():
         # config 3: a render_frames-timestep FLAME sequence (every frame its own pose), cameras cycling over the arc
         seq_r = synthetic.make_flame_sequence(args.render_frames, 0)
         # as engine/render.py does: consecutive frames go to three HIP streams with raster buffers of their own (independent frames)
-        rr = Renderer(rig, seq_r, g_init, W, H, coherent_order=args.coherent_order, n_streams=args.render_streams)
+        rr = Renderer(rig, seq_r, g_init, W, H, coherent_order=args.coherent_order, n_streams=args.render_streams, dup_capacity=render_cap)
         frames = [View(cams[i % len(cams)], timestep=i) for i in range(rank, args.render_frames, world)]
         for v in frames[:2 * args.render_streams + 2]:
             rr.render_async(v, rgb8=True)

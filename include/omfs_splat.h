@@ -164,7 +164,10 @@ typedef struct omfs_gaussians {
 } omfs_gaussians;
 
 typedef struct omfs_raster_buffers {
-  /* per Gaussian (written by project_fwd) */
+  /* per Gaussian (written by project_fwd): the projected-splat record, three float4.  omfs_record_stride() == 1 (the shipped
+   * build): three planar [n][4] arrays.  A library built with -DOMFS_REC_STRIDE=4 reads ONE 64-byte record per Gaussian instead
+   * (rec [n][16]: g1 = g0 + 4, g2 = g0 + 8 floats; measured 0.3 % slower per iteration: csrc/common.hpp) and returns 4;
+   * omfs_project_fwd refuses pointers that do not match the layout it was built for. */
   float* g0;              /* [n][4] mean2d.x, mean2d.y, conic.a, conic.b                         */
   float* g1;              /* [n][4] conic.c, opacity, r, g                                       */
   float* g2;              /* [n][4] b, depth, bits(radius | clamp<<28), bits(rect x0|y0<<8|x1<<16|y1<<24) */
@@ -205,6 +208,7 @@ typedef struct omfs_raster_buffers {
 #define OMFS_RB_FORWARD_ONLY 1u
 #define OMFS_RB_NO_DEPTH_HINT 2u   /* omfs_composite_fwd ignores the priority hint of a caller-owned quad_depth table (A/B measurements) */
 
+int omfs_record_stride(void);   /* float4 units between two Gaussians' records in g0 / g1 / g2: 1 (planar, the shipped build) or 4 (one 64-byte record) */
 /* deform + project + colour for one view -> g0,g1,g2. face_xf [n_faces][16]. */
 int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, const omfs_camera* cam,
                      const omfs_raster_buffers* rb, void* stream);
@@ -432,6 +436,13 @@ int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v,
  * omfs_adam_step_planes(.., 0, 14) does), so the whole Adam step of an iteration stays one launch.                        */
 int omfs_adam_step_sh_rest(float* params, const float* grads_low, const float* drgb, const float* dir, float* m, float* v, int n,
                            int n_pad, const omfs_adam_params* ap, int sh_degree, void* stream);
+/* omfs_sh_rest_grads + the Adam update of planes 14..58 in ONE launch (ABI 8; what the compact exchange of the trainer calls): the
+ * summed gradient of a Gaussian's 45 higher SH coefficients is formed in registers (same expressions, same order, same bits) and
+ * consumed on the spot -- the 45 gradient planes are neither written nor read, `grads` is not an argument.  g->params is updated
+ * in place; m, v [59][n_pad] Adam moments; ap as for omfs_adam_step (grad_scale = 1 / world size for a mean over the views). */
+int omfs_adam_step_sh_rest_views(const omfs_gaussians* g, const float* face_xf_all, int n_faces, const float* cam_pos_table,
+                                 const omfs_view_set* views, const float* drgb_all, int sh_degree, float* m, float* v,
+                                 const omfs_adam_params* ap, void* stream);
 
 /* The same step on the flat range [offset, offset + count) of the [59][n_pad] buffers (both multiples of 4): the shard a
  * data-parallel rank owns after a reduce-scatter of the gradient ("sharded" exchange: reduce-scatter, Adam on 1/W of the

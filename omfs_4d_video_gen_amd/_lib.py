@@ -144,6 +144,8 @@ SIGNATURES = {
     "omfs_rccl_reduce_scatter": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "omfs_sh_rest_grads": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.c_int, c_void_p, C.POINTER(ViewSetC), c_void_p, C.c_int,
                                      c_void_p, c_void_p]),
+    "omfs_adam_step_sh_rest_views": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.c_int, c_void_p, C.POINTER(ViewSetC), c_void_p, C.c_int,
+                                               c_void_p, c_void_p, C.POINTER(AdamParamsC), c_void_p]),
     "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_face_frames_bwd": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_face_frames_bwd_fx": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -159,6 +161,7 @@ SIGNATURES = {
                                  C.c_int, C.c_float, c_void_p]),
     "omfs_simpleflame_fwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 5 + [C.c_int, c_void_p, c_void_p, c_void_p]),
     "omfs_simpleflame_bwd": (C.c_int, [C.POINTER(SimpleFlameC)] + [c_void_p] * 3 + [C.c_int] + [c_void_p] * 7),
+    "omfs_record_stride": (C.c_int, []),
     "omfs_project_fwd": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
     "omfs_bin_count": (C.c_int, [C.POINTER(GaussiansC), C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),
     "omfs_bin_scan": (C.c_int, [C.POINTER(CameraC), C.POINTER(RasterBuffersC), c_void_p]),

@@ -9,6 +9,7 @@
 // tile is arbitrary (atomics), so equal depths are finally ordered by Gaussian id: the result is
 // exactly the order of the upstream stable global sort whose emission order is the Gaussian index.
 // HBM traffic: write 8 B + read 8 B + write 4 B per pair, versus ~24 B x 6 passes for the global sort.
+#include <type_traits>
 #include "common.hpp"
 
 namespace omfs {
@@ -206,15 +207,23 @@ struct PairSource {
   const float4* g0; const float4* g1; const float4* g2;
 };
 
-struct WaveRects {            // one wave's published rectangles (36 B per lane)
+// QUOT: r1 also carries the tile test's two per-Gaussian quotients (-b / c, -b / a), evaluated ONCE per Gaussian by the publishing
+// lane instead of once per rectangle tile (two correctly rounded divisions, ~20 of the test's ~200 instructions; same operands,
+// same bits).  Only the count kernel evaluates the test for every tile (the scatter replays its ballots), and only there the 8 extra
+// bytes per lane fit: its per-tile counters are 16-bit (a workgroup holds 512 Gaussians), which keeps three workgroups -- the whole
+// grid -- resident per CU.  (Round 2 published the quotients in both kernels with 32-bit counters: one workgroup per CU fewer, slower.)
+template <bool QUOT>
+struct WaveRectsT {           // one wave's published rectangles (36 / 44 B per lane)
   float4 r0[64];              // mean2d.xy, conic a, b
-  float2 r1[64];              // conic c, opacity
+  typename std::conditional<QUOT, float4, float2>::type r1[64];   // conic c, opacity (, -b / c, -b / a)
   uint32_t scan[64];          // inclusive prefix sum of rectangle areas
   uint32_t rect[64];          // packed x0 | y0<<8 | x1<<16 | y1<<24
   uint32_t depth[64];         // depth bits
   uint32_t coarse[8];         // scan[7], scan[15], ..., scan[63]: first level of the owner search
 };
+using WaveRects = WaveRectsT<false>;
 constexpr size_t BIN_SCRATCH_BYTES = sizeof(WaveRects) * BIN_WAVES;
+constexpr size_t BIN_COUNT_SCRATCH_BYTES = sizeof(WaveRectsT<true>) * BIN_WAVES;
 
 // Which Gaussian lane l of this wave owns (bin_count_kernel and bin_scatter_kernel, which must agree: the scatter replays the
 // count's ballots).  The Gaussians are stored in mesh order, so neighbours have similar footprints, and with 512 consecutive
@@ -252,11 +261,11 @@ static inline int bin_blocks(int n) { return ((cdiv(n, BIN_THREADS) + 31) / 32) 
 // calls f(tile) for every tile of Gaussian i's rectangle that passes the test (lane-per-Gaussian form, fallback kernels)
 template <typename F>
 __device__ __forceinline__ void for_each_touched_tile(const PairSource& ps, int i, int gx, F&& f) {
-  const float4 r2 = ps.g2[i];
+  const float4 r2 = ps.g2[RI(i)];
   const uint32_t rect = __float_as_uint(r2.w);
   if (rect == 0u) return;
-  const float4 r0 = ps.g0[i];
-  const float4 r1 = ps.g1[i];
+  const float4 r0 = ps.g0[RI(i)];
+  const float4 r1 = ps.g1[RI(i)];
   const int x0 = rect & 255u, y0 = (rect >> 8) & 255u, x1 = (rect >> 16) & 255u, y1 = rect >> 24;
   for (int y = y0; y < y1; ++y)
     for (int x = x0; x < x1; ++x)
@@ -264,18 +273,21 @@ __device__ __forceinline__ void for_each_touched_tile(const PairSource& ps, int 
 }
 
 // Every lane of the wave must call this (i >= n publishes an empty rectangle).  Returns the wave's rectangle-tile total.
-__device__ __forceinline__ uint32_t publish_rects(const PairSource& ps, int i, int n, WaveRects* wr, bool* visible = nullptr) {
+__device__ __forceinline__ void set_r1(float2& d, const float4& r0, const float4& t) { d = make_float2(t.x, t.y); }
+__device__ __forceinline__ void set_r1(float4& d, const float4& r0, const float4& t) { d = make_float4(t.x, t.y, -r0.w / t.x, -r0.w / r0.z); }
+template <bool QUOT>
+__device__ __forceinline__ uint32_t publish_rects(const PairSource& ps, int i, int n, WaveRectsT<QUOT>* wr, bool* visible = nullptr) {
   const int lane = lane_id();
   uint32_t rect = 0u, depth = 0u;
   bool vis = false;
   float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float2 r1 = make_float2(0.f, 0.f);
+  typename std::conditional<QUOT, float4, float2>::type r1{};
   if (i < n) {
-    const float4 r2 = ps.g2[i];
+    const float4 r2 = ps.g2[RI(i)];
     rect = __float_as_uint(r2.w);
     depth = __float_as_uint(r2.y);
     vis = (__float_as_uint(r2.z) & 0xFFFFFu) != 0u;     // radius > 0
-    if (rect) { r0 = ps.g0[i]; const float4 t = ps.g1[i]; r1 = make_float2(t.x, t.y); }
+    if (rect) { r0 = ps.g0[RI(i)]; const float4 t = ps.g1[RI(i)]; set_r1(r1, r0, t); }
   }
   if (visible) *visible = vis;
   const uint32_t area = (((rect >> 16) & 255u) - (rect & 255u)) * ((rect >> 24) - ((rect >> 8) & 255u));
@@ -295,8 +307,14 @@ __device__ __forceinline__ uint32_t publish_rects(const PairSource& ps, int i, i
 constexpr int HITS_PER_WAVE = 64;
 enum { HITS_NONE = 0, HITS_RECORD = 1, HITS_REPLAY = 2 };
 
-template <int MODE, typename F>
-__device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* wr, uint32_t total, int gx,
+__device__ __forceinline__ bool tile_test(const float4& r0, const float2& r1, int tx, int ty) {
+  return tile_touched(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
+}
+__device__ __forceinline__ bool tile_test(const float4& r0, const float4& r1, int tx, int ty) {
+  return tile_touched_pre(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, tx, ty);
+}
+template <int MODE, bool QUOT, typename F>
+__device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRectsT<QUOT>* wr, uint32_t total, int gx,
                                                                unsigned long long* hits, F&& f) {
   const int lane = lane_id();
   uint32_t step = 0;
@@ -323,8 +341,7 @@ __device__ __forceinline__ void for_each_touched_tile_balanced(const WaveRects* 
       hit = (hits[step] >> lane) & 1ull;
     } else {
       const float4 r0 = wr->r0[j];
-      const float2 r1 = wr->r1[j];
-      hit = tile_touched(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, tx, ty);
+      hit = tile_test(r0, wr->r1[j], tx, ty);
       if (MODE == HITS_RECORD && hits && step < (uint32_t)HITS_PER_WAVE) {
         const unsigned long long bal = __ballot(hit);
         if (lane == 0) hits[step] = bal;             // lane 0 runs every step of the walk (p = 64 step)
@@ -344,9 +361,10 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSourc
   __shared__ uint32_t s_vis, s_nlist;
   if (blockIdx.x == 0 && threadIdx.x == 0) status[1] = hits_all ? stamp : 0u;   // whose tile-test ballots keys_tmp now holds
   if (threadIdx.x == 0) s_nlist = 0u;
-  WaveRects* wr = reinterpret_cast<WaveRects*>(smem) + (threadIdx.x >> 6);
-  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_SCRATCH_BYTES);
-  for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) hist[t] = 0;
+  WaveRectsT<true>* wr = reinterpret_cast<WaveRectsT<true>*>(smem) + (threadIdx.x >> 6);
+  // per-tile counters of this workgroup: 16 bits each, two per word (512 Gaussians per workgroup: a count never reaches 2^16)
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + BIN_COUNT_SCRATCH_BYTES);
+  for (int t = threadIdx.x; t < (n_tiles + 1) / 2; t += BIN_THREADS) hist[t] = 0;
   if (threadIdx.x == 0) s_vis = 0u;
   const int i = bin_gaussian(lane_id());
   bool vis;
@@ -357,13 +375,13 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(int n, PairSourc
     if (lane_id() == 0 && cnt) atomicAdd(&s_vis, cnt);
   }
   unsigned long long* hits = hits_all ? hits_all + ((size_t)blockIdx.x * BIN_WAVES + (threadIdx.x >> 6)) * HITS_PER_WAVE : nullptr;
-  for_each_touched_tile_balanced<HITS_RECORD>(wr, total, gx, hits, [&](int t, int) { atomicAdd(&hist[t], 1u); });
+  for_each_touched_tile_balanced<HITS_RECORD>(wr, total, gx, hits, [&](int t, int) { atomicAdd(&hist[t >> 1], 1u << (16 * (t & 1))); });
   __syncthreads();
   // the block's non-empty (tile, count) pairs also go to a list of its own behind the ballots (entry 0: their number):
   // bin_scatter_kernel takes its slot ranges from it instead of walking every rectangle a second time just to count
   uint2* list = lists_all ? lists_all + (size_t)blockIdx.x * (size_t)(n_tiles + 1) : nullptr;
   for (int t = threadIdx.x; t < n_tiles; t += BIN_THREADS) {
-    const uint32_t c = hist[t];
+    const uint32_t c = (hist[t >> 1] >> (16 * (t & 1))) & 0xFFFFu;
     if (c) {
       atomicAdd(&tile_count[t], c);
       if (list) list[1u + atomicAdd(&s_nlist, 1u)] = make_uint2((uint32_t)t, c);
@@ -439,7 +457,7 @@ __global__ __launch_bounds__(256) void bin_count_direct_kernel(int n, PairSource
                                                                uint32_t* __restrict__ n_visible) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (n_visible) {
-    const bool vis = i < n && (__float_as_uint(ps.g2[i].z) & 0xFFFFFu) != 0u;
+    const bool vis = i < n && (__float_as_uint(ps.g2[RI(i)].z) & 0xFFFFFu) != 0u;
     const uint32_t cnt = (uint32_t)__popcll(__ballot(vis));
     if (lane_id() == 0 && cnt) atomicAdd(n_visible, cnt);
   }
@@ -451,7 +469,7 @@ __global__ __launch_bounds__(256) void bin_scatter_direct_kernel(int n, PairSour
                                                                  uint32_t* __restrict__ tile_cursor, uint2* __restrict__ keys) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || tile_start[n_tiles] == 0u) return;
-  const uint32_t depth_bits = __float_as_uint(ps.g2[i].y);
+  const uint32_t depth_bits = __float_as_uint(ps.g2[RI(i)].y);
   for_each_touched_tile(ps, i, gx, [&](int t) {
     keys[tile_start[t] + atomicAdd(&tile_cursor[t], 1u)] = make_uint2(depth_bits, (uint32_t)i);
   });
@@ -783,8 +801,9 @@ extern "C" int omfs_bin_count(const omfs_gaussians* g, const omfs_camera* cam, c
   const int gx = cdiv(cam->width, OMFS_TILE), n_tiles = gx * cdiv(cam->height, OMFS_TILE);
   hipStream_t s = (hipStream_t)stream;
   PairSource ps{(const float4*)rb->g0, (const float4*)rb->g1, (const float4*)rb->g2};
-  const size_t lds = (size_t)n_tiles * 4 + BIN_SCRATCH_BYTES;
-  if (lds <= BIN_LDS_LIMIT) {
+  // the LDS form is taken exactly when the scatter takes it (32-bit counters there); this kernel's own counters are 16-bit
+  const size_t lds_scatter = (size_t)n_tiles * 4 + BIN_SCRATCH_BYTES, lds = (size_t)((n_tiles + 1) / 2) * 4 + BIN_COUNT_SCRATCH_BYTES;
+  if (lds_scatter <= BIN_LDS_LIMIT) {
     static std::atomic<unsigned long long> attr_done{0};
     if (int rc = ensure_max_lds((const void*)bin_count_kernel, 159 * 1024, attr_done)) return rc;   // + a static word
     hipLaunchKernelGGL(bin_count_kernel, dim3(bin_blocks(g->n)), dim3(BIN_THREADS), lds, s, g->n, ps, gx, n_tiles, rb->tile_count,

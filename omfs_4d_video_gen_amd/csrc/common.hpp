@@ -22,6 +22,20 @@ int set_error(int code, const char* fmt, ...);
 
 constexpr int WAVE = 64;
 
+// Projected-splat records.  Three float4 per Gaussian -- (mean2d.xy, conic a, b) (conic c, opacity, r, g) (b, depth, radius | clamp
+// bits, packed tile rect) -- addressed as g0[RI(i)], g1[RI(i)], g2[RI(i)].  OMFS_REC_STRIDE 1 (default): three planar arrays.
+// OMFS_REC_STRIDE 4: ONE 64-byte record per Gaussian (g1 = g0 + 1, g2 = g0 + 2 float4), so that a gather by sorted id touches one
+// 64-byte sector instead of three -- built and measured in round 5 (VERDICT r4 Next 4; tools/ab/bq.sh, same box, two alternations):
+// composite_fwd 0.1907 -> 0.1870 ms, composite_bwd unchanged (0.1914 -> 0.1908: it is bound by instruction issue, not by its
+// gathers), but the streaming readers move 64 instead of 48 bytes per Gaussian in 16-byte pieces 64 bytes apart -- binning
+// 0.1453 -> 0.1480 ms, projection and its backward likewise -- and the iteration came out 0.3 % SLOWER (0.8001 -> 0.8022 ms).
+// Below the 1 % the change was to be kept for: the planar layout stays, the switch documents the measurement (every kernel and
+// test runs on either; omfs_record_stride() tells the host which layout the library was built for).
+#ifndef OMFS_REC_STRIDE
+#define OMFS_REC_STRIDE 1
+#endif
+#define RI(i) ((size_t)(i) * OMFS_REC_STRIDE)
+
 // ---- exactly specified fp32 helpers (DESIGN.md "Frozen arithmetic"): every operation is an
 // individually rounded IEEE op or an explicit fma, so the C oracle reproduces them bit for bit.
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
@@ -51,12 +65,14 @@ __device__ __forceinline__ float exp_exact(float x) {
 // pixel box, relaxed by a rounding slack, then o * exp(-q/2) against 1/255.  Conservative: a pair
 // it rejects contributes to no pixel, so dropping it from the tile list leaves the image unchanged.
 // Plain IEEE operations in a fixed order: bit-identical in oracle/splat_oracle.c.
-__device__ __forceinline__ bool tile_touched(float mx, float my, float A, float B, float C, float o, int tx, int ty) {
+// tile_touched_pre: the same test with the two quotients that depend on the Gaussian alone (nBoC = -B / C, nBoA = -B / A: the
+// unconstrained minimisers' slopes) handed in -- binning evaluates them once per Gaussian instead of once per rectangle tile
+// (two correctly rounded divisions, ~20 of the test's ~200 instructions); same operations on the same operands: same bits.
+__device__ __forceinline__ bool tile_touched_pre(float mx, float my, float A, float B, float C, float o, float nBoC, float nBoA, int tx, int ty) {
   if (!(A > 0.f && C > 0.f)) return true;
   const float x0 = (float)(tx * OMFS_TILE), y0 = (float)(ty * OMFS_TILE);
   const float dxl = mx - (x0 + 15.f), dxh = mx - x0, dyl = my - (y0 + 15.f), dyh = my - y0;
   if (dxl <= 0.f && dxh >= 0.f && dyl <= 0.f && dyh >= 0.f) return true;
-  const float nBoC = -B / C, nBoA = -B / A;
   float best = 3.0e38f, mag = 0.f;
   const float cx[4] = {dxl, dxh, fminf(fmaxf(nBoA * dyl, dxl), dxh), fminf(fmaxf(nBoA * dyh, dxl), dxh)};
   const float cy[4] = {fminf(fmaxf(nBoC * dxl, dyl), dyh), fminf(fmaxf(nBoC * dxh, dyl), dyh), dyl, dyh};
@@ -68,6 +84,9 @@ __device__ __forceinline__ bool tile_touched(float mx, float my, float A, float 
   }
   const float qa = fmaxf((best - 4e-5f * mag) - 1e-3f, 0.f);
   return o * exp_exact(-0.5f * qa) >= (1.f / 255.f) * 0.999f;
+}
+__device__ __forceinline__ bool tile_touched(float mx, float my, float A, float B, float C, float o, int tx, int ty) {
+  return tile_touched_pre(mx, my, A, B, C, o, -B / C, -B / A, tx, ty);
 }
 
 // ---- wave64 reductions via DPP (no LDS traffic).

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
   float r2 = 0.f;
   if (beg + lane < end) {
     const uint32_t id = sorted_ids[beg + lane];
-    r0 = g0[id]; r1 = g1[id]; r2 = g2[id].x;
+    r0 = g0[RI(id)]; r1 = g1[RI(id)]; r2 = g2[RI(id)].x;
   }
   if (lane == 0) {
     s0[0] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(64) OMFS_FWD_ATTR void composite_fwd_kernel(CompCam
     __builtin_amdgcn_wave_barrier();
     if (k + WB < lim) {   // next step's gather, in flight during the walk
       const uint32_t id = sorted_ids[k + WB];
-      r0 = g0[id]; r1 = g1[id]; r2 = g2[id].x;
+      r0 = g0[RI(id)]; r1 = g1[RI(id)]; r2 = g2[RI(id)].x;
     }
     // ---- walk: splats that can touch a sub-block which still has an unsaturated pixel
     auto combine = [&](unsigned long long lv) {
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
       for (int h = 0; h < 2; ++h) {
         q0[h] = make_float4(0.f, 0.f, 0.f, 0.f); q1[h] = q0[h]; q2[h] = 0.f;
         const uint32_t k = sb0 + h * WB + lane;
-        if (k < se) { const uint32_t id = sorted_ids[k]; q0[h] = g0[id]; q1[h] = g1[id]; q2[h] = g2[id].x; }
+        if (k < se) { const uint32_t id = sorted_ids[k]; q0[h] = g0[RI(id)]; q1[h] = g1[RI(id)]; q2[h] = g2[RI(id)].x; }
       }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -436,14 +436,14 @@ __global__ __launch_bounds__(DEEP_WAVES * 64) void composite_fwd_deep_kernel(
           bool hit = false;
           if (k < se) {
             const uint32_t id = sorted_ids[k];
-            const float4 a = g0[id], c = g1[id];
+            const float4 a = g0[RI(id)], c = g1[RI(id)];
             const float dx = a.x - pfx, dy = a.y - pfy;
             const float p2 = fma_((-0.5f * LOG2E * a.z) * dx, dx, fma_((-0.5f * LOG2E * c.x) * dy, dy, (-LOG2E * a.w) * dx * dy));
             const float e = p2 + __log2f(fmaxf(c.y, 1e-30f));
             if (p2 <= 0.f && e >= LOG2_INV255) {
               hit = true;
               alpha = fminf(0.99f, __builtin_amdgcn_exp2f(e));
-              c0 = c.z; c1 = c.w; c2 = g2[id].x;
+              c0 = c.z; c1 = c.w; c2 = g2[RI(id)].x;
             }
           }
           const float om = 1.f - alpha;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
     pre_step = (int)((n_up - 1u) / WB);
     if ((uint32_t)lane < n_up - (uint32_t)pre_step * WB) {
       rid = sorted_ids[beg + (uint32_t)pre_step * WB + lane];
-      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+      r0 = g0[RI(rid)]; r1 = g1[RI(rid)]; r2 = g2[RI(rid)].x;
     }
   }
   if (__ballot(last_g > kseg * OMFS_SEG) == 0ull) return;   // nothing of this quadrant reaches this segment (no depth word: decided here)
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
     const int cnt0 = (int)min((uint32_t)WB, n_visit - (uint32_t)(n_steps - 1) * WB);
     if (lane < cnt0) {
       rid = sorted_ids[beg + (uint32_t)(n_steps - 1) * WB + lane];
-      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+      r0 = g0[RI(rid)]; r1 = g1[RI(rid)]; r2 = g2[RI(rid)].x;
     }
   }
 #ifdef OMFS_DEBUG_COUNTERS
@@ -727,7 +727,7 @@ __global__ __launch_bounds__(64) OMFS_BWD_ATTR void composite_bwd_kernel(CompCam
     __builtin_amdgcn_wave_barrier();
     if (st > 0) {   // every earlier step is full
       rid = sorted_ids[beg + cbase - WB + lane];
-      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+      r0 = g0[RI(rid)]; r1 = g1[RI(rid)]; r2 = g2[RI(rid)].x;
     }
     // The record of the next splat is fetched from LDS while the current one is evaluated; two register sets
     // alternate (the loop body is written once and instantiated twice), so no copies are needed.

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFM
     pre_step = (int)((n_up - 1u) / WB);
     if ((uint32_t)lane < n_up - (uint32_t)pre_step * WB) {
       rid = sorted_ids[beg + (uint32_t)pre_step * WB + lane];
-      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+      r0 = g0[RI(rid)]; r1 = g1[RI(rid)]; r2 = g2[RI(rid)].x;
     }
   }
   if (__ballot(last_g > kseg * OMFS_SEG) == 0ull) return;   // nothing of this quadrant reaches this segment (no depth word: decided here)
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFM
     const int cnt0 = (int)min((uint32_t)WB, n_visit - (uint32_t)(n_steps - 1) * WB);
     if (lane < cnt0) {
       rid = sorted_ids[beg + (uint32_t)(n_steps - 1) * WB + lane];
-      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+      r0 = g0[RI(rid)]; r1 = g1[RI(rid)]; r2 = g2[RI(rid)].x;
     }
   }
   for (int st = n_steps - 1; st >= 0; --st) {
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_BWD_MFM
     __builtin_amdgcn_wave_barrier();
     if (st > 0) {   // every earlier step is full
       rid = sorted_ids[beg + cbase - WB + lane];
-      r0 = g0[rid]; r1 = g1[rid]; r2 = g2[rid].x;
+      r0 = g0[RI(rid)]; r1 = g1[RI(rid)]; r2 = g2[RI(rid)].x;
     }
     int jbn = m ? 63 - __builtin_clzll(m) : 0;
     float4 recA0 = s0[jbn], recA1 = s1[jbn], recA2 = s2[jbn], recB0 = recA0, recB1 = recA1, recB2 = recA2;
@@ -402,8 +402,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(OMFS_ENT_WAV
     uint32_t id = 0;
     if (have) {
       id = sorted_ids[tbeg + first + e_rel];
-      const float4 r0 = g0[id], r1 = g1[id];
-      const float r2 = g2[id].x;
+      const float4 r0 = g0[RI(id)], r1 = g1[RI(id)];
+      const float r2 = g2[RI(id)].x;
       mxl = r0.x - (float)tx0; myl = r0.y - (float)ty0;             // exact: both are multiples of ulp(mean) (see DESIGN)
       qa = -0.5f * LOG2E * r0.z; qb = -LOG2E * r0.w; qc = -0.5f * LOG2E * r1.x;
       opac = r1.y;

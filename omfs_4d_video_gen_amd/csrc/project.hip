@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(int n, int n_pad, cons
       }
     }
   }
-  g0[i] = o0;
-  g1[i] = o1;
-  g2[i] = o2;
+  g0[RI(i)] = o0;
+  g1[RI(i)] = o1;
+  g2[RI(i)] = o2;
 }
 
 __global__ __launch_bounds__(1024) void count_visible_kernel(const float4* __restrict__ g2, int n, uint32_t* __restrict__ out) {
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(1024) void count_visible_kernel(const float4* __res
   if (threadIdx.x == 0) cnt = 0;
   __syncthreads();
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t vis = (i < n) && ((__float_as_uint(g2[i].z) & 0xFFFFFu) != 0u);
+  const uint32_t vis = (i < n) && ((__float_as_uint(g2[RI(i)].z) & 0xFFFFFu) != 0u);
   const unsigned long long m = __ballot(vis);
   if (lane_id() == 0 && m) atomicAdd(&cnt, (uint32_t)__popcll(m));
   __syncthreads();
@@ -176,6 +176,8 @@ extern "C" int omfs_project_fwd(const omfs_gaussians* g, const float* face_xf, c
   OMFS_REQUIRE(cam->width > 0 && cam->height > 0 && cam->width <= 4080 && cam->height <= 4080, "image size (tile coords are 8 bit)");
   OMFS_REQUIRE(cam->sh_degree >= 0 && cam->sh_degree <= 3, "sh_degree");
   OMFS_REQUIRE(rb->g0 && rb->g1 && rb->g2, "raster buffers");
+  OMFS_REQUIRE(OMFS_REC_STRIDE == 1 || (rb->g1 == rb->g0 + 4 && rb->g2 == rb->g0 + 8),
+               "this library reads ONE 64-byte record per Gaussian: g1 = g0 + 4 floats, g2 = g0 + 8 floats (omfs_record_stride() == 4)");
   ProjCam pc = make_projcam(cam);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(project_fwd_kernel, dim3(cdiv(g->n, 256)), dim3(256), 0, s, g->n, g->n_pad, g->params, g->binding,
@@ -192,3 +194,5 @@ extern "C" int omfs_count_visible(const omfs_raster_buffers* rb, int n, uint32_t
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }
+
+extern "C" int omfs_record_stride(void) { return OMFS_REC_STRIDE; }

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) OMFS_PBWD_ATTR void project_bwd_kernel(int n, 
   auto P = [&](int plane) { return params[(size_t)plane * n_pad + i]; };
   auto G = [&](int plane, float v) { grads[(size_t)plane * n_pad + i] = v; };
 
-  const uint32_t rbits = __float_as_uint(g2[i].z);
+  const uint32_t rbits = __float_as_uint(g2[RI(i)].z);
   const bool visible = (rbits & 0xFFFFFu) != 0u;
   if (!visible) {
     for (int p = 0; p < (drgb_out ? OMFS_P_SH + 3 : OMFS_NPLANES); ++p) G(p, 0.f);
@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) OMFS_PBWD_ATTR void project_bwd_kernel(int n, 
   // composite_bwd accumulates the MOMENTS of dL/dG * G over the pixels (dx = mean - pixel):
   //   d0 = (S_x, S_y, S_xx, S_xy), d1.x = S_yy;   with the projected conic (A, B, C) of g0 / g1
   //   d mean2d = -(A S_x + B S_y, C S_y + B S_x),   d conic = (-S_xx / 2, -S_xy, -S_yy / 2)
-  const float4 c0 = g0[i];
-  const float cA = c0.z, cB = c0.w, cC = g1[i].x;
+  const float4 c0 = g0[RI(i)];
+  const float cA = c0.z, cB = c0.w, cC = g1[RI(i)].x;
   const float dpx = -fma_(cA, d0.x, cB * d0.y), dpy = -fma_(cC, d0.y, cB * d0.x);
   const float dA = -0.5f * d0.z, dB = -d0.w, dC = -0.5f * d1.x, dop = d1.y;
   if (densify_stats) {   // adaptive density control statistics
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void extract_drgb_kernel(int n, int n_pad, con
                                                            const float4* __restrict__ dsplat, float* __restrict__ drgb_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const uint32_t rbits = __float_as_uint(g2[i].z);
+  const uint32_t rbits = __float_as_uint(g2[RI(i)].z);
   float d[3] = {0.f, 0.f, 0.f};
   if ((rbits & 0xFFFFFu) != 0u) {
     const float4 d1 = dsplat[(size_t)i * 4 + 1], d2 = dsplat[(size_t)i * 4 + 2];

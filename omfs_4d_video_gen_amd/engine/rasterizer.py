@@ -47,14 +47,27 @@ class Rasterizer:
         self.n, self.width, self.height = int(n), int(width), int(height)
         self.gx, self.gy = (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
         self.n_tiles = self.gx * self.gy
-        # 288 GB of HBM: be generous rather than re-allocate; overflow is flagged by the device
-        # default capacity: 48 pairs per Gaussian at 1080p, growing with the image area beyond that (a splat covers four times
-        # as many tiles at 3840x2160); exceeding it is flagged by the device, engine/train.py grows the buffers
+        # Default pair capacity: 20 pairs per Gaussian at 1080p, growing with the image area beyond that (a splat covers four times
+        # as many tiles at 3840x2160).  Measured on the synthetic heads (tools/early_d.py, profiles/r05_early_tile_pairs.json): the
+        # UNTRAINED cloud is the heaviest, 15.8 pairs per Gaussian at 1080p for 300 k and 500 k Gaussians, 12.1 per unit of area at
+        # 4K, 5.8 at 512 x 512; a trained cloud holds 11-12.  The capacity sizes keys / keys_tmp / sorted_ids, the checkpoint
+        # buffer (4 KB per 128 pairs) and the grid of the backward pass (4 waves per 128 pairs + 4 per tile), so it is kept close
+        # (a quarter above the heaviest cloud measured: 16 would leave 1.4 %, and a renderer has no way to redo a frame inside
+        # render()): rounds 1-4 allocated 48 per Gaussian, three quarters of it never touched.  Exceeding it is flagged by the device and every
+        # caller grows the buffers and redoes the work: engine/train.py (rollback to the last clean snapshot), engine/render.py
+        # (the split is rendered again), bench.py (the warm-up is repeated), Trainer users through rast.overflowed().
         area = max(1.0, (width * height) / float(1920 * 1080))
-        self.dup_capacity = int(dup_capacity if dup_capacity else max(1 << 20, int(48 * n * area)))
+        self.dup_capacity = int(dup_capacity if dup_capacity else max(1 << 20, int(20 * n * area)))
         dev = self.device
         z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=dev)
-        self.g0, self.g1, self.g2 = z(n, 4), z(n, 4), z(n, 4)
+        # projected-splat records: three planar arrays, or -- a library built with -DOMFS_REC_STRIDE=4 (A/B builds; 0.3 % slower) --
+        # ONE 64-byte record per Gaussian of which g0 / g1 / g2 are views
+        if L.load().omfs_record_stride() == 4:
+            self.rec = z(n, 16)
+            self.g0, self.g1, self.g2 = self.rec[:, 0:4], self.rec[:, 4:8], self.rec[:, 8:12]
+        else:
+            self.rec = None
+            self.g0, self.g1, self.g2 = z(n, 4), z(n, 4), z(n, 4)
         self.tile_count = z(self.n_tiles, dt=torch.int32)
         self.tile_start = z(self.n_tiles + 1, dt=torch.int32)
         self.tile_cursor = z(self.n_tiles, dt=torch.int32)
@@ -264,6 +277,14 @@ class Adam:
         m = self.model
         L.check(L.load().omfs_adam_step_sh_rest(L.ptr(m.params), L.ptr(grads_low), L.ptr(drgb), L.ptr(view_dir), L.ptr(self.m), L.ptr(self.v),
                                                 m.n, m.n_pad, C.byref(self.ap), int(sh_degree), L.stream_ptr()), "omfs_adam_step_sh_rest")
+
+    def apply_sh_rest_views(self, gauss_c, face_xf_all: torch.Tensor, n_faces: int, cam_pos_table: torch.Tensor, view_set, drgb_all: torch.Tensor,
+                            sh_degree: int):
+        """Compact data-parallel exchange: the summed gradient of the 45 higher SH planes over the ranks' views, rebuilt from the
+        gathered dL/dcolour planes AND consumed by the Adam update in one launch (omfs_adam_step_sh_rest_views)."""
+        L.check(L.load().omfs_adam_step_sh_rest_views(gauss_c, L.ptr(face_xf_all), int(n_faces), L.ptr(cam_pos_table), view_set, L.ptr(drgb_all),
+                                                      int(sh_degree), L.ptr(self.m), L.ptr(self.v), C.byref(self.ap), L.stream_ptr()),
+                "omfs_adam_step_sh_rest_views")
 
     def apply_range(self, grad_shard: torch.Tensor, offset: int, count: int):
         """The update on the flat range [offset, offset + count) of the [59][n_pad] buffers; grad_shard holds that range's

@@ -114,20 +114,27 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
         with open(path, "wb") as f:
             f.writelines(IO.png_parts_from_zlib_stream(r.fetch_png_stream(k, event), w, h))
 
-    for idx in mine:
-        view = View(cams[idx], split["timestep_of_frame"][idx])
-        if len(pending) >= n_slots:                           # the pinned ring is reused: keep at most n_slots frames in flight
-            pending.pop(0).result()
-        k, event = r.render_png_stream(view, n_slots)         # GPU-side scanlines + deflate into ring slot k
-        pending.append(pool.submit(encode_and_write, out_dir / "renders" / f"{idx:05d}.png", k, event))
-        # gt/: the target the trainer was shown for this frame -- resized to the training resolution, matted on the run's
-        # background (engine/targets.py) -- so an evaluator compares like with like (validation_reporting.py:60-78)
-        if os.path.exists(os.path.join(args.source_path, split["frames"][idx]["file_path"])):
-            rgb, mask = TG.load_frame_pixels(args.source_path, split["frames"][idx])
-            gt = TG.prepare_target(rgb, mask, w, h, bg, as_u8=True).cpu().numpy()
-            pending_gt.append(pool.submit(IO.write_png, out_dir / "gt" / f"{idx:05d}.png", gt))
-    for f in pending + pending_gt:
-        f.result()
+    while True:
+        for idx in mine:
+            view = View(cams[idx], split["timestep_of_frame"][idx])
+            if len(pending) >= n_slots:                           # the pinned ring is reused: keep at most n_slots frames in flight
+                pending.pop(0).result()
+            k, event = r.render_png_stream(view, n_slots)         # GPU-side scanlines + deflate into ring slot k
+            pending.append(pool.submit(encode_and_write, out_dir / "renders" / f"{idx:05d}.png", k, event))
+            # gt/: the target the trainer was shown for this frame -- resized to the training resolution, matted on the run's
+            # background (engine/targets.py) -- so an evaluator compares like with like (validation_reporting.py:60-78)
+            if os.path.exists(os.path.join(args.source_path, split["frames"][idx]["file_path"])):
+                rgb, mask = TG.load_frame_pixels(args.source_path, split["frames"][idx])
+                gt = TG.prepare_target(rgb, mask, w, h, bg, as_u8=True).cpu().numpy()
+                pending_gt.append(pool.submit(IO.write_png, out_dir / "gt" / f"{idx:05d}.png", gt))
+        for f in pending + pending_gt:
+            f.result()
+        pending, pending_gt = [], []
+        if not r.overflowed():
+            break
+        # the default pair capacity is sized for a typical head (20 pairs per Gaussian at 1080p); a scene beyond it rendered empty
+        # lists from the overflowing frame on: grow the buffers and render this rank's frames of the split again
+        print(f"[engine] tile-list capacity exceeded: {r.grow_dup_capacity(2.0)} pairs now, rendering the split again", flush=True)
     pool.shutdown()
     r.check_status()
     return len(mine)

@@ -19,6 +19,7 @@ from omfs_4d_video_gen_amd.engine.trainer import Renderer, Trainer, View  # noqa
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--pretrain", type=int, default=100)
+ap.add_argument("--mode", default="both", choices=("both", "counters", "timeline"), help="what the experiments library was built with: the per-step counters slow the kernel a hundredfold, so the timeline is taken from a build without them")
 a = ap.parse_args()
 N, W, H = 300000, 1920, 1080
 srig = synthetic.make_rig(0)
@@ -45,17 +46,21 @@ cnt = (ctypes.c_ulonglong * 32)()
 for _ in range(2):
     L.composite_bwd("entries", cam, r.rb, gb, s)
 torch.cuda.synchronize()
-ce.omfs_experiment_debug_counters(cnt, 1)
 NTL = 1 << 19
 buf = (ctypes.c_ulonglong * (3 * NTL))()
-ce.omfs_experiment_debug_timeline(2, buf, NTL, 1)
+if a.mode != "timeline":
+    ce.omfs_experiment_debug_counters(cnt, 1)
+if a.mode != "counters":
+    ce.omfs_experiment_debug_timeline(2, buf, NTL, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 L.composite_bwd("entries", cam, r.rb, gb, s)
 e1.record()
 torch.cuda.synchronize()
-ce.omfs_experiment_debug_counters(cnt, 0)
-assert ce.omfs_experiment_debug_timeline(2, buf, NTL, 2) == 0
+if a.mode != "timeline":
+    ce.omfs_experiment_debug_counters(cnt, 0)
+if a.mode != "counters":
+    assert ce.omfs_experiment_debug_timeline(2, buf, NTL, 2) == 0
 b = [int(x) for x in cnt]
 units, passes, pix, ents, wsteps, hit_steps, hit_lanes = b[14], b[15], b[8], b[9], b[0], b[1], b[2]
 # the same scene seen by the product kernel: visited entries per tile (depth), pixels
@@ -68,10 +73,15 @@ raw = np.frombuffer(buf, dtype=np.uint64)
 tt = raw[:2 * NTL].reshape(2, NTL).astype(np.int64)
 work = raw[2 * NTL:2 * NTL + NTL // 2].view(np.uint32)[:NTL].astype(np.int64)
 ok = tt[0] > 0
+if not ok.any():
+    ok[:] = True
 t0, t1, w = tt[0][ok], tt[1][ok], work[ok]
 dur = (t1 - t0) * 10e-3
-span = (t1.max() - t0.min()) * 10e-3
+span = max((t1.max() - t0.min()) * 10e-3, 1e-9)
 real = w > 0
+if not real.any():
+    real[:] = True
+edges = np.linspace(t0.min(), t1.max(), 11)
 out = {
     "kernel": "composite_bwd_entries_kernel (debug-counter + timeline build: slower than the product build)",
     "launch_ms_debug_build": round(e0.elapsed_time(e1), 4), "D": int(r.tile_start[-1]), "D_visit_tile_level": int(depth.sum()),
@@ -83,6 +93,8 @@ out = {
                  "steps_per_working_wave": round(float(w[real].mean()), 1), "lifetime_us_p50": round(float(np.percentile(dur[real], 50)), 2),
                  "lifetime_us_p90": round(float(np.percentile(dur[real], 90)), 2), "lifetime_us_max": round(float(dur[real].max()), 2),
                  "ns_per_wave_step": round(float(1e3 * dur[real].sum() / w[real].sum()), 1),
-                 "resident_working_waves_per_simd": round(float(dur[real].sum() / (span * 1024)), 2)},
+                 "resident_working_waves_per_simd": round(float(dur[real].sum() / (span * 1024)), 2),
+                 "working_waves_in_flight_per_tenth_of_the_span": [int(((t0[real] < edges[i + 1]) & (t1[real] > edges[i])).sum()) for i in range(10)]},
+    "mode": a.mode,
 }
 print(json.dumps(out))
