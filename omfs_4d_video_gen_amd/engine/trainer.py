@@ -83,6 +83,16 @@ def _cached_camera(cache: dict, camera: dict, sh_degree: int, bg):
     return hit[1]
 
 
+class _Done:
+    """Stands in for the work handle of a collective that was enqueued in stream order."""
+
+    def wait(self):
+        return None
+
+
+_DONE = _Done()
+
+
 class Trainer:
     def __init__(self, rig: FlameRig, flame_params: dict, gaussians: dict, views: list, width: int, height: int,
                  bg=(0.0, 0.0, 0.0), device="cuda", iterations: int = 30000, lambda_dssim: float = 0.2,
@@ -149,8 +159,8 @@ class Trainer:
         # torch.distributed -- the path a host without PyTorch takes; the process group then only carries the communicator's id
         self._abi_comm = None
         if self.dp and os.environ.get("OMFS_DP_IMPL", "torch") == "abi":
-            if self.compact_dp or self.sharded_dp:
-                raise ValueError("OMFS_DP_IMPL=abi drives the full exchange: set OMFS_DP_EXCHANGE=full")
+            if self.sharded_dp:
+                raise ValueError("OMFS_DP_IMPL=abi drives the full or the compact exchange: set OMFS_DP_EXCHANGE=full or compact")
             import atexit
             from .distributed import AbiComm
             self._abi_comm = AbiComm(self.rank, self.world, process_group)
@@ -277,6 +287,15 @@ class Trainer:
                              float(self.lambda_dssim), L.ptr(r.loss), L.ptr(r.loss_scratch))
             hit = self._view_steps[key] = (vs, g, gb, rp, cam, fxf)
         return hit[0]
+
+    def _allgather_drgb(self):
+        """All ranks' dL/dcolour planes (compact exchange): asynchronously on torch's collective stream -- it then runs under
+        omfs_project_bwd at the price of two stream hand-overs -- or, with the C ABI's own communicator, in stream order."""
+        if self._abi_comm is not None:
+            self._abi_comm.allgather_(self.drgb_all, self.drgb_local)
+            return _DONE
+        from .distributed import allgather_into_
+        return allgather_into_(self.drgb_all, self.drgb_local, self.pg, async_op=True)
 
     def view_for_step(self, step: int) -> View:
         from .distributed import view_index
@@ -530,7 +549,7 @@ class Trainer:
             L.check(lib.omfs_view_forward_composite_bwd(vs, L.ptr(self.drgb_local) if self.compact_dp else 0, s), "omfs_view_forward_composite_bwd")
             if self.compact_dp:
                 from .distributed import allgather_into_
-                gather = allgather_into_(self.drgb_all, self.drgb_local, self.pg, async_op=True)
+                gather = self._allgather_drgb()
             L.check(lib.omfs_view_project_bwd(vs, s), "omfs_view_project_bwd")
         else:
             r.project(self.model, fxf, cam); tm.mark("project")
@@ -557,7 +576,7 @@ class Trainer:
             if self.compact_dp:            # dL/dcolour is final here: its all-gather runs under project_bwd
                 from .distributed import allgather_into_
                 L.check(lib.omfs_extract_drgb(r.rb, L.ptr(r.dsplat), self.model.n, self.model.n_pad, L.ptr(self.drgb_local), s), "omfs_extract_drgb")
-                gather = allgather_into_(self.drgb_all, self.drgb_local, self.pg, async_op=True)
+                gather = self._allgather_drgb()
             rp = L.RegParamsC(*[float(x) for x in self.reg], L.ptr(r.n_visible))
             L.check(lib.omfs_project_bwd(g, L.ptr(fxf), cam, r.rb, gb, rp, s), "omfs_project_bwd"); tm.mark("project_bwd")
         if ft_pipe:
@@ -591,7 +610,12 @@ class Trainer:
             if self.compact_dp:
                 # 14 contiguous planes, asynchronously: the 45 rebuilt SH planes are updated while they are on the links
                 # (with FLAME fine-tuning: the FLAME gradients in front of plane 0 travel in the same collective)
-                reduce14 = allreduce_sum_(self.grad_store[:self._grad_head + (P_SH + 3) * self.model.n_pad], self.pg, async_op=True)
+                low = self.grad_store[:self._grad_head + (P_SH + 3) * self.model.n_pad]
+                if self._abi_comm is not None:      # in stream order on the compute stream: no hand-over, no overlap either
+                    self._abi_comm.allreduce_(low)
+                    reduce14 = _DONE
+                else:
+                    reduce14 = allreduce_sum_(low, self.pg, async_op=True)
                 gather.wait()
                 if not self.dp_fold:       # OMFS_DP_FOLD=0: the rebuilt planes through the gradient buffer (two launches, rounds 2-4)
                     L.check(lib.omfs_sh_rest_grads(g, L.ptr(face_xf), self.dflame.rig.n_faces, L.ptr(self.cam_pos_table), pat[1],

@@ -163,16 +163,20 @@ def image_parity(image, final_T, n_contrib, ref: dict, max_near_fraction: float 
 
 
 def assert_same_up_to_atomic_noise(a, b, mean_rel, tail_abs, what=""):
-    """Two runs of the same training that differ only by the order of float atomics: Adam's sign-like first steps amplify that
-    noise element-wise (a single parameter can end a few learning-rate steps apart), so the discriminating bound is the MEAN
-    (a run that differs for real sits an order of magnitude further away); the tail is held at the 99.9th percentile, and the
-    maximum only against garbage (a handful of elements may sit 2 x lr x steps apart)."""
+    """Two runs of the same training in the DEFAULT mode, which differ only by the order of float atomics: Adam's sign-like first
+    steps amplify that noise element-wise (a single parameter can end a few learning-rate steps apart), so the discriminating bound
+    is the MEAN (a run that differs for real sits an order of magnitude further away); the tail is held at the 99.9th percentile, the
+    number of elements beyond four times the tail bound at 1e-4 of the tensor (a resume or rollback that mis-restores a handful of
+    Gaussians' 59 parameters lands here), and the maximum only against garbage.  The EXACT form of these comparisons -- resume ==
+    uninterrupted, rollback + redo == clean run, bit for bit -- runs under OMFS_DETERMINISTIC=1 (tests/test_gpu_deterministic.py)."""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     d = np.abs(a - b)
     assert np.isfinite(d).all(), what
     scale = max(1.0, float(np.abs(b).max()))
     q = float(np.quantile(d, 0.999)) if d.size else 0.0
-    assert d.mean() <= mean_rel * scale and q <= tail_abs and d.max() <= 20.0 * tail_abs + 1e-3, (what, float(d.mean()), q, float(d.max()), scale)
+    far = int((d > 4.0 * tail_abs).sum())
+    assert d.mean() <= mean_rel * scale and q <= tail_abs and far <= max(3, int(1e-4 * d.size)) and d.max() <= 20.0 * tail_abs + 1e-3, \
+        (what, float(d.mean()), q, far, float(d.max()), scale)
 
 
 def build_cli_dataset(d):

@@ -159,8 +159,8 @@ def test_sharded_exchange_resumes_from_whole_moments_like_a_continuous_run():
 
 def _worker_rccl(port, q, exchange):
     impl = "torch"
-    if exchange == "full-abi":            # the full exchange issued by the library's own communicator (omfs_rccl_allreduce_grads)
-        exchange, impl = "full", "abi"
+    if exchange.endswith("-abi"):         # the exchange issued by the library's own communicator (omfs_rccl_allreduce_grads / _allgather)
+        exchange, impl = exchange[:-4], "abi"
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", OMFS_DP_EXCHANGE=exchange,
                       OMFS_DP_FORCE="1", OMFS_DP_IMPL=impl)
     torch.cuda.set_device(0)
@@ -180,7 +180,7 @@ def _worker_rccl(port, q, exchange):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["compact", "full", "sharded", "full-abi"])
+@pytest.mark.parametrize("exchange", ["compact", "full", "sharded", "full-abi", "compact-abi"])
 def test_exchange_path_over_rccl_with_one_rank_equals_the_plain_step(exchange):
     """The collectives of the data-parallel step issued on the real backend ("nccl" = RCCL; one rank is all a one-GPU
     box has): asynchronous all-gather under project_bwd, asynchronous all-reduce of the 14 planes under the SH update.
