@@ -38,6 +38,7 @@ def parse(argv=None):
     p.add_argument("--resolution", "-r", type=int, default=None, help="default: the resolution the model was trained at (cfg_args.json)")
     p.add_argument("--sh_degree", type=int, default=3)
     p.add_argument("--png_workers", type=int, default=8)
+    p.add_argument("--dup_capacity", type=int, default=0, help="initial (Gaussian, tile) pair capacity (0 = sized from the cloud and the image; grown, and the split rendered again, on overflow)")
     args, unknown = p.parse_known_args(argv)
     if unknown:
         print(f"[engine] ignoring unknown arguments: {unknown}")
@@ -103,7 +104,8 @@ def render_split(args, split_name: str, it: int, rank: int, world: int):
     (out_dir / "gt").mkdir(parents=True, exist_ok=True)
     flame = tuned_flame(Path(args.model_path) / "point_cloud" / f"iteration_{it}", split["flame"])
     # the frames of a sequence are independent: three streams with raster buffers of their own (see Renderer)
-    r = Renderer(load_rig(), flame, g, w, h, bg=bg, sh_degree=args.sh_degree, n_streams=int(os.environ.get("OMFS_RENDER_STREAMS", "3")))
+    r = Renderer(load_rig(), flame, g, w, h, bg=bg, sh_degree=args.sh_degree, n_streams=int(os.environ.get("OMFS_RENDER_STREAMS", "3")),
+                 dup_capacity=args.dup_capacity or None)
     pool = ThreadPoolExecutor(max_workers=max(1, args.png_workers))
     pending, pending_gt = [], []
     mine = range(rank, len(cams), world)

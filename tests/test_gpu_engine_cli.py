@@ -226,6 +226,29 @@ def test_renderer_uses_each_frames_own_camera():
             assert torch.equal(a, want[i]) and torch.equal(b.cpu(), want[(i + 2) % T]), (n_streams, i)
 
 
+def test_render_grows_an_exceeded_pair_capacity_and_renders_again(dataset, tmp_path):
+    """engine/render.py with a tile-list capacity far too small (the default is sized close to the heaviest cloud measured, 20 pairs
+    per Gaussian at 1080p, so the path must exist): frames rendered after the overflow hold empty lists; the engine doubles the
+    buffers, renders the split again and every PNG is the SAME BYTES an amply sized run writes."""
+    env = {**os.environ, "OMFS_SYNTHETIC_RIG": "1", "PYTHONPATH": str(ROOT)}
+    eng = ROOT / "omfs_4d_video_gen_amd" / "engine"
+    m = tmp_path / "m"
+    r = subprocess.run([sys.executable, str(eng / "train.py"), "--source_path", str(dataset), "--model_path", str(m), "--bind_to_mesh",
+                        "--white_background", "--n_gaussians", "12000", "--iterations", "20", "--log_every", "10", "--no_densify"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = {}
+    for name, extra in (("small", ["--dup_capacity", "3000"]), ("ample", [])):
+        r = subprocess.run([sys.executable, str(eng / "render.py"), "--source_path", str(dataset), "--model_path", str(m), "--bind_to_mesh",
+                            "--skip_val", "--skip_test", *extra], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+        assert ("tile-list capacity exceeded" in r.stdout) == (name == "small"), r.stdout[-1500:]
+        d = m / "train" / "ours_20" / "renders"
+        outs[name] = {p.name: p.read_bytes() for p in sorted(d.iterdir())}
+        shutil.rmtree(m / "train")
+    assert len(outs["ample"]) > 40 and outs["small"] == outs["ample"]
+
+
 def test_engine_clis_under_a_two_rank_launch(dataset, tmp_path):
     """SURVEY section 8e at the level of the engine's own command lines (configs 3 and 4 in small): `engine/train.py` and `engine/render.py`
     started by `torch.distributed.run --nproc-per-node 2` (both ranks on the box's one card, OMFS_DIST_BACKEND=gloo).  Training:
