@@ -23,7 +23,11 @@ m = rec["modes"]
 single = m["plain"]["ms_per_step"] * 1e3                     # the one-GPU line (in-place SH Adam), us
 fixed = {k: m[k]["ms_per_step"] * 1e3 for k in ("compact", "full", "sharded") if k in m}      # whole step with the exchange's launches, no link time
 S14, S59, s3 = 14 * a.n_pad * 4.0, 59 * a.n_pad * 4.0, 3 * a.n_pad * 4.0
-HIDE_AR, HIDE_AG = 75.0, 42.0       # us of work the asynchronous collectives run under: rebuilt-plane Adam launch; project_bwd
+# us of work the asynchronous collectives run under (engine/trainer.py, data-parallel step with FLAME fine-tuning on, the bench workload):
+# the all-gather of dL/dcolour is issued behind composite_bwd and waited for behind project_bwd (42 us) AND the FLAME backward (33 us: its
+# gradients travel in the all-reduce, so it runs first); the 14-plane all-reduce is issued there and waited for behind the rebuilt-plane
+# Adam launch (75 us)
+HIDE_AR, HIDE_AG = 75.0, 42.0 + 33.0
 lat = a.latency_us
 
 
