@@ -136,6 +136,19 @@ def test_two_ranks_match_single_process_gradient_sum(exchange):
     assert np.allclose(got, p0, rtol=2e-4, atol=2e-6), np.abs(got - p0).max()
 
 
+@pytest.mark.parametrize("exchange", ["full", "sharded"])
+def test_two_ranks_equal_the_single_process_sum_bit_for_bit_when_deterministic(exchange, monkeypatch):
+    """OMFS_DETERMINISTIC=1 makes every gradient a function of the parameters alone (no float-atomic order), so two ranks that
+    all-reduce their views' gradients end on EXACTLY the parameters of one process that adds the same two gradient buffers itself
+    (a + b is the one floating-point sum both form; the compact exchange rebuilds its SH planes with fused multiply-adds over the
+    views and is only close).  The statistical form of this comparison, in the default mode, is the test above."""
+    monkeypatch.setenv("OMFS_DETERMINISTIC", "1")
+    (_, ok0, _, p0), (_, ok1, _, p1) = _run_two_ranks(exchange)
+    assert ok0 and ok1 and np.array_equal(p0, p1)
+    got = _single_process_sum(2)
+    assert np.array_equal(got, p0), float(np.abs(got - p0).max())
+
+
 @pytest.mark.parametrize("exchange", ["compact", "full", "sharded"])
 def test_four_ranks_on_one_card_match_the_four_view_gradient_sum(exchange):
     """The widest rehearsal one card allows (the box admits 6 GPU processes; world size 8 itself is covered on CPU tensors in
