@@ -166,7 +166,7 @@ def assert_same_up_to_atomic_noise(a, b, mean_rel, tail_abs, what=""):
     """Two runs of the same training in the DEFAULT mode, which differ only by the order of float atomics: Adam's sign-like first
     steps amplify that noise element-wise (a single parameter can end a few learning-rate steps apart), so the discriminating bound
     is the MEAN (a run that differs for real sits an order of magnitude further away); the tail is held at the 99.9th percentile, the
-    number of elements beyond four times the tail bound at 1e-4 of the tensor (a resume or rollback that mis-restores a handful of
+    number of elements beyond four times the tail bound at 2e-4 of the tensor (at least 8) (a resume or rollback that mis-restores a handful of
     Gaussians' 59 parameters lands here), and the maximum only against garbage.  The EXACT form of these comparisons -- resume ==
     uninterrupted, rollback + redo == clean run, bit for bit -- runs under OMFS_DETERMINISTIC=1 (tests/test_gpu_deterministic.py)."""
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
@@ -175,7 +175,7 @@ def assert_same_up_to_atomic_noise(a, b, mean_rel, tail_abs, what=""):
     scale = max(1.0, float(np.abs(b).max()))
     q = float(np.quantile(d, 0.999)) if d.size else 0.0
     far = int((d > 4.0 * tail_abs).sum())
-    assert d.mean() <= mean_rel * scale and q <= tail_abs and far <= max(3, int(1e-4 * d.size)) and d.max() <= 20.0 * tail_abs + 1e-3, \
+    assert d.mean() <= mean_rel * scale and q <= tail_abs and far <= max(8, int(2e-4 * d.size)) and d.max() <= 20.0 * tail_abs + 1e-3, \
         (what, float(d.mean()), q, far, float(d.max()), scale)
 
 
