@@ -175,6 +175,8 @@ def assert_same_up_to_atomic_noise(a, b, mean_rel, tail_abs, what=""):
     scale = max(1.0, float(np.abs(b).max()))
     q = float(np.quantile(d, 0.999)) if d.size else 0.0
     far = int((d > 4.0 * tail_abs).sum())
+    print(f"[two-run noise] {what}: mean {d.mean():.3g} (bound {mean_rel * scale:.3g}), p99.9 {q:.3g} (bound {tail_abs:.3g}), "
+          f"beyond 4x the tail bound {far} of {d.size} (bound {max(8, int(2e-4 * d.size))}), max {d.max():.3g} (bound {20.0 * tail_abs + 1e-3:.3g})")
     assert d.mean() <= mean_rel * scale and q <= tail_abs and far <= max(8, int(2e-4 * d.size)) and d.max() <= 20.0 * tail_abs + 1e-3, \
         (what, float(d.mean()), q, far, float(d.max()), scale)
 

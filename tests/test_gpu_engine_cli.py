@@ -130,7 +130,7 @@ def test_finetune_flame_checkpoint_resume_and_tuned_render(dataset, tmp_path, mo
     ga = IO.load_gaussian_ply(a / "point_cloud" / "iteration_40" / "point_cloud.ply")
     gb = IO.load_gaussian_ply(b / "point_cloud" / "iteration_40" / "point_cloud.ply")
     for k in ("xyz", "log_scale", "opacity", "sh"):    # Adam's sign-like first steps amplify the float-atomic noise
-        H.assert_same_up_to_atomic_noise(ga[k], gb[k], 2e-4, 5e-2, k)
+        H.assert_same_up_to_atomic_noise(ga[k], gb[k], 2e-4, 1e-2, k)      # measured: p99.9 <= 6.4e-4, max 1.2e-3 (printed into the test log)
     fa = dict(np.load(a / "point_cloud" / "iteration_40" / "flame_param.npz"))
     fb = dict(np.load(b / "point_cloud" / "iteration_40" / "flame_param.npz"))
     src = dict(np.load(a / "point_cloud" / "iteration_40" / "flame_param_source.npz"))
@@ -163,7 +163,7 @@ def test_overflowed_interval_is_rolled_back_and_redone(dataset, tmp_path):
     # Adam's sign-like first steps amplify the float-atomic noise between two runs (see the resume test): the clouds agree in the
     # mean to a few 1e-4; a run that had KEPT its empty-render steps would sit an order of magnitude further away
     for k in ("params", "adam_m"):
-        H.assert_same_up_to_atomic_noise(ca[k].numpy(), cb[k].numpy(), 3e-4, 0.1, k)
+        H.assert_same_up_to_atomic_noise(ca[k].numpy(), cb[k].numpy(), 3e-4, 0.02, k)      # measured: p99.9 4.6e-3, max 0.089 (one element)
     la = [float(m) for m in re.findall(r"loss=([0-9.]+)", r1.stdout)]
     lb = [float(m) for m in re.findall(r"loss=([0-9.]+)", r2.stdout)]
     assert abs(la[-1] - lb[-1]) < 0.02 * lb[-1]

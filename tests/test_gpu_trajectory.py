@@ -158,7 +158,7 @@ def test_graph_replay_of_whole_iterations_matches_eager_steps(finetune):
     assert lg[-4:].mean() < 0.9 * lg[:4].mean()
     for lo, hi in ((0, 3), (3, 6), (6, 10), (10, 11), (11, 59)):
         a, b = tg.model.params[lo:hi, :n].cpu().numpy(), te.model.params[lo:hi, :n].cpu().numpy()
-        helpers.assert_same_up_to_atomic_noise(a, b, 3e-4, 0.1, lo)
+        helpers.assert_same_up_to_atomic_noise(a, b, 3e-4, 0.02, lo)      # measured: p99.9 <= 3.1e-3, max 0.040
     if finetune:
         for k in ("expr", "pose", "translation"):
             a, b = tg.flame_ft.params[k].cpu().numpy(), te.flame_ft.params[k].cpu().numpy()
