@@ -65,6 +65,8 @@ def parse(argv=None):
                    help="store the cloud along a Morton curve over its parent triangles (measured neutral on MI355X: projection kernels "
                         "gain what the atomic-based binning loses; off by default)")
     p.add_argument("--no_shuffle", action="store_true", help="visit the views in index order instead of a seeded random order per epoch")
+    p.add_argument("--deterministic", action="store_true",
+                   help="bit-reproducible training (= OMFS_DETERMINISTIC=1): fixed-point gradient accumulation instead of float atomics, ~4 %% slower")
     p.add_argument("--target_storage", choices=("auto", "f32", "u8"), default="auto",
                    help="how training images are kept in HBM: fp32 planes, 8-bit RGB expanded per step, or by dataset size")
     args, unknown = p.parse_known_args(argv)
@@ -146,6 +148,8 @@ class Rollback:
 
 def main(argv=None):
     args = parse(argv)
+    if args.deterministic:
+        os.environ["OMFS_DETERMINISTIC"] = "1"       # read by Rasterizer / FlameFineTuner when the trainer is built below
     from omfs_4d_video_gen_amd.engine import io_formats as IO
     from omfs_4d_video_gen_amd.engine.rig_loader import load_rig
     from omfs_4d_video_gen_amd.engine.trainer import Trainer, View

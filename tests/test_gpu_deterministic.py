@@ -130,7 +130,8 @@ def test_resume_equals_the_uninterrupted_run_bit_for_bit(dataset, tmp_path):
               "--flame_trans_lr", "1e-4", "--flame_pose_lr", "1e-4", "--white_background", "--iterations", "40"]
     a, b = tmp_path / "a", tmp_path / "b"
     _cli([*common, "--model_path", str(a), "--checkpoint_iterations", "25", "40"])
-    r2 = _cli([*common, "--model_path", str(b), "--start_checkpoint", str(a / "chkpnt25.pth"), "--checkpoint_iterations", "40"])
+    # the resumed process asks for the mode with the engine's own flag instead of the environment variable
+    r2 = _cli([*common, "--deterministic", "--model_path", str(b), "--start_checkpoint", str(a / "chkpnt25.pth"), "--checkpoint_iterations", "40"], det=False)
     assert "resumed from" in r2.stdout
     ca, cb = torch.load(a / "chkpnt40.pth", weights_only=True), torch.load(b / "chkpnt40.pth", weights_only=True)
     for k in ("params", "adam_m", "adam_v", "binding"):
