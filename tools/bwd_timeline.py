@@ -1,5 +1,5 @@
-"""Debug build only (EXTRA_HIPCC_FLAGS=-DOMFS_DEBUG_TIMELINE): per-wave start / end / visits of composite_bwd for both
-implementations (OMFS_BWD_IMPL) on the bench scene: how many waves do real work, how long they live, what a visit costs.
+"""Debug build only (EXTRA_HIPCC_FLAGS=-DOMFS_DEBUG_TIMELINE): per-wave start / end / visits of the three implementations
+of the composite backward (the product kernel; matrix-core reduction and lanes = entries from libomfs_experiments.so) on the bench scene: how many waves do real work, how long they live, what a visit costs.
 usage (GPU box): python tools/bwd_timeline.py [--pretrain 100]"""
 import argparse
 import ctypes
@@ -35,14 +35,17 @@ gb = L.GradBuffersC(L.ptr(r.dsplat), L.ptr(t.grads), L.ptr(r.dimage), 0, 0, 0)
 cd = ctypes.CDLL(L.LIB_PATH)
 NTL = 1 << 19
 buf = (ctypes.c_ulonglong * (3 * NTL))()
-for impl in ("dpp", "mfma"):
+L.load_experiments()
+ce = ctypes.CDLL(L.EXPERIMENTS_PATH)               # the second implementations stamp the arrays of THEIR library
+for impl in ("dpp", "mfma", "entries"):
+    read = cd.omfs_debug_timeline if impl == "dpp" else ce.omfs_experiment_debug_timeline
     for _ in range(3):
         L.composite_bwd(impl, cam, r.rb, gb, s)
     torch.cuda.synchronize()
-    cd.omfs_debug_timeline(2, buf, NTL, 1)          # reset
+    read(2, buf, NTL, 1)          # reset
     L.composite_bwd(impl, cam, r.rb, gb, s)
     torch.cuda.synchronize()
-    assert cd.omfs_debug_timeline(2, buf, NTL, 2) == 0
+    assert read(2, buf, NTL, 2) == 0
     raw = np.frombuffer(buf, dtype=np.uint64)
     tt = raw[:2 * NTL].reshape(2, NTL).astype(np.int64)
     work = raw[2 * NTL:2 * NTL + NTL // 2].view(np.uint32)[:NTL].astype(np.int64)
