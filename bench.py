@@ -434,6 +434,40 @@ def main():
         "library": _lib_identity(),
     }
 
+    # ---- the collectives of the exchange, timed ALONE on this node (N > 1 only; outside the timed region): the bus bandwidth RCCL
+    # delivers for the compact exchange's two messages is the one unknown of the scaling model (tools/dp_model.py:
+    # >= 6x at 8 ranks needs ~188 GB/s for the 16.8 MB all-reduce), so the line that carries the scaling also carries that figure
+    if world > 1:
+        import torch.distributed as dist
+        n_pad = trainer.model.n_pad
+        ar = torch.zeros(14 * n_pad, device="cuda")
+        ag_in, ag_out = torch.zeros(3 * n_pad, device="cuda"), torch.zeros(world, 3 * n_pad, device="cuda")
+
+        def timed(fn, reps=10):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(); barrier()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            dt_ = torch.tensor([(time.perf_counter() - t) / reps], device="cuda", dtype=torch.float64)
+            dist.all_reduce(dt_, op=dist.ReduceOp.MAX)
+            return float(dt_.item())
+        t_ar = timed(lambda: dist.all_reduce(ar))
+        try:
+            t_ag = timed(lambda: dist.all_gather_into_tensor(ag_out.view(-1), ag_in))
+        except (RuntimeError, NotImplementedError):
+            t_ag = None
+        out["collectives_alone"] = {
+            "backend": backend, "allreduce_bytes": int(ar.numel() * 4), "allreduce_us": round(t_ar * 1e6, 1),
+            "allreduce_busbw_GBs": round(ar.numel() * 4 * 2.0 * (world - 1) / world / t_ar / 1e9, 1),
+            "allgather_bytes_per_rank": int(ag_in.numel() * 4), "allgather_us": round(t_ag * 1e6, 1) if t_ag else None,
+            "allgather_busbw_GBs": round(ag_in.numel() * 4 * (world - 1) / t_ag / 1e9, 1) if t_ag else None,
+            "note": "back-to-back launches of the message alone, max over ranks; busbw as rccl-tests defines it; read against profiles/r05_dp_model.json"}
+        del ar, ag_in, ag_out
+        log("collectives timed")
+
     # ---- aux: render_surgery fps on the same scene (frames shard across ranks, no collective)
     if not args.no_aux:
         # config 3: a render_frames-timestep FLAME sequence (every frame its own pose), cameras cycling over the arc
