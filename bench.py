@@ -244,8 +244,6 @@ def main():
     del tr
 
     log("targets rendered")
-    # upstream's default for --bind_to_mesh (the reference's argv passes no opt-out, train_ghost.py:227-237): the per-timestep
-    # FLAME parameters are optimised with the Gaussians, so FLAME LBS + triangle frames are posed INSIDE the timed step
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -257,6 +255,8 @@ def main():
     # (checked again after it).
     dup_capacity = None
     while True:
+        # upstream's default for --bind_to_mesh (the reference's argv passes no opt-out, train_ghost.py:227-237): the per-timestep
+        # FLAME parameters are optimised with the Gaussians, so FLAME LBS + triangle frames are posed INSIDE the timed step
         trainer = Trainer(rig, seq, g_init, views, W, H, iterations=30000, start_sh_degree=3,
                           rank=rank, world_size=world, process_group=pg, finetune_flame=not args.frozen_flame,
                           coherent_order=args.coherent_order, dup_capacity=dup_capacity)
