@@ -436,13 +436,6 @@ int omfs_adam_step_planes(float* params, const float* grads, float* m, float* v,
  * omfs_adam_step_planes(.., 0, 14) does), so the whole Adam step of an iteration stays one launch.                        */
 int omfs_adam_step_sh_rest(float* params, const float* grads_low, const float* drgb, const float* dir, float* m, float* v, int n,
                            int n_pad, const omfs_adam_params* ap, int sh_degree, void* stream);
-/* omfs_sh_rest_grads + the Adam update of planes 14..58 in ONE launch (ABI 8; what the compact exchange of the trainer calls): the
- * summed gradient of a Gaussian's 45 higher SH coefficients is formed in registers (same expressions, same order, same bits) and
- * consumed on the spot -- the 45 gradient planes are neither written nor read, `grads` is not an argument.  g->params is updated
- * in place; m, v [59][n_pad] Adam moments; ap as for omfs_adam_step (grad_scale = 1 / world size for a mean over the views). */
-int omfs_adam_step_sh_rest_views(const omfs_gaussians* g, const float* face_xf_all, int n_faces, const float* cam_pos_table,
-                                 const omfs_view_set* views, const float* drgb_all, int sh_degree, float* m, float* v,
-                                 const omfs_adam_params* ap, void* stream);
 
 /* The same step on the flat range [offset, offset + count) of the [59][n_pad] buffers (both multiples of 4): the shard a
  * data-parallel rank owns after a reduce-scatter of the gradient ("sharded" exchange: reduce-scatter, Adam on 1/W of the

@@ -144,8 +144,6 @@ SIGNATURES = {
     "omfs_rccl_reduce_scatter": (C.c_int, [c_void_p, c_void_p, c_void_p, C.c_size_t, c_void_p]),
     "omfs_sh_rest_grads": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.c_int, c_void_p, C.POINTER(ViewSetC), c_void_p, C.c_int,
                                      c_void_p, c_void_p]),
-    "omfs_adam_step_sh_rest_views": (C.c_int, [C.POINTER(GaussiansC), c_void_p, C.c_int, c_void_p, C.POINTER(ViewSetC), c_void_p, C.c_int,
-                                               c_void_p, c_void_p, C.POINTER(AdamParamsC), c_void_p]),
     "omfs_face_frames": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, C.c_int, c_void_p, c_void_p]),
     "omfs_face_frames_bwd": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "omfs_face_frames_bwd_fx": (C.c_int, [c_void_p, C.c_int, c_void_p, C.c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

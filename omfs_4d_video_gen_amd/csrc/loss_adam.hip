@@ -458,87 +458,6 @@ __global__ __launch_bounds__(256) void adam_sh_rest_kernel(float4* __restrict__ 
   }
 }
 
-// Compact data-parallel exchange (ABI 8): omfs_sh_rest_grads and the Adam pass of the 45 rebuilt planes in ONE launch, in the shape
-// of adam_sh_rest_kernel: grid = (n_pad / 1024, 5), block row y owns the NINE planes of SH coefficients k = 1 + 3 y .. 3 + 3 y, a
-// thread four consecutive Gaussians with 16-byte accesses to every plane.  The sum over the ranks' views of Y_k(dir_w) * dL/dcolour_w
-// is formed in registers -- each Gaussian's mean is re-posed with every view's triangle frame (one 64-byte gather, L2) as
-// sh_rest_grads_kernel does (project_bwd.hip), the basis by sh_basis_k, the views added in the same order: same bits -- and consumed
-// by adam_kernel's update on the spot: the 45 gradient planes are never written nor read back (2 x 54 MB at 300 k Gaussians) and the
-// step loses a launch.  (First written as one lane per Gaussian walking all 45 planes with 4-byte accesses: 6.6 us SLOWER than the
-// two launches it replaces -- the shape round 3 had already measured out for the single-GPU form.)
-struct ViewSetA {
-  int n_views;
-  int view[16];
-};
-__global__ __launch_bounds__(256) void adam_sh_rest_views_kernel(int n, int n4_per_plane, float4* __restrict__ p, const int32_t* __restrict__ binding,
-                                                                 const float* __restrict__ face_xf_all, int n_faces,
-                                                                 const float* __restrict__ cam_pos_table, ViewSetA vs,
-                                                                 const float4* __restrict__ drgb_all, int ncoef, float4* __restrict__ m,
-                                                                 float4* __restrict__ v, AdamK k) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n4_per_plane) return;
-  const int k0 = 1 + 3 * blockIdx.y;
-  const float4 LX = p[(size_t)(OMFS_P_XYZ + 0) * n4_per_plane + i], LY = p[(size_t)(OMFS_P_XYZ + 1) * n4_per_plane + i],
-               LZ = p[(size_t)(OMFS_P_XYZ + 2) * n4_per_plane + i];
-  const float lx[4] = {LX.x, LX.y, LX.z, LX.w}, ly[4] = {LY.x, LY.y, LY.z, LY.w}, lz[4] = {LZ.x, LZ.y, LZ.z, LZ.w};
-  int face[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) face[e] = 4 * i + e < n ? binding[4 * i + e] : 0;
-  float acc[3][3][4];
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[a][c][e] = 0.f;
-  for (int w = 0; w < vs.n_views; ++w) {
-    const float4* dr = drgb_all + (size_t)w * 3 * n4_per_plane;
-    const float4 G0 = dr[i], G1 = dr[(size_t)n4_per_plane + i], G2 = dr[(size_t)2 * n4_per_plane + i];
-    const float g[3][4] = {{G0.x, G0.y, G0.z, G0.w}, {G1.x, G1.y, G1.z, G1.w}, {G2.x, G2.y, G2.z, G2.w}};
-    const float* cp = cam_pos_table + (size_t)vs.view[w] * 3;
-    const float cpx = cp[0], cpy = cp[1], cpz = cp[2];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float4* fr = reinterpret_cast<const float4*>(face_xf_all) + ((size_t)w * n_faces + face[e]) * 4;
-      const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2], f3 = fr[3];
-      const float sf = f3.x;
-      const float mu0 = fma_(dot3_(f0.x, f0.y, f0.z, lx[e], ly[e], lz[e]), sf, f2.y);
-      const float mu1 = fma_(dot3_(f0.w, f1.x, f1.y, lx[e], ly[e], lz[e]), sf, f2.z);
-      const float mu2 = fma_(dot3_(f1.z, f1.w, f2.x, lx[e], ly[e], lz[e]), sf, f2.w);
-      const float vx = mu0 - cpx, vy = mu1 - cpy, vz = mu2 - cpz;
-      const float vl = sqrtf(fmaxf(vx * vx + vy * vy + vz * vz, 1e-20f));
-      const float x = vx / vl, y = vy / vl, z = vz / vl;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const int kk = k0 + a;
-        const float b = kk < ncoef ? sh_basis_k(kk, x, y, z) : 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[a][c][e] = fma_(b, g[c][e], acc[a][c][e]);
-      }
-    }
-  }
-  auto upd = [&](float& pe, float ge, float& me, float& ve, float lr) {
-    ge *= k.grad_scale;
-    me = fma_(k.b1, me, (1.f - k.b1) * ge);
-    ve = fma_(k.b2, ve, (1.f - k.b2) * ge * ge);
-    const float denom = fma_(sqrtf(ve), k.inv_sqrt_bc2, k.eps);
-    pe = pe - lr * (me / denom);
-  };
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const int plane = OMFS_P_SH + 3 * (k0 + a) + c;
-      const size_t o = (size_t)plane * n4_per_plane + i;
-      const float lr = k.lr_step[plane];
-      float4 pp = p[o], mm = m[o], vv = v[o];
-      upd(pp.x, acc[a][c][0], mm.x, vv.x, lr); upd(pp.y, acc[a][c][1], mm.y, vv.y, lr);
-      upd(pp.z, acc[a][c][2], mm.z, vv.z, lr); upd(pp.w, acc[a][c][3], mm.w, vv.w, lr);
-      p[o] = pp; m[o] = mm; v[o] = vv;
-    }
-  }
-}
-
 // The same update on a flat range [offset, offset + count) of the [59][n_pad] buffers (count, offset multiples of 4):
 // a data-parallel rank that owns one contiguous shard of the reduce-scattered gradient.  p / g / m / v point at the
 // START of the range; the plane of element offset + i selects the learning rate.
@@ -637,30 +556,6 @@ extern "C" int omfs_adam_step_sh_rest(float* params, const float* grads_low, con
   hipLaunchKernelGGL(adam_sh_rest_kernel, dim3(cdiv(n4, 256), grads_low ? 5 + OMFS_P_SH + 3 : 5), dim3(256), 0, (hipStream_t)stream,
                      (float4*)params, (const float4*)drgb, (const float4*)dir, (float4*)m, (float4*)v, n4, k, (sh_degree + 1) * (sh_degree + 1),
                      (const float4*)grads_low);
-  OMFS_CHECK_HIP(hipGetLastError());
-  return OMFS_OK;
-}
-
-extern "C" int omfs_adam_step_sh_rest_views(const omfs_gaussians* g, const float* face_xf_all, int n_faces, const float* cam_pos_table,
-                                            const omfs_view_set* views, const float* drgb_all, int sh_degree, float* m, float* v,
-                                            const omfs_adam_params* ap, void* stream) {
-  OMFS_REQUIRE(g && face_xf_all && cam_pos_table && views && drgb_all && m && v && ap, "null pointer");
-  OMFS_REQUIRE(g->n > 0 && g->n_pad >= g->n && g->n_pad % 256 == 0 && g->params && g->binding && n_faces > 0 && ap->step >= 1, "buffers");
-  OMFS_REQUIRE(views->n_views >= 1 && views->n_views <= 16 && sh_degree >= 0 && sh_degree <= 3, "views");
-  AdamK k;
-  const double bc1 = 1.0 - pow((double)ap->beta1, ap->step), bc2 = 1.0 - pow((double)ap->beta2, ap->step);
-  for (int i = 0; i < OMFS_NPLANES; ++i) k.lr_step[i] = (float)(ap->lr[i] / bc1);
-  k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-  k.b1 = ap->beta1; k.b2 = ap->beta2; k.eps = ap->eps;
-  k.grad_scale = ap->grad_scale;
-  ViewSetA vs;
-  vs.n_views = views->n_views;
-  for (int w = 0; w < 16; ++w) vs.view[w] = w < views->n_views ? views->view[w] : 0;
-  const int n4 = g->n_pad / 4;
-  hipLaunchKernelGGL(adam_sh_rest_views_kernel, dim3(cdiv(n4, 256), 5), dim3(256), 0, (hipStream_t)stream, g->n, n4,
-                     (float4*)const_cast<float*>(g->params),      // the optimiser's view of the cloud: planes 14..58 are updated in place
-                     g->binding, face_xf_all, n_faces, cam_pos_table, vs, (const float4*)drgb_all, (sh_degree + 1) * (sh_degree + 1),
-                     (float4*)m, (float4*)v, k);
   OMFS_CHECK_HIP(hipGetLastError());
   return OMFS_OK;
 }

@@ -278,14 +278,6 @@ class Adam:
         L.check(L.load().omfs_adam_step_sh_rest(L.ptr(m.params), L.ptr(grads_low), L.ptr(drgb), L.ptr(view_dir), L.ptr(self.m), L.ptr(self.v),
                                                 m.n, m.n_pad, C.byref(self.ap), int(sh_degree), L.stream_ptr()), "omfs_adam_step_sh_rest")
 
-    def apply_sh_rest_views(self, gauss_c, face_xf_all: torch.Tensor, n_faces: int, cam_pos_table: torch.Tensor, view_set, drgb_all: torch.Tensor,
-                            sh_degree: int):
-        """Compact data-parallel exchange: the summed gradient of the 45 higher SH planes over the ranks' views, rebuilt from the
-        gathered dL/dcolour planes AND consumed by the Adam update in one launch (omfs_adam_step_sh_rest_views)."""
-        L.check(L.load().omfs_adam_step_sh_rest_views(gauss_c, L.ptr(face_xf_all), int(n_faces), L.ptr(cam_pos_table), view_set, L.ptr(drgb_all),
-                                                      int(sh_degree), L.ptr(self.m), L.ptr(self.v), C.byref(self.ap), L.stream_ptr()),
-                "omfs_adam_step_sh_rest_views")
-
     def apply_range(self, grad_shard: torch.Tensor, offset: int, count: int):
         """The update on the flat range [offset, offset + count) of the [59][n_pad] buffers; grad_shard holds that range's
         (summed) gradient.  Data-parallel "sharded" exchange: moments outside the rank's range are not touched."""

@@ -152,7 +152,6 @@ class Trainer(GraphReplayMixin):
         if mode not in ("compact", "full", "sharded"):
             raise ValueError(f"OMFS_DP_EXCHANGE={mode!r}: expected compact, full or sharded")
         self.compact_dp = self.dp and self.world <= 16 and mode == "compact"
-        self.dp_fold = os.environ.get("OMFS_DP_FOLD", "1") != "0"
         # "sharded": reduce-scatter of the gradient buffer, Adam on this rank's contiguous 1/W of the [59][n_pad] elements,
         # all-gather of the updated parameters (the Adam moments of the other shards are not maintained on this rank)
         self.sharded_dp = self.dp and mode == "sharded"
@@ -479,9 +478,8 @@ class Trainer(GraphReplayMixin):
                 else:
                     reduce14 = allreduce_sum_(low, self.pg, async_op=True)
                 gather.wait()
-                if not self.dp_fold:       # OMFS_DP_FOLD=0: the rebuilt planes through the gradient buffer (two launches, rounds 2-4)
-                    L.check(lib.omfs_sh_rest_grads(g, L.ptr(face_xf), self.dflame.rig.n_faces, L.ptr(self.cam_pos_table), pat[1],
-                                                   L.ptr(self.drgb_all), self.sh_degree, L.ptr(self.grads), s), "omfs_sh_rest_grads")
+                L.check(lib.omfs_sh_rest_grads(g, L.ptr(face_xf), self.dflame.rig.n_faces, L.ptr(self.cam_pos_table), pat[1],
+                                               L.ptr(self.drgb_all), self.sh_degree, L.ptr(self.grads), s), "omfs_sh_rest_grads")
             elif self.sharded_dp:
                 from .distributed import reduce_scatter_sum_
                 flat = self.grads.view(-1)
@@ -503,10 +501,7 @@ class Trainer(GraphReplayMixin):
         self.opt.set_lr(self.lr_planes)
         if self.compact_dp:
             self.opt.begin_step(1.0 / self.world)
-            if self.dp_fold:    # rebuild + update in ONE launch: the 45 gradient planes are never written (omfs_adam_step_sh_rest_views)
-                self.opt.apply_sh_rest_views(g, face_xf, self.dflame.rig.n_faces, self.cam_pos_table, pat[1], self.drgb_all, self.sh_degree)
-            else:
-                self.opt.apply_planes(self.grads, P_SH + 3, NPLANES - (P_SH + 3))     # the rebuilt SH planes
+            self.opt.apply_planes(self.grads, P_SH + 3, NPLANES - (P_SH + 3))     # the rebuilt SH planes
             reduce14.wait()
             self.opt.apply_planes(self.grads, 0, P_SH + 3)
         elif self.sharded_dp:

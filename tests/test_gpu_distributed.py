@@ -261,21 +261,6 @@ def test_three_exchange_modes_give_the_same_replicas():
         assert np.allclose(ends[mode], ends["compact"], rtol=2e-4, atol=2e-6), (mode, np.abs(ends[mode] - ends["compact"]).max())
 
 
-def test_folded_rebuild_and_adam_equals_the_two_launch_path(monkeypatch):
-    """Compact exchange: omfs_adam_step_sh_rest_views (the 45 higher SH gradients of ALL ranks' views rebuilt in registers and consumed
-    by the Adam update in one launch; the default) against omfs_sh_rest_grads + omfs_adam_step_planes through the gradient buffer
-    (OMFS_DP_FOLD=0).  Same expressions in the same order: with the backward pass made order-independent (OMFS_DETERMINISTIC=1)
-    the two runs end on the SAME bits, FLAME fine-tuning included."""
-    monkeypatch.setenv("OMFS_DETERMINISTIC", "1")
-    ends = {}
-    for fold in ("1", "0"):
-        monkeypatch.setenv("OMFS_DP_FOLD", fold)
-        (_, ok0, _, p0), (_, ok1, _, p1) = _run_two_ranks("compact", finetune=True)
-        assert ok0 and ok1 and np.array_equal(p0, p1), fold
-        ends[fold] = p0
-    assert np.array_equal(ends["1"], ends["0"]), float(np.abs(ends["1"] - ends["0"]).max())
-
-
 def test_bench_two_ranks_end_to_end_on_one_card():
     """`python bench.py --gpus 2 ...` end to end: the parent starts two ranks, both share the box's one card
     (OMFS_DIST_BACKEND=gloo: functional rehearsal, no RCCL link involved), rank 0 prints ONE JSON line that says what ran."""

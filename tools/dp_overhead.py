@@ -37,7 +37,6 @@ def run(mode, steps):
     if not mode.startswith("plain"):
         os.environ["OMFS_DP_FORCE"] = "1"
         os.environ["OMFS_DP_EXCHANGE"] = "full" if mode.startswith("full") else ("compact" if mode.startswith("compact") else mode)
-        os.environ["OMFS_DP_FOLD"] = "0" if mode == "compact_two_launches" else "1"     # round 5: rebuild + Adam of the 45 SH planes in one launch
         pg = dist.group.WORLD
     else:
         os.environ.pop("OMFS_DP_FORCE", None)
@@ -70,7 +69,7 @@ def main():
     # plain = the single-GPU step as benchmarked (45 SH gradient planes formed inside the Adam launch); plain_all_planes = the
     # same with all 59 planes through the gradient buffer, which is what every exchange mode starts from; full-abi = the full
     # exchange issued by the library's own communicator (omfs_rccl_allreduce_grads) instead of torch.distributed
-    out = {m: run(m, a.steps) for m in ("plain", "plain_all_planes", "compact", "compact_two_launches", "compact-abi", "full", "full-abi", "sharded")}
+    out = {m: run(m, a.steps) for m in ("plain", "plain_all_planes", "compact", "compact-abi", "full", "full-abi", "sharded")}
     base = out["plain_all_planes"]["ms_per_step"]
     rec = {"workload": "bench default (300k Gaussians, 1920x1080, 16 views, FLAME fine-tuning on)", "steps": a.steps, "modes": out,
            "overhead_us_over_plain_all_planes": {m: round((v["ms_per_step"] - base) * 1e3, 1) for m, v in out.items() if not m.startswith("plain")},
