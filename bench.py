@@ -418,8 +418,8 @@ def main():
                                f"SH degree 3, L1+D-SSIM, Adam, fixed N (no densification), "
                                + ("fixed FLAME sequence" if args.frozen_flame else "FLAME-parameter fine-tuning on (upstream default): FLAME LBS + frames + their backward in every step"),
                    "n_gaussians": N, "width": W, "height": H, "views": args.views, "tile_pairs_D": D,
-                   "parallelism": (f"dp{world} (views sharded; RCCL all-reduce of 14 planes = {14 * trainer.model.n_pad * 4 / 1e6:.1f} MB "
-                                   f"+ all-gather of {3 * trainer.model.n_pad * 4 / 1e6:.1f} MB dL/dcolour per rank, 45 SH planes rebuilt locally)"
+                   "parallelism": (f"dp{world} (views sharded; RCCL all-reduce of 11 planes = {11 * trainer.model.n_pad * 4 / 1e6:.1f} MB "
+                                   f"+ all-gather of {3 * trainer.model.n_pad * 4 / 1e6:.1f} MB dL/dcolour per rank, 48 SH planes rebuilt locally)"
                                    if trainer.compact_dp else
                                    f"dp{world} (views sharded, RCCL all-reduce of {59 * trainer.model.n_pad * 4 / 1e6:.1f} MB grads)")
                    if world > 1 else "single GPU"},
@@ -436,11 +436,11 @@ def main():
 
     # ---- the collectives of the exchange, timed ALONE on this node (N > 1 only; outside the timed region): the bus bandwidth RCCL
     # delivers for the compact exchange's two messages is the one unknown of the scaling model (tools/dp_model.py:
-    # >= 6x at 8 ranks needs ~188 GB/s for the 16.8 MB all-reduce), so the line that carries the scaling also carries that figure
+    # >= 6x at 8 ranks needs ~165 GB/s for the 13.2 MB all-reduce), so the line that carries the scaling also carries that figure
     if world > 1:
         import torch.distributed as dist
         n_pad = trainer.model.n_pad
-        ar = torch.zeros(14 * n_pad, device="cuda")
+        ar = torch.zeros(11 * n_pad, device="cuda")
         ag_in, ag_out = torch.zeros(3 * n_pad, device="cuda"), torch.zeros(world, 3 * n_pad, device="cuda")
 
         def timed(fn, reps=10):

@@ -338,10 +338,11 @@ int omfs_project_bwd(const omfs_gaussians* g, const float* face_xf, const omfs_c
                      const omfs_raster_buffers* rb, const omfs_grad_buffers* gb,
                      const omfs_reg_params* reg, void* stream);
 
-/* Data-parallel exchange in compact form.  The gradient of the SH coefficients of degree >= 1 is a rank-1 product per
- * Gaussian and view: d SH[k][c] = Y_k(dir) * dL/dcolour[c].  Every rank holds the same parameters, triangle frames and
+/* Data-parallel exchange in compact form.  The gradient of every SH coefficient is a rank-1 product per Gaussian and view:
+ * d SH[k][c] = Y_k(dir) * dL/dcolour[c] (Y_0 = the constant C0).  Every rank holds the same parameters, triangle frames and
  * cameras, so it can rebuild the sum over all ranks' views from the gathered dL/dcolour alone:
- *   grads[(14 + 3(k-1) + c) * n_pad + i] = sum_w Y_k(dir_w(i)) * drgb_all[w][c][i],   k = 1..15
+ *   grads[(11 + 3 k + c) * n_pad + i] = sum_w Y_k(dir_w(i)) * drgb_all[w][c][i],   k = 0..15   (ABI 8: k = 0 included, so only
+ * the 11 geometry / opacity planes travel in the all-reduce; ABI <= 7 rebuilt k = 1..15 and all-reduced 14 planes)
  * face_xf_all [n_views][n_faces][16] (the views' timesteps), cam_pos_table [*][3] indexed by views->view[w],
  * drgb_all [n_views][3][n_pad].  Identical on every rank (same order of summation). */
 typedef struct omfs_view_set {

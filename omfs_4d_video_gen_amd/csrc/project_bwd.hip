@@ -303,8 +303,9 @@ struct ViewSetK {
   int view[16];
 };
 
-// Sum over the views of Y_k(dir_w) * dL/dcolour_w for the SH coefficients of degree >= 1 (planes 14..58): one lane
-// per Gaussian, the mean is re-posed with each view's triangle frame (64-byte gather, L2) exactly as project_bwd does.
+// Sum over the views of Y_k(dir_w) * dL/dcolour_w for ALL 16 SH coefficients (planes 11..58; round 5: degree 0 too -- its basis is
+// the constant C0, so the three SH-dc planes need not travel in the all-reduce either: 11 planes instead of 14 on the links): one
+// lane per Gaussian, the mean is re-posed with each view's triangle frame (64-byte gather, L2) exactly as project_bwd does.
 __global__ __launch_bounds__(256) void sh_rest_grads_kernel(int n, int n_pad, const float* __restrict__ params,
                                                             const int32_t* __restrict__ binding, const float* __restrict__ face_xf_all,
                                                             int n_faces, const float* __restrict__ cam_pos_table, ViewSetK vs,
@@ -314,9 +315,9 @@ __global__ __launch_bounds__(256) void sh_rest_grads_kernel(int n, int n_pad, co
   const float l[3] = {params[(size_t)(OMFS_P_XYZ + 0) * n_pad + i], params[(size_t)(OMFS_P_XYZ + 1) * n_pad + i],
                       params[(size_t)(OMFS_P_XYZ + 2) * n_pad + i]};
   const int face = binding[i];
-  float acc[15][3];
+  float acc[15][3], acc0[3] = {0.f, 0.f, 0.f};
   for (int k = 0; k < 15; ++k) acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
-  constexpr float C1 = 0.4886025119029199f;
+  constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
   constexpr float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
   constexpr float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
                            -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(256) void sh_rest_grads_kernel(int n, int n_pad, co
     const float* dr = drgb_all + (size_t)w * 3 * n_pad;
     const float g0 = dr[i], g1 = dr[(size_t)n_pad + i], g2 = dr[(size_t)2 * n_pad + i];
     if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;
+    acc0[0] = fma_(C0, g0, acc0[0]); acc0[1] = fma_(C0, g1, acc0[1]); acc0[2] = fma_(C0, g2, acc0[2]);   // degree 0: project_bwd's C0 * dL/dcolour
     const float4* fr = reinterpret_cast<const float4*>(face_xf_all) + ((size_t)w * n_faces + face) * 4;
     const float4 f0 = fr[0], f1 = fr[1], f2 = fr[2], f3 = fr[3];
     const float Rf[9] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w, f2.x};
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(256) void sh_rest_grads_kernel(int n, int n_pad, co
       acc[k][0] = fma_(b, g0, acc[k][0]); acc[k][1] = fma_(b, g1, acc[k][1]); acc[k][2] = fma_(b, g2, acc[k][2]);
     }
   }
+  for (int c = 0; c < 3; ++c) grads[(size_t)(OMFS_P_SH + c) * n_pad + i] = acc0[c];
   for (int k = 0; k < 15; ++k)
     for (int c = 0; c < 3; ++c) grads[(size_t)(OMFS_P_SH + 3 * (k + 1) + c) * n_pad + i] = acc[k][c];
 }

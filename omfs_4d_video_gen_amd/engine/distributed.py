@@ -2,9 +2,9 @@
 
 train_ghost: rank r of W takes view (step*W + r) mod n_views; after the local backward every rank
 holds a full [59][n_pad] gradient buffer; the exchange is either ONE all-reduce (sum) over that buffer ("full") or,
-by default, the compact form (trainer.py): all-reduce of the 14 planes that are not rank-1 (geometry, opacity, SH
-degree 0) + all-gather of each rank's dL/dcolour (3 planes), from which every rank rebuilds the summed gradient of the
-45 higher SH planes itself (omfs_sh_rest_grads) -- 2.3x fewer bytes per rank on the xGMI links at 8 ranks.  Then every
+by default, the compact form (trainer.py): all-reduce of the 11 planes that are not rank-1 (geometry, opacity) + all-gather of
+each rank's dL/dcolour (3 planes), from which every rank rebuilds the summed gradient of all 48 SH planes itself
+(omfs_sh_rest_grads; degree 0 too since round 5: its basis is a constant) -- 2.4x fewer bytes per rank on the xGMI links at 8 ranks.  Then every
 rank applies the same Adam step with grad_scale = 1/W, so replicas stay bit-identical.  A third form ("sharded",
 SURVEY.md section 8e): reduce-scatter of the whole buffer, Adam on the rank's 1/W of the elements (omfs_adam_step_range), all-gather
 of the updated parameters -- the bytes of "full" on the links, Adam traffic divided by W.

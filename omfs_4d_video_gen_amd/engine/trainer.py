@@ -469,9 +469,9 @@ class Trainer(GraphReplayMixin):
         if self.dp:
             from .distributed import allgather_into_, allreduce_sum_
             if self.compact_dp:
-                # 14 contiguous planes, asynchronously: the 45 rebuilt SH planes are updated while they are on the links
+                # 11 contiguous planes, asynchronously: the 48 rebuilt SH planes are updated while they are on the links
                 # (with FLAME fine-tuning: the FLAME gradients in front of plane 0 travel in the same collective)
-                low = self.grad_store[:self._grad_head + (P_SH + 3) * self.model.n_pad]
+                low = self.grad_store[:self._grad_head + P_SH * self.model.n_pad]     # 11 planes: xyz, scale, rotation, opacity
                 if self._abi_comm is not None:      # in stream order on the compute stream: no hand-over, no overlap either
                     self._abi_comm.allreduce_(low)
                     reduce14 = _DONE
@@ -501,9 +501,9 @@ class Trainer(GraphReplayMixin):
         self.opt.set_lr(self.lr_planes)
         if self.compact_dp:
             self.opt.begin_step(1.0 / self.world)
-            self.opt.apply_planes(self.grads, P_SH + 3, NPLANES - (P_SH + 3))     # the rebuilt SH planes
+            self.opt.apply_planes(self.grads, P_SH, NPLANES - P_SH)     # the 48 rebuilt SH planes
             reduce14.wait()
-            self.opt.apply_planes(self.grads, 0, P_SH + 3)
+            self.opt.apply_planes(self.grads, 0, P_SH)
         elif self.sharded_dp:
             from .distributed import allgather_shards_
             S = self._gshard.numel()

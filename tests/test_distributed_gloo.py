@@ -1,5 +1,5 @@
 """CPU, world_size 2 and 8 over gloo: the N>1 path of the engine -- views shard disjointly, the ONE
-all-reduce over the gradient SoA gives the cross-rank sum (also on the 14-plane slice of the compact
+all-reduce over the gradient SoA gives the cross-rank sum (also on the low-plane slice of the compact
 exchange, whose dL/dcolour planes are all-gathered in rank order), replicas that apply the same update stay
 bit-identical, and frames shard without overlap."""
 import os
@@ -35,7 +35,7 @@ def _worker(rank, world, port, q):
         assert replicas_in_sync(grads)
         params -= 0.01 * grads / world              # same update on every rank
         assert replicas_in_sync(params)
-    # compact exchange: 14-plane slice all-reduced in place, dL/dcolour planes gathered in rank order
+    # compact exchange: low-plane slice all-reduced in place, dL/dcolour planes gathered in rank order
     grads = torch.randn(59, n_pad, generator=g)
     local = grads.clone()
     allreduce_sum_(grads[:14])

@@ -196,7 +196,7 @@ def _worker_rccl(port, q, exchange):
 @pytest.mark.parametrize("exchange", ["compact", "full", "sharded", "full-abi", "compact-abi"])
 def test_exchange_path_over_rccl_with_one_rank_equals_the_plain_step(exchange):
     """The collectives of the data-parallel step issued on the real backend ("nccl" = RCCL; one rank is all a one-GPU
-    box has): asynchronous all-gather under project_bwd, asynchronous all-reduce of the 14 planes under the SH update.
+    box has): asynchronous all-gather under project_bwd, asynchronous all-reduce of the 11 geometry / opacity planes under the SH update.
     With one rank the sums are the rank's own gradients, so the trajectory is the single-GPU one."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -249,7 +249,7 @@ def test_c_abi_communicator_collectives_with_one_rank():
 
 
 def test_three_exchange_modes_give_the_same_replicas():
-    """compact (14-plane all-reduce + dL/dcolour all-gather), full (one all-reduce) and sharded (reduce-scatter, Adam on 1/W of
+    """compact (11-plane all-reduce + dL/dcolour all-gather), full (one all-reduce) and sharded (reduce-scatter, Adam on 1/W of
     the elements, all-gather of the parameters): the ranks of each run are bit-identical, and the three runs end in the same
     parameters up to the order in which the float atomics of the backward pass and the collectives add."""
     ends = {}

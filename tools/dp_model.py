@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The data-parallel step model of DESIGN.md section 7, as a script: from the measured single-GPU step and the measured fixed cost of
 each exchange mode on a one-rank RCCL group (profiles/r05_dp_overhead.json) to the step time, the aggregate it/s and the scaling
-at W = 2 / 4 / 8 as a function of the ONE unknown -- the RCCL bus bandwidth the node delivers for a 16.9 MB (compact) or 70.9 MB
+at W = 2 / 4 / 8 as a function of the ONE unknown -- the RCCL bus bandwidth the node delivers for a 13.2 MB (compact) or 70.8 MB
 (full) all-reduce -- and the thresholds the first SCALE record is to be read against.  Nothing here is measured on more than one GPU.
 
   python tools/dp_model.py [profiles/r05_dp_overhead.json] [--single_ms 0.803]
@@ -22,10 +22,10 @@ rec = json.load(open(a.overhead))
 m = rec["modes"]
 single = m["plain"]["ms_per_step"] * 1e3                     # the one-GPU line (in-place SH Adam), us
 fixed = {k: m[k]["ms_per_step"] * 1e3 for k in ("compact", "full", "sharded") if k in m}      # whole step with the exchange's launches, no link time
-S14, S59, s3 = 14 * a.n_pad * 4.0, 59 * a.n_pad * 4.0, 3 * a.n_pad * 4.0
+S14, S59, s3 = 11 * a.n_pad * 4.0, 59 * a.n_pad * 4.0, 3 * a.n_pad * 4.0     # (S14: the low planes of the compact exchange -- 11 since round 5)
 # us of work the asynchronous collectives run under (engine/trainer.py, data-parallel step with FLAME fine-tuning on, the bench workload):
 # the all-gather of dL/dcolour is issued behind composite_bwd and waited for behind project_bwd (42 us) AND the FLAME backward (33 us: its
-# gradients travel in the all-reduce, so it runs first); the 14-plane all-reduce is issued there and waited for behind the rebuilt-plane
+# gradients travel in the all-reduce, so it runs first); the 11-plane all-reduce is issued there and waited for behind the rebuilt-plane
 # Adam launch (75 us)
 HIDE_AG = 42.0 + 33.0
 # the rebuild of the 45 SH planes + their Adam pass, timed alone with W views (profiles/r05_fold_time.json, "two_launches"): the work the
@@ -58,7 +58,7 @@ def bisect(fn, lo=1.0, hi=5000.0):
 
 
 out = {"single_gpu_step_us": round(single, 1), "fixed_step_us_one_rank_group": {k: round(v, 1) for k, v in fixed.items()},
-       "bytes": {"allreduce_14_planes": S14, "allreduce_59_planes": S59, "allgather_per_rank": s3}, "latency_us_per_collective": lat, "per_W": {}}
+       "bytes": {"allreduce_11_planes": S14, "allreduce_59_planes": S59, "allgather_per_rank": s3}, "latency_us_per_collective": lat, "per_W": {}}
 for W in (2, 4, 8):
     peak = 76.8 * (W - 1)
     row = {"xgmi_peak_busbw_GBs": round(peak, 1)}
@@ -69,7 +69,7 @@ for W in (2, 4, 8):
         row[f"at_{eff:.2f}_of_peak"] = {"busbw_GBs": round(B, 1), **{mo: {"step_us": round(v, 1), "its": round(W * 1e6 / v), "x_single": round(W * single / v, 2)} for mo, v in t.items()},
                                         "fastest": best}
     # thresholds: the busbw below which ... (compact exchange)
-    row["busbw_GBs_hiding_the_14_plane_allreduce"] = round(bisect(lambda B: S14 * 2 * (W - 1) / W / (B * 1e3) + lat <= REBUILD_ADAM_US[W]), 1)
+    row["busbw_GBs_hiding_the_11_plane_allreduce"] = round(bisect(lambda B: S14 * 2 * (W - 1) / W / (B * 1e3) + lat <= REBUILD_ADAM_US[W]), 1)
     row["busbw_GBs_below_which_full_beats_compact"] = None      # never on xGMI: see note
     target = {2: 1.5, 4: 3.0, 8: 6.0}[W]
     row[f"busbw_GBs_needed_for_{target}x"] = round(bisect(lambda B: W * single / step_us("compact", W, B) >= target), 1)
