@@ -121,6 +121,38 @@ def test_backward_is_linear_in_dimage_and_checkpoints_match(scene):
             assert bool((b[live, 1:] >= a[live, 1:] - 1e-6).all())
 
 
+def test_deterministic_backward_at_full_size(scene):
+    """omfs_composite_bwd with the fixed-point accumulators (omfs_grad_buffers.dsplat_fx) at BASELINE's size, against the loss's
+    own dL/dimage: two launches give the SAME records bit for bit (the float-atomic launches differ run to run), equal to the
+    float path's within its run-to-run spread, nothing saturates (the largest total is far inside +-2^24 / +-2^16), and the
+    accumulators are handed back zeroed."""
+    from omfs_4d_video_gen_amd import _lib as L
+    g, model, rast, fxf, cam = scene
+    img = rast.forward(model, fxf, cam).clone()
+    rast._ensure_bwd()
+    gen = torch.Generator().manual_seed(9)
+    target = (img.cpu() + 0.05 * torch.randn(3, H, W, generator=gen)).clamp(0, 1).cuda().contiguous()
+    rast.loss_l1_ssim(target, 0.2)                          # dL/dimage of the training loss: the scale the fixed point is laid out for
+    fx = torch.zeros(N, 16, dtype=torch.int64, device="cuda")
+    gb_fx = L.GradBuffersC(L.ptr(rast.dsplat), 0, L.ptr(rast.dimage), 0, 0, 0, 0, L.ptr(fx), N)
+    gb_fl = L.GradBuffersC(L.ptr(rast.dsplat), 0, L.ptr(rast.dimage), 0, 0, 0, 0, 0, 0)
+    out = {}
+    for name, gb in (("fx1", gb_fx), ("fx2", gb_fx), ("fl1", gb_fl), ("fl2", gb_fl)):
+        rast.dsplat.zero_()
+        L.check(L.load().omfs_composite_bwd(cam, rast.rb, gb, L.stream_ptr()), "omfs_composite_bwd")
+        torch.cuda.synchronize()
+        out[name] = rast.dsplat[:, :9].clone()
+    rast.dsplat.zero_()
+    assert int(fx.abs().max()) == 0
+    assert torch.equal(out["fx1"], out["fx2"])
+    assert float(out["fx1"].abs().max()) > 0
+    for q in range(9):
+        ref, spread = out["fl1"][:, q], float((out["fl1"][:, q] - out["fl2"][:, q]).abs().max())
+        scale = float(ref.abs().max())
+        assert scale < (2.0 ** 24 if q < 5 else 2.0 ** 16) * 1e-3, (q, scale)           # three orders of magnitude inside the range
+        assert float((out["fx1"][:, q] - ref).abs().max()) <= 4.0 * spread + 1e-5 * scale + 1e-11, (q, spread, scale)
+
+
 def test_loss_gradient_matches_a_directional_difference(scene):
     g, model, rast, fxf, cam = scene
     img = rast.forward(model, fxf, cam).clone()
